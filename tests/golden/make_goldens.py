@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by importing and running the REAL reference (/root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box); the
+resulting .npz files under tests/golden/ are data: inputs + expected outputs.
+
+    python tests/golden/make_goldens.py
+
+What is recorded per case (sets G1..G7):
+  G1 raw tables -> normalised docEmbed/userEmbed          (models/cvae.py:26-41)
+  G2 forward 6-tuple + cond + prior                        (models/pivotcvae.py:229-276)
+  G3 loss terms at n_neg=N and with a recorded mask        (train_generative.py:36-65)
+  G4 every .grad (and which are None), params after 1 and 3 Adam steps
+                                                           (train_generative.py:103,124-134)
+  G5 recommend(): pivot ids, item ids, z_mu, score margins (models/pivotcvae.py:278-296)
+  G6 candidate path p[R,Cn] + recLoss                      (models/pivotcvae.py:265-271)
+  G7 UserResponseModel_MLP click logits                    (env/response_model.py:76-87)
+
+The reference draws eps / Bernoulli masks / Categorical samples from torch's global
+generator.  We do not try to replay that stream on the device: the draws are RECORDED
+here by wrapping the three torch entry points while the reference runs, and fed back to
+the oracle / HIP path as explicit inputs.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+np.float = float  # reference uses the removed alias (train_generative.py:110)
+sys.path.insert(0, REF)
+with contextlib.redirect_stdout(io.StringIO()):
+    import models.pivotcvae as ref_pivot
+    import models.listcvae as ref_list
+    import env.response_model as ref_env
+    import train_generative as ref_tg
+from torch.distributions.categorical import Categorical
+
+
+# ----------------------------------------------------------------------------- recorders
+class Recorder:
+    """Wrap normal_/bernoulli/Categorical.sample so every draw the reference makes is kept."""
+
+    def __init__(self):
+        self.eps, self.masks, self.cats = [], [], []
+
+    def __enter__(self):
+        self._normal = torch.Tensor.normal_
+        self._bern = torch.bernoulli
+        self._sample = Categorical.sample
+        rec = self
+
+        def normal_(t, *a, **k):
+            out = rec._normal(t, *a, **k)
+            rec.eps.append(out.detach().clone())
+            return out
+
+        def bernoulli(t, *a, **k):
+            out = rec._bern(t, *a, **k)
+            rec.masks.append(out.detach().clone())
+            return out
+
+        def sample(d, *a, **k):
+            out = rec._sample(d, *a, **k)
+            rec.cats.append(out.detach().clone())
+            return out
+
+        torch.Tensor.normal_ = normal_
+        torch.bernoulli = bernoulli
+        Categorical.sample = sample
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.normal_ = self._normal
+        torch.bernoulli = self._bern
+        Categorical.sample = self._sample
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def structs(model, S, D, Z, H, HP, no_user):
+    C = S + 1
+    u = 0 if no_user else D
+    enc = [S * D + C + u, H, H]
+    prior = [C + u, HP, HP]
+    if model == "listcvae":
+        return dict(enc=enc, dec=[Z + C + u, H, H, S * D], prior=prior)
+    return dict(enc=enc, psm=[Z + C + u, H, H, D], scm=[Z + C + D + u, H, H, (S - 1) * D], prior=prior)
+
+
+def build(model, st, raw_doc, raw_user, S, D, Z, no_user):
+    C = S + 1
+    if model == "listcvae":
+        return quiet(ref_list.UserListCVAEWithPrior, raw_doc, None if no_user else raw_user, S, D, Z, C,
+                     st["enc"], st["dec"], st["prior"], no_user, "cpu")
+    return quiet(ref_pivot.PIVOTCVAE_MODELS[model], raw_doc, None if no_user else raw_user, S, D, Z, C,
+                 st["enc"], st["psm"], st["scm"], st["prior"], no_user, "cpu")
+
+
+def top2_margin(scores):
+    """scores [R, N] -> (best - second best) per row; used to qualify bit-exact id claims."""
+    v, _ = torch.topk(scores, 2, dim=1)
+    return (v[:, 0] - v[:, 1]).numpy()
+
+
+def make_case(name, model, S, D, Z, N, NU, B, H, HP, no_user, seed, beta=0.001, lr=3e-4, n_neg_part=None):
+    torch.manual_seed(seed)
+    a = (2.0 / D) ** 0.5
+    raw_doc = torch.nn.Embedding(N, D)
+    raw_doc.weight.data.uniform_(-a, a)
+    raw_user = torch.nn.Embedding(NU, D)
+    raw_user.weight.data.uniform_(-a, a)
+    st = structs(model, S, D, Z, H, HP, no_user)
+    m = build(model, st, raw_doc, raw_user, S, D, Z, no_user)
+
+    g = torch.Generator().manual_seed(seed + 1000)
+    s = torch.randint(0, N, (B, S), generator=g)
+    u = torch.randint(0, NU, (B, 1), generator=g)
+    r = (torch.rand(B, S, generator=g) < 0.5).float()
+    # make sure both the all-zero and the all-one response rows are exercised
+    r[0] = 0.0
+    r[-1] = 1.0
+
+    out = {}
+    out["raw_doc"] = raw_doc.weight.detach().numpy().copy()
+    out["raw_user"] = raw_user.weight.detach().numpy().copy()
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.detach().numpy().copy()
+    out["s"], out["r"], out["u"] = s.numpy(), r.numpy(), u.numpy()
+
+    # ---- G2 forward (training mode: true pivot given) + prior
+    torch.manual_seed(seed + 1)
+    with Recorder() as rec, torch.no_grad():
+        p, rx, z, emb, z_mu, z_logvar = m.forward(s, r, u=u)
+        pMu, pLogvar = m.get_prior(r, u)
+        cond = m.get_condition(r)
+    out["fwd/eps"] = rec.eps[0].numpy()
+    if rec.cats:
+        out["fwd/pivot_sample"] = rec.cats[0].numpy()
+    for k, v in dict(p=p, rx=rx, z=z, emb=emb, z_mu=z_mu, z_logvar=z_logvar, pMu=pMu, pLogvar=pLogvar,
+                     cond=cond).items():
+        out["fwd/" + k] = v.numpy().copy()
+
+    batch = {"slates": s.numpy(), "users": u.numpy(), "responses": r.numpy()}
+    CEL = torch.nn.CrossEntropyLoss()
+
+    # ---- G3 loss, full-catalog softmax (n_neg = N: the mask is all ones)
+    torch.manual_seed(seed + 2)
+    m.zero_grad()
+    with Recorder() as rec:
+        loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m, CEL, beta, n_neg=N)
+        loss.backward()
+    out["full/eps"] = rec.eps[0].numpy()
+    if rec.cats:
+        out["full/pivot_sample"] = rec.cats[0].numpy()
+    out["full/loss"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+    # ---- G4 gradients (which are None is part of the contract: SURVEY 0.7)
+    none_grads = []
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            none_grads.append(k)
+        else:
+            out["grad/" + k] = prm.grad.detach().numpy().copy()
+
+    # ---- G3 loss with a recorded Bernoulli mask (n_neg < N)
+    n_neg_part = n_neg_part or max(8, N // 4)
+    torch.manual_seed(seed + 3)
+    m.zero_grad()
+    with Recorder() as rec:
+        loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m, CEL, beta, n_neg=n_neg_part)
+        loss.backward()
+    out["part/eps"] = rec.eps[0].numpy()
+    if rec.cats:
+        out["part/pivot_sample"] = rec.cats[0].numpy()
+    out["part/neg_sample"] = rec.masks[0].numpy().astype(np.uint8)  # the raw Bernoulli draw [R, N]
+    out["part/loss"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+    for k, prm in m.named_parameters():
+        if prm.grad is not None:
+            out["part/grad/" + k] = prm.grad.detach().numpy().copy()
+
+    # ---- G4 Adam: 3 steps on the same batch, n_neg = N, eps recorded per step
+    m2 = build(model, st, raw_doc, raw_user, S, D, Z, no_user)
+    m2.load_state_dict(m.state_dict())
+    opt = torch.optim.Adam(m2.parameters(), lr=lr)
+    torch.manual_seed(seed + 4)
+    for step in range(3):
+        opt.zero_grad()
+        with Recorder() as rec:
+            loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m2, CEL, beta, n_neg=N)
+        loss.backward()
+        opt.step()
+        out[f"adam/eps{step}"] = rec.eps[0].numpy()
+        if rec.cats:
+            out[f"adam/pivot_sample{step}"] = rec.cats[0].numpy()
+        out[f"adam/loss{step}"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+        if step in (0, 2):
+            for k, v in m2.state_dict().items():
+                out[f"adam/step{step + 1}/" + k] = v.detach().numpy().copy()
+
+    # ---- G5 recommend (inference: pivot chosen by the model)
+    ctx = torch.zeros(B, S)
+    ctx[:, : min(3, S)] = 1.0
+    ctx[0] = 0.0
+    uu = None if no_user else u
+    pivots = []
+    hook = m.docEmbed.register_forward_hook(lambda mod, inp, o: pivots.append(inp[0].detach().clone()))
+    torch.manual_seed(seed + 5)
+    with Recorder() as rec, torch.no_grad():
+        items, rec_mu = m.recommend(ctx, uu, return_item=True)
+    hook.remove()
+    out["rec/r"] = ctx.numpy()
+    out["rec/eps"] = rec.eps[0].numpy()
+    out["rec/items"] = items.numpy()
+    out["rec/z_mu"] = rec_mu.numpy()
+    if model != "listcvae":
+        out["rec/pivot"] = pivots[0].numpy()
+        if rec.cats:
+            out["rec/pivot_sample"] = rec.cats[0].numpy()
+    # rx and margins from a replay with the same eps (recommend(return_item=False))
+    torch.manual_seed(seed + 5)
+    with torch.no_grad():
+        rx_rec, _ = m.recommend(ctx, uu, return_item=False)
+        E = m.docEmbed.weight
+        out["rec/rx"] = rx_rec.numpy().copy()
+        out["rec/item_margin"] = top2_margin(rx_rec.reshape(-1, D) @ E.t())
+
+    # ---- G6 candidate path (the reference's default when --mask_train is absent)
+    Cn = 13
+    gc = torch.Generator().manual_seed(seed + 2000)
+    cand = torch.randint(0, N, (B, S, Cn), generator=gc)
+    tgt = torch.zeros(B, S, dtype=torch.long)
+    for b in range(B):
+        for i in range(S):  # data_loader.py:46-55 semantics
+            hit = (cand[b, i] == s[b, i]).nonzero()
+            if len(hit) > 0:
+                tgt[b, i] = hit[0, 0]
+            else:
+                cand[b, i, 0] = s[b, i]
+    m.candidateFlag = True
+    cb = dict(batch, sample_candidates=cand.numpy(), sample_targets=tgt.numpy())
+    torch.manual_seed(seed + 6)
+    m.zero_grad()
+    with Recorder() as rec:
+        loss, recLoss, KLD = ref_tg.get_gen_loss(cb, m, CEL, beta)
+        loss.backward()
+    with torch.no_grad():
+        torch.manual_seed(seed + 6)
+        pc = m.forward(s, r, candidates=cand, u=u)[0]
+    m.candidateFlag = False
+    out["cand/eps"] = rec.eps[0].numpy()
+    if rec.cats:
+        out["cand/pivot_sample"] = rec.cats[0].numpy()
+    out["cand/candidates"] = cand.numpy()
+    out["cand/targets"] = tgt.numpy()
+    out["cand/p"] = pc.numpy().copy()
+    out["cand/loss"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+    for k, prm in m.named_parameters():
+        if prm.grad is not None:
+            out["cand/grad/" + k] = prm.grad.detach().numpy().copy()
+
+    meta = dict(name=name, model=model, S=S, D=D, Z=Z, N=N, NU=NU, B=B, no_user=no_user, beta=beta, lr=lr,
+                n_neg_part=n_neg_part, structs=st, none_grads=none_grads, seed=seed,
+                torch=torch.__version__)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(out)} arrays, none_grads={len(none_grads)}")
+
+
+def make_response_model(name, N, NU, D, S, B, H, seed):
+    """G7: UserResponseModel_MLP (env/response_model.py:46-87)."""
+    torch.manual_seed(seed)
+    rm = quiet(ref_env.UserResponseModel_MLP, N - 1, NU - 1, D, S, [(S + 1) * D, H, H, S], "cpu", False)
+    g = torch.Generator().manual_seed(seed + 1)
+    s = torch.randint(0, N, (B, S), generator=g)
+    u = torch.randint(0, NU, (B,), generator=g)
+    with torch.no_grad():
+        logits = rm(s, u)
+    out = {"sd/" + k: v.numpy().copy() for k, v in rm.state_dict().items()}
+    out.update(s=s.numpy(), u=u.numpy(), logits=logits.numpy())
+    out["meta"] = np.array(json.dumps(dict(name=name, N=N, NU=NU, D=D, S=S, B=B, H=H, seed=seed)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(out)} arrays")
+
+
+def main():
+    keys = list(ref_pivot.PIVOTCVAE_MODELS)
+    # all 8 pivot variants, with user, S=5 D=16 (N=203: seven 32-row catalog tiles, ragged tail)
+    for i, k in enumerate(keys):
+        make_case(k + "_user", k, S=5, D=16, Z=4, N=203, NU=11, B=7, H=24, HP=12, no_user=False, seed=100 + i)
+    # no-user variants
+    make_case("pivotcvae_gt_pi_nouser", "pivotcvae_gt_pi", S=5, D=16, Z=4, N=203, NU=11, B=7, H=24, HP=12,
+              no_user=True, seed=201)
+    # a second shape: S=10 D=32 Z=8, N just over a tile multiple
+    make_case("pivotcvae_gt_pi_s10", "pivotcvae_gt_pi", S=10, D=32, Z=8, N=321, NU=9, B=5, H=32, HP=16,
+              no_user=False, seed=202)
+    # List-CVAE baseline (config 1 plumbing)
+    make_case("listcvae_user", "listcvae", S=5, D=16, Z=4, N=203, NU=11, B=7, H=24, HP=12, no_user=False, seed=301)
+    make_case("listcvae_nouser", "listcvae", S=5, D=16, Z=4, N=203, NU=11, B=7, H=24, HP=12, no_user=True, seed=302)
+    make_response_model("response_mlp", N=203, NU=11, D=16, S=5, B=9, H=24, seed=401)
+
+
+if __name__ == "__main__":
+    main()

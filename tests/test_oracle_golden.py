@@ -1,0 +1,131 @@
+"""Pin the CPU oracle against goldens minted from the real reference.
+
+The oracle uses the same torch CPU ops in (nearly) the same order as the reference, so the
+agreement is expected at the 1e-6 level; tolerances are stated per check.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pivotcvae_oracle as orc
+from tests.helpers import load, model_cases
+
+CASES = model_cases()
+RTOL, ATOL = 2e-6, 2e-7
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g1_normalised_tables(name):
+    g = load(name)
+    close(orc.normalize_rows(g.t("raw_doc")), g.t("sd/docEmbed.weight"))
+    if not g.meta["no_user"]:
+        close(orc.normalize_rows(g.t("raw_user")), g.t("sd/userEmbed.weight"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g2_forward(name):
+    g = load(name)
+    cfg = g.cfg()
+    ps = g.t("fwd/pivot_sample") if g.has("fwd/pivot_sample") else None
+    f = orc.forward(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("fwd/eps"), pivot_sample=ps)
+    for k in ("p", "rx", "z", "emb", "z_mu", "z_logvar", "cond"):
+        close(f[k], g.t("fwd/" + k))
+    pmu, plv = orc.prior(g.sd, cfg, g.t("r"), g.t("u"))
+    close(pmu, g.t("fwd/pMu"))
+    close(plv, g.t("fwd/pLogvar"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g3_g4_loss_and_grads_full(name):
+    g = load(name)
+    cfg = g.cfg()
+    ps = g.t("full/pivot_sample") if g.has("full/pivot_sample") else None
+    (loss, rec, kld), grads = orc.loss_and_grads(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("full/eps"),
+                                                 g.meta["beta"], pivot_sample=ps)
+    np.testing.assert_allclose([loss, rec, kld], g.a["full/loss"], rtol=1e-6)
+    none = sorted(k for k, v in grads.items() if v is None)
+    want_none = sorted(k for k in g.meta["none_grads"] if not k.startswith(("docEmbed", "userEmbed")))
+    assert none == want_none  # PSM never receives a gradient
+    for k, v in g.sub("grad").items():
+        close(grads[k], v, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g3_loss_with_recorded_mask(name):
+    g = load(name)
+    cfg = g.cfg()
+    ps = g.t("part/pivot_sample") if g.has("part/pivot_sample") else None
+    (loss, rec, kld), grads = orc.loss_and_grads(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("part/eps"),
+                                                 g.meta["beta"], neg_sample=g.t("part/neg_sample"), pivot_sample=ps)
+    np.testing.assert_allclose([loss, rec, kld], g.a["part/loss"], rtol=1e-6)
+    for k, v in g.sub("part/grad").items():
+        close(grads[k], v, rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g4_adam_three_steps(name):
+    g = load(name)
+    cfg = g.cfg()
+    sd, state = g.sd, {}
+    for step in range(3):
+        ps = g.t(f"adam/pivot_sample{step}") if g.has(f"adam/pivot_sample{step}") else None
+        (loss, rec, kld), grads = orc.loss_and_grads(sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t(f"adam/eps{step}"),
+                                                     g.meta["beta"], pivot_sample=ps)
+        np.testing.assert_allclose([loss, rec, kld], g.a[f"adam/loss{step}"], rtol=2e-6)
+        sd = orc.adam_step(sd, grads, state, g.meta["lr"])
+        if step in (0, 2):
+            for k, v in g.sub(f"adam/step{step + 1}").items():
+                close(sd[k], v, rtol=1e-5, atol=1e-7)
+    # PSM weights are exactly unchanged by training
+    for k in g.meta["none_grads"]:
+        assert torch.equal(sd[k], g.sd[k])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g5_recommend(name):
+    g = load(name)
+    cfg = g.cfg()
+    ps = g.t("rec/pivot_sample") if g.has("rec/pivot_sample") else None
+    u = None if cfg.no_user else g.t("u")
+    o = orc.recommend(g.sd, cfg, g.t("rec/r"), u, g.t("rec/eps"), pivot_sample=ps)
+    close(o["z_mu"], g.t("rec/z_mu"))
+    close(o["rx"], g.t("rec/rx"))
+    assert torch.equal(o["items"], g.t("rec/items"))  # greedy ids bit-exact
+    if cfg.model != "listcvae":
+        assert torch.equal(o["pivot"], g.t("rec/pivot"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_g6_candidate_path(name):
+    g = load(name)
+    cfg = g.cfg()
+    ps = g.t("cand/pivot_sample") if g.has("cand/pivot_sample") else None
+    kw = dict(candidates=g.t("cand/candidates"), pivot_sample=ps)
+    f = orc.forward(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("cand/eps"), **kw)
+    close(f["p"], g.t("cand/p"))
+    (loss, rec, kld), grads = orc.loss_and_grads(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("cand/eps"),
+                                                 g.meta["beta"], cand_targets=g.t("cand/targets"), **kw)
+    np.testing.assert_allclose([loss, rec, kld], g.a["cand/loss"], rtol=1e-6)
+    for k, v in g.sub("cand/grad").items():
+        close(grads[k], v, rtol=2e-5, atol=1e-7)
+
+
+def test_g7_response_mlp():
+    g = load("response_mlp")
+    close(orc.response_mlp(g.sd, g.t("s"), g.t("u")), g.t("logits"))
+
+
+def test_downsample_semantics():
+    """masked-out logits become 0 (not -inf) and the target column is always kept."""
+    pred = torch.arange(12, dtype=torch.float32).reshape(3, 4) + 1
+    slate = torch.tensor([[1], [3], [0]])
+    neg = torch.zeros(3, 4)
+    neg[0, 1] = 1  # overlaps the target: stays 1, not 2
+    neg[1, 0] = 1
+    out = orc.downsample(pred, slate, neg)
+    want = torch.tensor([[0, 2, 0, 0], [5, 0, 0, 8], [9, 0, 0, 0]], dtype=torch.float32)
+    assert torch.equal(out, want)
