@@ -1,0 +1,175 @@
+/* pcvae.h - C ABI of libpcvae_hip.so: the MI355X (gfx950) kernels behind the PivotCVAE
+ * slate-generation hot path.
+ *
+ * The reference (CharlieMat/PivotCVAE) has no FFI/plugin interface: its hot path is a chain of aten
+ * calls inside Python.  Each entry point below replaces one such call site; the
+ * reference file:line it stands in for is cited per function (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller (torch's caching
+ *     allocator on the Python host side); nothing is allocated, freed or retained by the library.
+ *   - all matrices are row-major fp32 with an explicit leading dimension `ld*` (floats between rows),
+ *     so concatenations (torch.cat in the reference) are just column windows of one buffer.
+ *   - indices are int64 (torch.LongTensor in the reference).
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream and
+ *     graph-capturable (no allocation, no synchronisation, no host read-back).
+ *   - return value: 0 on success, negative PCVAE_E* otherwise; pcvae_last_error() gives the text
+ *     (thread-local).  Shape/argument violations are rejected on the host BEFORE any launch.
+ */
+#ifndef PCVAE_H
+#define PCVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCVAE_ABI_VERSION 1
+
+#define PCVAE_OK 0
+#define PCVAE_EINVAL (-1)   /* bad argument / unsupported shape */
+#define PCVAE_ELAUNCH (-2)  /* HIP launch error */
+#define PCVAE_EWORKSPACE (-3) /* workspace too small */
+
+#define PCVAE_ACT_NONE 0
+#define PCVAE_ACT_LEAKY 1   /* LeakyReLU(0.01): models/cvae.py:43 */
+
+/* catalog precision modes (arithmetic the [R,D]x[D,N] contraction is computed in) */
+#define PCVAE_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact k-ordered fmaf chain (bit-exact ids) */
+#define PCVAE_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16 on a bf16 copy of the table, fp32 accumulate */
+#define PCVAE_PREC_BF16X3 2 /* split-bf16 (hi+lo) 3-product emulation of fp32 on the bf16 MFMA pipe */
+
+typedef void* pcvae_stream_t;
+
+int pcvae_abi_version(void);
+const char* pcvae_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1  item / user embedding gather          models/pivotcvae.py:253,258 ; :194 ; :192
+ *     out[(i / group) * out_ld + (i % group) * D + d] = table[idx[i] * D + d],  i in [0, n_idx)
+ *     group = 1, out_ld = D is a plain nn.Embedding lookup; group = S, out_ld = enc_in writes the
+ *     [B, S*D] slate block straight into the encoder input buffer.
+ * ------------------------------------------------------------------------------------------- */
+int pcvae_gather_rows(const float* table, int64_t n_rows, int D, const int64_t* idx, int64_t n_idx,
+                      int group, float* out, int64_t out_ld, pcvae_stream_t stream);
+
+/* K2  click-count one-hot condition         models/cvae.py:85-92
+ *     out[b * out_ld + c] = (c == sum_s r[b, s]),  c in [0, S]                                  */
+int pcvae_condition(const float* r, int64_t B, int S, float* out, int64_t out_ld, pcvae_stream_t stream);
+
+/* strided 2-D copy (the torch.cat of models/pivotcvae.py:167,203,213,236 becomes column windows) */
+int pcvae_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
+                 pcvae_stream_t stream);
+
+/* out[r, c] = x[r, c] * scale_host * (scale_dev ? *scale_dev : 1)   (chain rule through 'mean') */
+int pcvae_scale_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int cols,
+                     const float* scale_dev, float scale_host, pcvae_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3  MLP layers (addmm + leaky_relu)       models/pivotcvae.py:167-173, 205-210, 215-220, 232-239
+ *     fwd : Y[M,N]  = act(X[M,K] @ W[N,K]^T + bias[N])          (bias may be NULL: dense scores,
+ *                                                                 models/pivotcvae.py:274)
+ *     dX  : dX[M,K] = (dY[M,N] @ W[N,K]) * act'(Xact[M,K])      (Xact = ACTIVATED output that fed
+ *                                                                 this layer, NULL -> no act')
+ *     dW  : dW[N,K] += dY[M,N]^T @ X[M,K] ;  db[N] += colsum(dY)   (accumulating; db may be NULL)
+ * ------------------------------------------------------------------------------------------- */
+int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                     int64_t ldy, int64_t M, int64_t N, int64_t K, int act, pcvae_stream_t stream);
+int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
+                           int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
+                           pcvae_stream_t stream);
+int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
+                            float* db, int64_t M, int64_t N, int64_t K, pcvae_stream_t stream);
+/* in place: g *= (y > 0 ? 1 : 0.01)  - LeakyReLU backward keyed on the activated output */
+int pcvae_leaky_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t rows, int cols,
+                    pcvae_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4  reparameterisation                    models/cvae.py:79-83
+ *     z = mu + exp(0.5 * logvar) * eps.   eps_in != NULL: use it (parity mode, the reference draws
+ *     eps from torch's global generator).  eps_in == NULL: eps ~ N(0,1) from Philox4x32-10 keyed by
+ *     `seed`, counter = offset + element index (results independent of launch geometry and of how a
+ *     batch is sharded over ranks).  eps_out (optional) receives the eps used (needed by backward).
+ *     bwd: dmu += dz ; dlogvar += dz * eps * 0.5 * exp(0.5 * logvar)
+ * ------------------------------------------------------------------------------------------- */
+int pcvae_reparam_fwd(const float* mu, const float* logvar, const float* eps_in, uint64_t seed, uint64_t offset,
+                      float* z, int64_t ldz, float* eps_out, int64_t B, int Z, pcvae_stream_t stream);
+int pcvae_reparam_bwd(const float* dz, int64_t lddz, const float* eps, const float* logvar, float* dmu,
+                      float* dlogvar, int64_t B, int Z, pcvae_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7  Gaussian-prior KL (sum over batch and latent)     train_generative.py:61
+ *     kld = -1/2 sum(1 + lv - plv - (exp(lv) + (mu - pmu)^2) / exp(plv))  -> *kld_out (1 float)
+ *     bwd: d{mu,lv,pmu,plv} += scale * dKLD/d{...}   (any of the four outputs may be NULL)
+ * ------------------------------------------------------------------------------------------- */
+int pcvae_kld_fwd(const float* mu, const float* lv, const float* pmu, const float* plv, int64_t n, float* kld_out,
+                  pcvae_stream_t stream);
+int pcvae_kld_bwd(const float* mu, const float* lv, const float* pmu, const float* plv, int64_t n,
+                  const float* scale_dev, float scale_host, float* dmu, float* dlv, float* dpmu, float* dplv,
+                  pcvae_stream_t stream);
+
+/* deterministic reduction: *out = scale * sum(x[0..n))   (CrossEntropyLoss 'mean', train_generative.py:59) */
+int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5  fused full-catalog softmax cross-entropy          models/pivotcvae.py:274 +
+ *                                                       train_generative.py:36-42 (downsample), :59
+ *     For every row r of rx[R,D] against the whole table E[N,D], WITHOUT materialising [R,N]:
+ *        s_n   = <rx_r, E_n>
+ *        keep_n= (n == target_r) | mask(r, n)                    mask: all ones (keep_prob >= 1),
+ *                                                                explicit uint8 [R,N], or Philox
+ *                                                                Bernoulli(keep_prob) keyed by
+ *                                                                (seed, row_offset + r, n)
+ *        z_n   = keep_n ? s_n : 0                                (masked-out logits are 0, not -inf)
+ *        lse_r = log sum_n exp(z_n) ;  nll_r = lse_r - z_target
+ *        dx_r  = sum_n keep_n * (softmax(z)_n - [n == target_r]) * E_n        (optional, [R,D])
+ *     i.e. loss AND its gradient direction in one streaming pass (online softmax over catalog
+ *     tiles, flash-style), so the backward pass is dx * (upstream / R).
+ *     E_lo: second table for PCVAE_PREC_BF16X3 (residual), E is the bf16 table for BF16/BF16X3 and
+ *     the fp32 table for F32.  `ws` is scratch of at least pcvae_catalog_ws_bytes().
+ * ------------------------------------------------------------------------------------------- */
+size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_dx);
+int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
+                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
+                     const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, size_t ws_bytes,
+                     pcvae_stream_t stream);
+
+/* K6  fused catalog argmax (greedy decode)              models/cvae.py:97-101 ; models/pivotcvae.py:191
+ *     idx[r] = first n maximising <x_r, E_n>  (torch.max tie rule: lowest index)                 */
+int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
+                         int64_t* idx, float* best, void* ws, size_t ws_bytes, pcvae_stream_t stream);
+
+/* K10 sampled pivot                                     models/pivotcvae.py:349-351, 371-373
+ *     idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) over the whole catalog, drawn with the Gumbel-max trick
+ *     (argmax_n log sigmoid(s_n) - log(-log u_n), u_n = Philox(seed, row_offset + r, n)); the reference's
+ *     torch.multinomial stream cannot be matched, parity is distributional (tests) or by feeding the
+ *     recorded draw back in on the host side.                                                       */
+int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
+                         uint64_t seed, uint64_t row_offset, int64_t* idx, void* ws, size_t ws_bytes,
+                         pcvae_stream_t stream);
+
+/* fp32 table -> bf16 hi (round-to-nearest-even) and optional bf16 lo (residual) copies */
+int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, pcvae_stream_t stream);
+
+/* K9  candidate-set scores                              models/pivotcvae.py:265-271
+ *     p[r, c] = <E[cand[r, c]], rx_r> ;  bwd: drx_r = sum_c dp[r, c] * E[cand[r, c]]            */
+int pcvae_candidate_scores(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* cand,
+                           int Cn, float* p, pcvae_stream_t stream);
+int pcvae_candidate_scores_bwd(const float* dp, int64_t R, const float* E, int64_t N, int D, const int64_t* cand,
+                               int Cn, float* drx, pcvae_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8  Adam over one flat fp32 buffer                    train_generative.py:103,134
+ *     torch.optim.Adam defaults (betas 0.9/0.999, eps 1e-8, no weight decay, bias-corrected):
+ *        g' = g * grad_scale ; m += (g' - m)(1 - b1) ; v = b2 v + (1 - b2) g'^2
+ *        p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+ * ------------------------------------------------------------------------------------------- */
+int pcvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                    float eps, int step, float grad_scale, pcvae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCVAE_H */

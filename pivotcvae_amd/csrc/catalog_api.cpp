@@ -1,0 +1,72 @@
+// extern "C" entry points of the catalog kernels: argument validation + precision dispatch.
+#include "catalog_plan.h"
+
+using namespace pcvae;
+
+static bool supported_d(int D) { return D == 16 || D == 32 || D == 64 || D == 128 || D == 256; }
+
+extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_dx) {
+    if (R <= 0 || N <= 0 || D <= 0) return 0;
+    const CatalogPlan pl = catalog_plan(R, N, D);
+    const size_t rows = (size_t)pl.nsplit * (size_t)R;
+    size_t ce = rows * 2 * sizeof(float) + (want_dx ? rows * (size_t)D * sizeof(float) : 0);
+    size_t am = (rows + 1) * sizeof(float) + rows * sizeof(int64_t) + 16;
+    return (ce > am ? ce : am) + 256;
+}
+
+extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
+                                int prec, const int64_t* target, float keep_prob, uint64_t seed,
+                                uint64_t row_offset, const uint8_t* keep_mask, float* nll, float* lse, float* dx,
+                                void* ws, size_t ws_bytes, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(rx && E && target && nll && ws, "catalog_ce: null pointer");
+    PCVAE_REQUIRE(R > 0 && N > 0, "catalog_ce: empty problem R=%lld N=%lld", (long long)R, (long long)N);
+    PCVAE_REQUIRE(supported_d(D), "catalog_ce: unsupported D=%d (16, 32, 64, 128, 256)", D);
+    PCVAE_REQUIRE(keep_prob > 0.f, "catalog_ce: keep_prob must be > 0 (n_neg > N raises in the reference too)");
+    PCVAE_REQUIRE(((uintptr_t)rx % 16 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)ws % 16 == 0) &&
+                      (!dx || (uintptr_t)dx % 16 == 0),
+                  "catalog_ce: rx/E/ws/dx must be 16-byte aligned");
+    if (ws_bytes < pcvae_catalog_ws_bytes(R, N, D, dx != nullptr)) {
+        set_error("catalog_ce: workspace %zu < %zu bytes", ws_bytes, pcvae_catalog_ws_bytes(R, N, D, dx != nullptr));
+        return PCVAE_EWORKSPACE;
+    }
+    if (prec == PCVAE_PREC_F32) {
+        (void)E_lo;
+        return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E), N, D, target, keep_prob, seed, row_offset,
+                              keep_mask, nll, lse, dx, ws, as_stream(stream));
+    }
+    set_error("catalog_ce: precision mode %d not available in this build", prec);
+    return PCVAE_EINVAL;
+}
+
+static int argmax_common(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
+                         bool sample, uint64_t seed, uint64_t row_offset, int64_t* idx, float* best, void* ws,
+                         size_t ws_bytes, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(x && E && idx && ws, "catalog_argmax: null pointer");
+    PCVAE_REQUIRE(R > 0 && N > 0, "catalog_argmax: empty problem R=%lld N=%lld", (long long)R, (long long)N);
+    PCVAE_REQUIRE(supported_d(D), "catalog_argmax: unsupported D=%d (16, 32, 64, 128, 256)", D);
+    PCVAE_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)ws % 16 == 0),
+                  "catalog_argmax: x/E/ws must be 16-byte aligned");
+    if (ws_bytes < pcvae_catalog_ws_bytes(R, N, D, 0)) {
+        set_error("catalog_argmax: workspace %zu < %zu bytes", ws_bytes, pcvae_catalog_ws_bytes(R, N, D, 0));
+        return PCVAE_EWORKSPACE;
+    }
+    if (prec == PCVAE_PREC_F32) {
+        (void)E_lo;
+        return catalog_argmax_f32(x, R, reinterpret_cast<const float*>(E), N, D, sample, seed, row_offset, idx, best,
+                                  ws, as_stream(stream));
+    }
+    set_error("catalog_argmax: precision mode %d not available in this build", prec);
+    return PCVAE_EINVAL;
+}
+
+extern "C" int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
+                                    int prec, int64_t* idx, float* best, void* ws, size_t ws_bytes,
+                                    pcvae_stream_t stream) {
+    return argmax_common(x, R, E, E_lo, N, D, prec, false, 0, 0, idx, best, ws, ws_bytes, stream);
+}
+
+extern "C" int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
+                                    int prec, uint64_t seed, uint64_t row_offset, int64_t* idx, void* ws,
+                                    size_t ws_bytes, pcvae_stream_t stream) {
+    return argmax_common(x, R, E, E_lo, N, D, prec, true, seed, row_offset, idx, nullptr, ws, ws_bytes, stream);
+}

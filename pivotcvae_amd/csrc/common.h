@@ -1,0 +1,68 @@
+// Shared device/host helpers for libpcvae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/pcvae.h"
+
+namespace pcvae {
+
+// ---- host-side error plumbing (thread-local text behind pcvae_last_error()) ------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define PCVAE_REQUIRE(cond, ...)                       \
+    do {                                               \
+        if (!(cond)) {                                 \
+            ::pcvae::set_error(__VA_ARGS__);           \
+            return PCVAE_EINVAL;                       \
+        }                                              \
+    } while (0)
+
+static inline hipStream_t as_stream(pcvae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr float kLeakySlope = 0.01f;  // nn.LeakyReLU() default (reference models/cvae.py:43)
+constexpr int kWave = 64;
+
+// ---- XCD-aware block remap ---------------------------------------------------------------------
+// Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md "Workgroup dispatch").
+// Map the hardware block id to a logical id such that every XCD walks a CONTIGUOUS range of logical
+// ids: neighbours in logical order (which share catalog tiles) then hit the same private L2.
+// Bijective for any grid size; affects speed only, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}
+
+// ---- Philox4x32-10 (counter-based RNG; Salmon et al. 2011) -----------------------------------
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * b) >> 32);
+#endif
+}
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                           uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = mulhi32(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = mulhi32(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += W0; k1 += W1;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+
+__device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }
+
+}  // namespace pcvae

@@ -1,0 +1,436 @@
+// HBM-bound kernels of the PivotCVAE hot path (gfx950): embedding gather (K1), click-count
+// condition (K2), reparameterisation with wavefront Philox (K4), Gaussian-prior KL (K7), Adam over
+// a flat buffer (K8), candidate-set scores (K9) and small helpers.  All are sized for 64-wide
+// wavefronts and 16 B/lane accesses where alignment allows.
+#include "common.h"
+
+using namespace pcvae;
+
+// =============================================================================================
+// K1: row gather.  One 16-byte chunk per lane; LPR lanes cover one row, 64/LPR rows per
+// wave-instruction, UNROLL row groups in flight per wave so the dependent idx->row loads overlap.
+// =============================================================================================
+template <int UNROLL>
+__global__ void __launch_bounds__(256) gather_rows_vec4_kernel(const float4* __restrict__ table, int chunks, int lpr,
+                                                               const int64_t* __restrict__ idx, int64_t n_idx,
+                                                               int group, float* __restrict__ out, int64_t out_ld,
+                                                               int D) {
+    const int lane = threadIdx.x & 63;
+    const int rows_per_wave = 64 / lpr;
+    const int sub = lane / lpr;    // which row of the wave's row group
+    const int chunk0 = lane % lpr;  // first 16 B chunk of the row handled by this lane
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t n_groups = (n_idx + rows_per_wave - 1) / rows_per_wave;
+    for (int64_t g0 = wave * UNROLL; g0 < n_groups; g0 += n_waves * UNROLL) {
+        int64_t src[UNROLL];
+        int64_t i_[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int64_t i = (g0 + u) * rows_per_wave + sub;
+            i_[u] = i;
+            src[u] = (g0 + u < n_groups && i < n_idx) ? idx[i] : -1;
+        }
+        for (int c = chunk0; c < chunks; c += lpr) {
+            float4 v[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (src[u] >= 0) v[u] = table[src[u] * chunks + c];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                if (src[u] >= 0) {
+                    float* o = out + (i_[u] / group) * out_ld + (i_[u] % group) * (int64_t)D + c * 4;
+                    *reinterpret_cast<float4*>(o) = v[u];
+                }
+        }
+    }
+}
+
+// generic fallback (any D / alignment): one wave per row, 4 B per lane
+__global__ void __launch_bounds__(256) gather_rows_scalar_kernel(const float* __restrict__ table, int D,
+                                                                 const int64_t* __restrict__ idx, int64_t n_idx,
+                                                                 int group, float* __restrict__ out, int64_t out_ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t i = wave; i < n_idx; i += n_waves) {
+        const float* s = table + idx[i] * D;
+        float* o = out + (i / group) * out_ld + (i % group) * (int64_t)D;
+        for (int d = lane; d < D; d += 64) o[d] = s[d];
+    }
+}
+
+extern "C" int pcvae_gather_rows(const float* table, int64_t n_rows, int D, const int64_t* idx, int64_t n_idx,
+                                 int group, float* out, int64_t out_ld, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(table && idx && out, "gather_rows: null pointer");
+    PCVAE_REQUIRE(D > 0 && n_rows > 0 && group > 0, "gather_rows: bad D/n_rows/group (%d, %lld, %d)", D,
+                  (long long)n_rows, group);
+    PCVAE_REQUIRE(out_ld >= (int64_t)group * D, "gather_rows: out_ld %lld < group*D %lld", (long long)out_ld,
+                  (long long)group * D);
+    if (n_idx == 0) return PCVAE_OK;
+    const bool vec = (D % 4 == 0) && (out_ld % 4 == 0) && (((uintptr_t)out) % 16 == 0) && (((uintptr_t)table) % 16 == 0);
+    if (vec) {
+        const int chunks = D / 4;
+        int lpr = 1;
+        while (lpr < chunks && lpr < 64) lpr <<= 1;
+        const int rows_per_wave = 64 / lpr;
+        const int64_t n_groups = cdiv(n_idx, rows_per_wave);
+        const int64_t blocks = std::min<int64_t>(cdiv(cdiv(n_groups, 4), 4), 256 * 8);
+        hipLaunchKernelGGL(gather_rows_vec4_kernel<4>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0,
+                           as_stream(stream), reinterpret_cast<const float4*>(table), chunks, lpr, idx, n_idx, group,
+                           out, out_ld, D);
+    } else {
+        const int64_t blocks = std::min<int64_t>(cdiv(n_idx, 4), 256 * 8);
+        hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), table,
+                           D, idx, n_idx, group, out, out_ld);
+    }
+    return check_launch("gather_rows");
+}
+
+// =============================================================================================
+// K2: condition one-hot
+// =============================================================================================
+__global__ void condition_kernel(const float* __restrict__ r, int64_t B, int S, float* __restrict__ out,
+                                 int64_t out_ld) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float cnt = 0.f;
+    for (int s = 0; s < S; ++s) cnt += r[b * S + s];
+    const int c = (int)cnt;  // torch: sum(r).to(long) truncates
+    for (int j = 0; j <= S; ++j) out[b * out_ld + j] = (j == c) ? 1.f : 0.f;
+}
+
+extern "C" int pcvae_condition(const float* r, int64_t B, int S, float* out, int64_t out_ld, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(r && out && S > 0 && out_ld >= S + 1, "condition: bad arguments");
+    if (B == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(condition_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), r, B, S, out,
+                       out_ld);
+    return check_launch("condition");
+}
+
+// =============================================================================================
+// strided 2-D copy / LeakyReLU backward
+// =============================================================================================
+__global__ void copy2d_kernel(const float* __restrict__ src, int64_t src_ld, float* __restrict__ dst, int64_t dst_ld,
+                              int64_t rows, int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i % cols);
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+
+extern "C" int pcvae_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
+                            pcvae_stream_t stream) {
+    PCVAE_REQUIRE(src && dst && cols > 0 && src_ld >= cols && dst_ld >= cols, "copy2d: bad arguments");
+    if (rows == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(rows * cols, 256), 2048);
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, src_ld, dst, dst_ld,
+                       rows, cols);
+    return check_launch("copy2d");
+}
+
+__global__ void scale_rows_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
+                                  int64_t rows, int cols, const float* __restrict__ scale_dev, float scale_host) {
+    const float sc = scale_host * (scale_dev ? scale_dev[0] : 1.f);
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i % cols);
+        out[r * ldo + c] = x[r * ldx + c] * sc;
+    }
+}
+
+extern "C" int pcvae_scale_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int cols,
+                                const float* scale_dev, float scale_host, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(x && out && cols > 0 && ldx >= cols && ldo >= cols, "scale_rows: bad arguments");
+    if (rows == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(rows * cols, 256), 4096);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, ldx, out, ldo,
+                       rows, cols, scale_dev, scale_host);
+    return check_launch("scale_rows");
+}
+
+__global__ void leaky_bwd_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ y, int64_t ldy,
+                                 int64_t rows, int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i % cols);
+        if (!(y[r * ldy + c] > 0.f)) g[r * ldg + c] *= kLeakySlope;
+    }
+}
+
+extern "C" int pcvae_leaky_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t rows, int cols,
+                               pcvae_stream_t stream) {
+    PCVAE_REQUIRE(g && y && cols > 0 && ldg >= cols && ldy >= cols, "leaky_bwd: bad arguments");
+    if (rows == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(rows * cols, 256), 2048);
+    hipLaunchKernelGGL(leaky_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, ldg, y, ldy, rows,
+                       cols);
+    return check_launch("leaky_bwd");
+}
+
+// =============================================================================================
+// K4: reparameterisation.  eps from Philox4x32-10 + Box-Muller; element e uses Philox counter
+// (offset + e) / 4, lane (offset + e) % 4 -> independent of launch geometry and of rank sharding.
+// =============================================================================================
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t e) {
+    const uint64_t ctr = e >> 2;
+    const Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0x5043564Au /*"PCVJ"*/, 0u, (uint32_t)seed,
+                                    (uint32_t)(seed >> 32));
+    const int j = (int)(e & 3);
+    const uint32_t a = (j < 2) ? p.x : p.z;
+    const uint32_t b = (j < 2) ? p.y : p.w;
+    const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0, 1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.28318530717958647692f * u2, &s, &c);
+    return rad * ((j & 1) ? s : c);
+}
+
+__global__ void reparam_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ logvar,
+                                   const float* __restrict__ eps_in, uint64_t seed, uint64_t offset,
+                                   float* __restrict__ z, int64_t ldz, float* __restrict__ eps_out, int64_t B, int Z) {
+    const int64_t n = B * Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float eps = eps_in ? eps_in[i] : philox_normal(seed, offset + (uint64_t)i);
+        const float sd = expf(0.5f * logvar[i]);
+        z[(i / Z) * ldz + (i % Z)] = eps * sd + mu[i];
+        if (eps_out) eps_out[i] = eps;
+    }
+}
+
+extern "C" int pcvae_reparam_fwd(const float* mu, const float* logvar, const float* eps_in, uint64_t seed,
+                                 uint64_t offset, float* z, int64_t ldz, float* eps_out, int64_t B, int Z,
+                                 pcvae_stream_t stream) {
+    PCVAE_REQUIRE(mu && logvar && z && Z > 0 && ldz >= Z, "reparam_fwd: bad arguments");
+    if (B == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(B * Z, 256), 2048);
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), mu, logvar, eps_in,
+                       seed, offset, z, ldz, eps_out, B, Z);
+    return check_launch("reparam_fwd");
+}
+
+__global__ void reparam_bwd_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ eps,
+                                   const float* __restrict__ logvar, float* __restrict__ dmu,
+                                   float* __restrict__ dlogvar, int64_t B, int Z) {
+    const int64_t n = B * Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = dz[(i / Z) * lddz + (i % Z)];
+        dmu[i] += g;
+        dlogvar[i] += g * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+    }
+}
+
+extern "C" int pcvae_reparam_bwd(const float* dz, int64_t lddz, const float* eps, const float* logvar, float* dmu,
+                                 float* dlogvar, int64_t B, int Z, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(dz && eps && logvar && dmu && dlogvar && Z > 0 && lddz >= Z, "reparam_bwd: bad arguments");
+    if (B == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(B * Z, 256), 2048);
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dz, lddz, eps,
+                       logvar, dmu, dlogvar, B, Z);
+    return check_launch("reparam_bwd");
+}
+
+// =============================================================================================
+// deterministic single-block reductions (K7 forward, CE mean)
+// =============================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum_1024(float v) {
+    __shared__ float part[16];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x < 64) {
+        t = threadIdx.x < (blockDim.x >> 6) ? part[threadIdx.x] : 0.f;
+        t = wave_sum(t);
+    }
+    return t;  // valid in wave 0
+}
+
+__global__ void __launch_bounds__(1024) kld_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                       const float* __restrict__ pmu, const float* __restrict__ plv,
+                                                       int64_t n, float* __restrict__ out) {
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = mu[i] - pmu[i];
+        acc += 1.f + lv[i] - plv[i] - (expf(lv[i]) + d * d) / expf(plv[i]);
+    }
+    const float t = block_sum_1024(acc);
+    if (threadIdx.x == 0) out[0] = -0.5f * t;
+}
+
+extern "C" int pcvae_kld_fwd(const float* mu, const float* lv, const float* pmu, const float* plv, int64_t n,
+                             float* kld_out, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(mu && lv && pmu && plv && kld_out && n >= 0, "kld_fwd: bad arguments");
+    hipLaunchKernelGGL(kld_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), mu, lv, pmu, plv, n, kld_out);
+    return check_launch("kld_fwd");
+}
+
+__global__ void kld_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                               const float* __restrict__ pmu, const float* __restrict__ plv, int64_t n,
+                               const float* __restrict__ scale_dev, float scale_host, float* __restrict__ dmu,
+                               float* __restrict__ dlv, float* __restrict__ dpmu, float* __restrict__ dplv) {
+    const float sc = scale_host * (scale_dev ? scale_dev[0] : 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float ip = expf(-plv[i]);
+        const float d = mu[i] - pmu[i];
+        const float ev = expf(lv[i]);
+        if (dmu) dmu[i] += sc * d * ip;
+        if (dlv) dlv[i] += sc * (-0.5f) * (1.f - ev * ip);
+        if (dpmu) dpmu[i] += sc * (-d * ip);
+        if (dplv) dplv[i] += sc * (-0.5f) * (-1.f + (ev + d * d) * ip);
+    }
+}
+
+extern "C" int pcvae_kld_bwd(const float* mu, const float* lv, const float* pmu, const float* plv, int64_t n,
+                             const float* scale_dev, float scale_host, float* dmu, float* dlv, float* dpmu,
+                             float* dplv, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(mu && lv && pmu && plv && n >= 0, "kld_bwd: bad arguments");
+    if (n == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 2048);
+    hipLaunchKernelGGL(kld_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), mu, lv, pmu, plv, n,
+                       scale_dev, scale_host, dmu, dlv, dpmu, dplv);
+    return check_launch("kld_bwd");
+}
+
+__global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ x, int64_t n, float scale,
+                                                   float* __restrict__ out) {
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += x[i];
+    const float t = block_sum_1024(acc);
+    if (threadIdx.x == 0) out[0] = t * scale;
+}
+
+extern "C" int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(x && out && n >= 0, "sum: bad arguments");
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, scale, out);
+    return check_launch("sum");
+}
+
+// =============================================================================================
+// fp32 -> bf16 hi/lo split (round-to-nearest-even, NaN preserved)
+// =============================================================================================
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // keep a NaN a (quiet) NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+__global__ void split_bf16_kernel(const float* __restrict__ src, int64_t n, uint16_t* __restrict__ hi,
+                                  uint16_t* __restrict__ lo) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = src[i];
+        const uint16_t h = f32_to_bf16_rne(x);
+        hi[i] = h;
+        if (lo) lo[i] = f32_to_bf16_rne(x - bf16_bits_to_f32(h));
+    }
+}
+
+extern "C" int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(src && hi && n >= 0, "split_bf16: bad arguments");
+    if (n == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 4096);
+    hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, n, hi, lo);
+    return check_launch("split_bf16");
+}
+
+// =============================================================================================
+// K9: candidate-set scores.  fwd: lane per candidate (each lane streams its own table row, the rx
+// row is wave-uniform); bwd: wave per slate row, lanes over d (coalesced row reads).
+// =============================================================================================
+__global__ void __launch_bounds__(256) candidate_scores_kernel(const float* __restrict__ rx, int64_t R,
+                                                               const float* __restrict__ E, int D,
+                                                               const int64_t* __restrict__ cand, int Cn,
+                                                               float* __restrict__ p) {
+    const int64_t total = R * (int64_t)Cn;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / Cn;
+        const float* e = E + cand[i] * D;
+        const float* x = rx + r * D;
+        float acc = 0.f;
+        for (int d = 0; d < D; ++d) acc = fmaf(e[d], x[d], acc);
+        p[i] = acc;
+    }
+}
+
+extern "C" int pcvae_candidate_scores(const float* rx, int64_t R, const float* E, int64_t N, int D,
+                                      const int64_t* cand, int Cn, float* p, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(rx && E && cand && p && D > 0 && Cn > 0 && N > 0, "candidate_scores: bad arguments");
+    if (R == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(R * Cn, 256), 256 * 16);
+    hipLaunchKernelGGL(candidate_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), rx, R, E, D,
+                       cand, Cn, p);
+    return check_launch("candidate_scores");
+}
+
+__global__ void __launch_bounds__(256) candidate_scores_bwd_kernel(const float* __restrict__ dp, int64_t R,
+                                                                   const float* __restrict__ E, int D,
+                                                                   const int64_t* __restrict__ cand, int Cn,
+                                                                   float* __restrict__ drx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t r = wave; r < R; r += n_waves) {
+        for (int d0 = 0; d0 < D; d0 += 64) {
+            const int d = d0 + lane;
+            float acc = 0.f;
+            if (d < D)
+                for (int c = 0; c < Cn; ++c) acc = fmaf(dp[r * Cn + c], E[cand[r * Cn + c] * D + d], acc);
+            if (d < D) drx[r * D + d] = acc;
+        }
+    }
+}
+
+extern "C" int pcvae_candidate_scores_bwd(const float* dp, int64_t R, const float* E, int64_t N, int D,
+                                          const int64_t* cand, int Cn, float* drx, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(dp && E && cand && drx && D > 0 && Cn > 0 && N > 0, "candidate_scores_bwd: bad arguments");
+    if (R == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(R, 4), 256 * 8);
+    hipLaunchKernelGGL(candidate_scores_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dp, R, E,
+                       D, cand, Cn, drx);
+    return check_launch("candidate_scores_bwd");
+}
+
+// =============================================================================================
+// K8: Adam over a flat buffer (torch.optim.Adam arithmetic: lerp for m, addcmul for v, addcdiv)
+// =============================================================================================
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
+                            float eps, float step_size, float sqrt_bc2, float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * grad_scale;
+        const float mi = m[i] + (gi - m[i]) * one_minus_b1;
+        const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+
+extern "C" int pcvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                               float eps, int step, float grad_scale, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adam_step: bad arguments");
+    if (n == 0) return PCVAE_OK;
+    const double bc1 = 1.0 - pow((double)b1, step);
+    const double bc2 = 1.0 - pow((double)b2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float sqrt_bc2 = (float)sqrt(bc2);
+    const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n,
+                       (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), eps, step_size, sqrt_bc2,
+                       grad_scale);
+    return check_launch("adam_step");
+}

@@ -1,0 +1,205 @@
+// K3: the MLP stacks of the PivotCVAE (encoder / pivot-selection / slate-completion / prior) as
+// LDS-tiled fp32 MFMA GEMMs on gfx950, with the bias + LeakyReLU epilogue fused (forward), the
+// LeakyReLU derivative fused into the input-gradient GEMM, and a split-K weight-gradient GEMM.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact fmaf chain), because the
+// parity contract is 1e-4 relative against an fp32 reference.  One 256-thread workgroup = 4 waves
+// (2x2), each wave owns one 32x32 accumulator tile of a 64x64 output tile; K is consumed 16 at a
+// time through K-MAJOR LDS tiles (row stride 65 floats) so both MFMA operands are fetched with
+// conflict-free ds_read_b32 (lane i reads element i of a k-row).
+//
+// One kernel template covers the three layouts of a Linear layer:
+//    forward      Y[M,N]  = X[M,K]  . W[N,K]^T    A k-contiguous, B k-contiguous
+//    input grad   dX[M,K] = dY[M,N] . W[N,K]      A k-contiguous, B row-contiguous
+//    weight grad  dW[N,K] = dY[M,N]^T . X[M,K]    A row-contiguous, B row-contiguous, split over M
+#include "common.h"
+
+using namespace pcvae;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = 65;
+
+enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
+
+struct GemmParams {
+    const float* A; int64_t lda;   // logical A(m, k)
+    const float* B; int64_t ldb;   // logical B(n, k)
+    float* C; int64_t ldc;         // C(m, n)
+    int64_t M, N, K;
+    const float* bias;             // EPI_FWD: [N] or null
+    const float* aux; int64_t ldaux;  // EPI_DX: activated input [M,N] or null
+    int act;
+    int64_t k_per_split;           // EPI_DW: reduction range per blockIdx.z
+};
+
+// Load a 64 x 16 (rows x k) tile of a logical operand P(row, k) into 4 registers per thread.
+//   KC  (k contiguous in memory):   P(row, k) = P[row * ld + k]
+//   !KC (row contiguous in memory): P(row, k) = P[k * ld + row]
+template <bool KC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
+                                          int64_t k0, int64_t kend, float (&v)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, k;
+        if (KC) { k = t & 15; row = (t >> 4) + 16 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
+        const int64_t gr = row0 + row, gk = k0 + k;
+        const bool ok = gr < rows && gk < kend;
+        v[i] = ok ? (KC ? P[gr * ld + gk] : P[gk * ld + gr]) : 0.f;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(float* S, const float (&v)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int row, k;
+        if (KC) { k = t & 15; row = (t >> 4) + 16 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
+        S[k * LDT + row] = v[i];
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
+    __shared__ float As[BK * LDT];
+    __shared__ float Bs[BK * LDT];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+
+    int64_t kbeg = 0, kend = p.K;
+    if (EPI == EPI_DW) {
+        kbeg = (int64_t)blockIdx.z * p.k_per_split;
+        kend = kbeg + p.k_per_split < p.K ? kbeg + p.k_per_split : p.K;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    float va[4], vb[4];
+    load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, va);
+    load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, vb);
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();  // previous tile fully consumed
+        store_tile<A_KC>(As, va);
+        store_tile<B_KC>(Bs, vb);
+        __syncthreads();
+        if (k0 + BK < kend) {  // prefetch the next tile while this one is multiplied
+            load_tile<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, kend, va);
+            load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, vb);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const float a = As[(2 * s + h) * LDT + wm * 32 + li];
+            const float b = Bs[(2 * s + h) * LDT + wn * 32 + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+
+    // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int64_t n = n0 + wn * 32 + li;
+    if (n >= p.N) return;
+    const float bias = (EPI == EPI_FWD && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[r];
+        if (EPI == EPI_FWD) {
+            v += bias;
+            if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
+            p.C[m * p.ldc + n] = v;
+        } else if (EPI == EPI_DX) {
+            if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
+            p.C[m * p.ldc + n] = v;
+        } else {
+            atomicAdd(&p.C[m * p.ldc + n], v);
+        }
+    }
+}
+
+// db[n] += sum_m dY[m, n]
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dY, int64_t ld, int64_t M, int64_t N,
+                                                     int64_t m_per_split, float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 64 + tx;
+    const int64_t mbeg = (int64_t)blockIdx.y * m_per_split;
+    const int64_t mend = mbeg + m_per_split < M ? mbeg + m_per_split : M;
+    float acc = 0.f;
+    if (n < N)
+        for (int64_t m = mbeg + ty; m < mend; m += 4) acc += dY[m * ld + n];
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && n < N) atomicAdd(&db[n], part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+}
+
+}  // namespace
+
+extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                                int64_t ldy, int64_t M, int64_t N, int64_t K, int act, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(X && W && Y, "linear_fwd: null pointer");
+    PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, "linear_fwd: bad shape M=%lld N=%lld K=%lld",
+                  (long long)M, (long long)N, (long long)K);
+    PCVAE_REQUIRE(act == PCVAE_ACT_NONE || act == PCVAE_ACT_LEAKY, "linear_fwd: unknown activation %d", act);
+    if (M == 0) return PCVAE_OK;
+    PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_fwd: M too large");
+    GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, 0, act, 0};
+    hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM)),
+                       dim3(256), 0, as_stream(stream), p);
+    return check_launch("linear_fwd");
+}
+
+extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
+                                      int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
+                                      pcvae_stream_t stream) {
+    PCVAE_REQUIRE(dY && W && dX, "linear_bwd_input: null pointer");
+    PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K && (!Xact || ldxa >= K),
+                  "linear_bwd_input: bad shape");
+    if (M == 0) return PCVAE_OK;
+    PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_bwd_input: M too large");
+    // C(m, kk) = sum_n dY[m, n] * W[n, kk]:  A = dY (reduction index contiguous), B(kk, n) = W[n * ldw + kk]
+    GemmParams p{dY, lddy, W, ldw, dX, lddx, M, K, N, nullptr, Xact, ldxa, 0, 0};
+    hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(M, BM)),
+                       dim3(256), 0, as_stream(stream), p);
+    return check_launch("linear_bwd_input");
+}
+
+extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
+                                       int64_t lddw, float* db, int64_t M, int64_t N, int64_t K,
+                                       pcvae_stream_t stream) {
+    PCVAE_REQUIRE(dY && X && dW, "linear_bwd_weight: null pointer");
+    PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "linear_bwd_weight: bad shape");
+    if (M == 0) return PCVAE_OK;
+    // C(n, kk) = sum_m dY[m, n] * X[m, kk]: both operands row-contiguous, reduction over M split
+    // across blockIdx.z so that a [256 x 1419] gradient still fills the chip; partials land with
+    // fp32 atomics in the (pre-zeroed, accumulating) gradient buffer.
+    const int64_t tiles = cdiv(N, BM) * cdiv(K, BN);
+    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), cdiv(M, 4 * BK)));
+    splits = std::min<int64_t>(splits, 64);
+    int64_t kps = cdiv(cdiv(M, splits), BK) * BK;
+    splits = cdiv(M, kps);
+    GemmParams p{dY, lddy, X, ldx, dW, lddw, N, K, M, nullptr, nullptr, 0, 0, kps};
+    hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_DW>),
+                       dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(N, BM), (unsigned)splits), dim3(256), 0,
+                       as_stream(stream), p);
+    int rc = check_launch("linear_bwd_weight");
+    if (rc != PCVAE_OK) return rc;
+    if (db) {
+        int64_t ms = std::max<int64_t>(1, std::min<int64_t>(64, cdiv(M, 256)));
+        int64_t mps = cdiv(M, ms);
+        ms = cdiv(M, mps);
+        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)ms), dim3(256), 0, as_stream(stream), dY,
+                           lddy, M, N, mps, db);
+        rc = check_launch("linear_bwd_weight(colsum)");
+    }
+    return rc;
+}

@@ -1,0 +1,120 @@
+"""BaseCVAE: what every slate CVAE shares (reference models/cvae.py:7-118).
+
+Same constructor arguments, attributes (``docEmbed``, ``userEmbed``, ``device``, ``candidateFlag``,
+``slate_size``, ``latent_size``, ``noUser``) and methods as the reference class, but the arithmetic is
+done by the HIP kernels of libpcvae_hip.so (``pivotcvae_amd.ops``); there is no eager fallback.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .._hip import PREC_F32, PREC_NAMES
+
+
+def _normalized_rows(w):
+    # F.normalize(w, p=2, dim=1): x / max(||x||_2, 1e-12)   (one-off at construction, models/cvae.py:31,39)
+    return w / w.pow(2).sum(dim=1, keepdim=True).sqrt().clamp_min(1e-12)
+
+
+class BaseCVAE(nn.Module):
+    def __init__(self, embeddings, u_embeddings, slate_size, latent_size, no_user, device, fine_tune=False):
+        super().__init__()
+        if fine_tune:
+            raise NotImplementedError("fine_tune=True (trainable item/user tables) is outside the accelerated path: "
+                                      "every reference model passes fine_tune=False (models/pivotcvae.py:319)")
+        self.candidateFlag = False  # forward() scores candidate sets (True) or the whole catalog (False)
+        self.slate_size = slate_size
+        self.latent_size = latent_size
+        self.noUser = no_user
+        self.device = device
+        with torch.no_grad():
+            self.docEmbed = nn.Embedding(embeddings.weight.shape[0], embeddings.weight.shape[1])
+            self.docEmbed.weight.data.copy_(_normalized_rows(embeddings.weight.detach().float()))
+            self.docEmbed.weight.requires_grad = False
+            if not no_user:
+                self.userEmbed = nn.Embedding(u_embeddings.weight.shape[0], u_embeddings.weight.shape[1])
+                self.userEmbed.weight.data.copy_(_normalized_rows(u_embeddings.weight.detach().float()))
+                self.userEmbed.weight.requires_grad = False
+        # precision of the [R,D]x[D,N] catalog contraction: "f32" (exact), "bf16x3", "bf16"
+        self.catalog_precision = PREC_F32
+        # Philox stream for eps when the caller does not supply one
+        self.rng_seed = 0
+        self._rng_offset = 0
+        self._table = None
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def set_catalog_precision(self, name):
+        self.catalog_precision = PREC_NAMES[name] if isinstance(name, str) else int(name)
+        return self
+
+    def catalog_table(self):
+        """CatalogTable over docEmbed.weight (caches the bf16 copies used by the MFMA bf16 modes)."""
+        w = self.docEmbed.weight
+        if self._table is None or self._table.weight is not w:
+            self._table = ops.CatalogTable(w)
+        return self._table
+
+    def __getstate__(self):  # keep torch.save(model) working: device scratch is not part of the model
+        state = self.__dict__.copy()
+        state["_table"] = None
+        return state
+
+    def _mlp_layers(self, prefix, n):
+        return [(getattr(self, f"{prefix}_{i + 1}").weight, getattr(self, f"{prefix}_{i + 1}").bias) for i in range(n)]
+
+    def _head(self, name):
+        m = getattr(self, name)
+        return [(m.weight, m.bias)]
+
+    def _next_offset(self, n):
+        o = self._rng_offset
+        self._rng_offset += int(n)
+        return o
+
+    # ---- reference API --------------------------------------------------------------------------
+    def encode(self, emb, c, u_emb=None):
+        raise NotImplementedError
+
+    def decode(self, z, c, u_emb=None):
+        raise NotImplementedError
+
+    def get_prior(self, r, u=None):
+        raise NotImplementedError
+
+    def forward(self, s, r, candidates=None, u=None):
+        raise NotImplementedError
+
+    def recommend(self, r, u=None, return_item=False):
+        raise NotImplementedError
+
+    def log(self, logger):
+        raise NotImplementedError
+
+    def reparametrize(self, mu, logvar, eps=None):
+        """z = eps * exp(0.5 logvar) + mu (models/cvae.py:79-83).
+
+        eps=None draws N(0,1) inside the kernel (Philox keyed by ``rng_seed`` and a running offset);
+        pass eps to reproduce a reference run exactly."""
+        off = 0 if eps is not None else self._next_offset(mu.numel())
+        z, self._last_eps = ops.reparam(mu, logvar, eps, seed=self.rng_seed, offset=off)
+        return z
+
+    def get_condition(self, r):
+        return ops.condition(r, self.slate_size)
+
+    def get_recommended_item(self, embeddings):
+        return ops.catalog_argmax(embeddings.reshape(-1, self.feature_size), self.catalog_table(),
+                                  prec=self.catalog_precision)
+
+    def _user_rows(self, u, B):
+        return None if self.noUser else ops.gather_rows(self.userEmbed.weight, u.reshape(-1)).reshape(B, -1)
+
+    def sample_encoding(self, s, r, u=None):
+        B = s.shape[0]
+        cond = self.get_condition(r)
+        emb = ops.gather_rows(self.docEmbed.weight, s.reshape(-1), group=s.shape[1])
+        return self.encode(emb, cond, self._user_rows(u, B))
+
+    # the north_star text calls the generation method generate(); the reference's name is recommend()
+    def generate(self, r, u=None, return_item=False, **kw):
+        return self.recommend(r, u, return_item=return_item, **kw)

@@ -1,0 +1,207 @@
+"""UserPivotCVAE and its 7 pivot-rule variants (reference models/pivotcvae.py:33-461).
+
+A slate is generated as: encoder MLP -> (mu, logvar) -> z -> pivot-selection MLP (PSM) -> pivot item ->
+slate-completion MLP (SCM) -> S-1 more slot vectors -> dot with the item catalog.  The 8 registry entries
+differ only in how the pivot is chosen during training / inference:
+
+    gt  ground-truth first item      pt / pi  catalog argmax of the PSM output
+    sgt sampled around ground truth  spt / spi sampled from sigmoid(PSM output . E^T)
+
+The arithmetic runs in libpcvae_hip.so (see pivotcvae_amd.ops); this file is host-side orchestration that
+keeps the reference's class names, constructor, attributes, state_dict keys and method signatures.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from .cvae import BaseCVAE
+from .listcvae import _stack
+
+
+class UserPivotCVAE(BaseCVAE):
+    TRAIN_RULE = "gt"
+    INFER_RULE = "pi"
+
+    def __init__(self, embeddings, u_embeddings, slate_size, feature_size, latent_size, condition_size,
+                 encoder_struct, psm_struct, scm_struct, prior_struct, no_user, device, fine_tune=False):
+        super().__init__(embeddings, u_embeddings, slate_size, latent_size, no_user, device, fine_tune)
+        u = 0 if no_user else feature_size
+        assert encoder_struct[0] == slate_size * feature_size + condition_size + u
+        assert psm_struct[0] == latent_size + condition_size + u
+        assert psm_struct[-1] == feature_size
+        assert scm_struct[0] == latent_size + condition_size + feature_size + u
+        assert scm_struct[-1] == (slate_size - 1) * feature_size
+        assert prior_struct[0] == condition_size + u
+        self.feature_size = feature_size
+        self.condition_size = condition_size
+        self.encoderStruct = encoder_struct
+        self.psmStruct = psm_struct
+        self.scmStruct = scm_struct
+        self.priorStruct = prior_struct
+        self._n_enc = _stack(self, "enc", encoder_struct)
+        self.encmu = nn.Linear(encoder_struct[-1], latent_size)
+        self.enclogvar = nn.Linear(encoder_struct[-1], latent_size)
+        self._n_psm = _stack(self, "psm", psm_struct)
+        self._n_scm = _stack(self, "scm", scm_struct)
+        self._n_prior = _stack(self, "prior", prior_struct)
+        self.priorMu = nn.Linear(prior_struct[-1], latent_size)
+        self.priorLogvar = nn.Linear(prior_struct[-1], latent_size)
+        self.pivot_override = None  # test hook: feed recorded Categorical draws back in
+        self.last_pivot = None      # pivot item ids chosen by the most recent decode()
+        self.to(self.device)
+
+    # ---- encoder / prior -----------------------------------------------------------------------
+    def encode(self, emb, c, u_emb=None):
+        x = ops.concat([emb, c] if self.noUser else [emb, c, u_emb])
+        h = ops.mlp(x, self._mlp_layers("enc", self._n_enc), last_linear=False)
+        return ops.mlp(h, self._head("encmu"), True), ops.mlp(h, self._head("enclogvar"), True)
+
+    def _prior_from(self, cond, u_emb):
+        x = cond if self.noUser else ops.concat([cond, u_emb])
+        h = ops.mlp(x, self._mlp_layers("prior", self._n_prior), last_linear=False)
+        return ops.mlp(h, self._head("priorMu"), True), ops.mlp(h, self._head("priorLogvar"), True)
+
+    def get_prior(self, r, u=None):
+        return self._prior_from(self.get_condition(r), self._user_rows(u, r.shape[0]))
+
+    # ---- pivot selection ------------------------------------------------------------------------
+    def _pivot_index(self, rule, pivot_output, true_pivot):
+        """Item id of the pivot for one of the rules gt / pt|pi / spt|spi / sgt (never differentiable)."""
+        if rule == "gt":
+            return true_pivot
+        if self.pivot_override is not None and rule in ("spt", "spi", "sgt"):
+            return self.pivot_override
+        table = self.catalog_table()
+        if rule in ("pt", "pi"):
+            return ops.catalog_argmax(pivot_output, table, prec=self.catalog_precision)
+        if rule in ("spt", "spi"):
+            query = pivot_output.detach()
+        else:  # sgt: scores of the ground-truth pivot's own embedding against the catalog
+            query = ops.gather_rows(self.docEmbed.weight, true_pivot)
+        B = query.shape[0]
+        return ops.catalog_sample(query, table, seed=self.rng_seed ^ 0x5A17, row_offset=self._next_offset(B),
+                                  prec=self.catalog_precision)
+
+    def pick_pivot(self, pivot_output, true_pivot):
+        """-> pivot embedding [B, D]; rule = TRAIN_RULE when a true pivot is given, else INFER_RULE."""
+        training = len(true_pivot) > 0
+        p = self._pivot_index(self.TRAIN_RULE if training else self.INFER_RULE, pivot_output, true_pivot)
+        self.last_pivot = p
+        return ops.gather_rows(self.docEmbed.weight, p)
+
+    def decode(self, z, c, u_emb=None, true_pivot=[]):
+        B = z.shape[0]
+        x = ops.concat([z, c] if self.noUser else [z, c, u_emb])
+        pivot_output = ops.mlp(x, self._mlp_layers("psm", self._n_psm), last_linear=True)
+        pivot_emb = self.pick_pivot(pivot_output, true_pivot)
+        return self._complete(z, c, u_emb, pivot_emb)
+
+    def _complete(self, z, c, u_emb, pivot_emb):
+        B = z.shape[0]
+        x = ops.concat([z, c, pivot_emb] if self.noUser else [z, c, pivot_emb, u_emb])
+        rest = ops.mlp(x, self._mlp_layers("scm", self._n_scm), last_linear=True)
+        return ops.concat([pivot_emb, rest]).reshape(B, self.slate_size, self.feature_size)
+
+    # ---- reference entry points -----------------------------------------------------------------
+    def forward(self, s, r, candidates=None, u=None, eps=None):
+        """-> (p, rx, z, emb, z_mu, z_logvar) exactly like the reference; p is the DENSE [B*S, N] logits (or the
+        [B*S, Cn] candidate logits), so this entry point is for catalogs where that matrix fits."""
+        B = s.shape[0]
+        cond = self.get_condition(r)
+        emb = ops.gather_rows(self.docEmbed.weight, s.reshape(-1), group=s.shape[1])
+        u_emb = self._user_rows(u, B)
+        z_mu, z_logvar = self.encode(emb, cond, u_emb)
+        z = self.reparametrize(z_mu, z_logvar, eps)
+        rx = self.decode(z, cond, u_emb=u_emb, true_pivot=s[:, 0])
+        prox = rx.reshape(-1, self.feature_size)
+        if self.candidateFlag:
+            p = ops.candidate_scores(prox, self.docEmbed.weight, candidates.reshape(prox.shape[0], -1))
+        else:
+            p = ops.dense_scores(prox, self.docEmbed.weight)
+        return p, rx, z, emb, z_mu, z_logvar
+
+    def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
+             eps_offset=None):
+        """Fused counterpart of train_generative.get_gen_loss (mask-train path) -> (loss, recLoss, KLD).
+
+        The [B*S, N] logits never exist: the full-catalog softmax CE (with the reference's downsample
+        semantics when n_neg < N) and its gradient come from one streaming pass over the catalog.
+        ``row_offset`` = index of this shard's first slate in the global batch (data parallel), so the
+        Philox mask / eps streams do not depend on the world size; ``inv_count`` overrides the 1/(B*S)
+        of the 'mean' (a rank passes 1/(B_local*S*world_size)).
+        With TRAIN_RULE == "gt" the PSM is skipped: its output is unused and it never receives a gradient in
+        the reference either.
+        """
+        B, S = s.shape
+        N = self.docEmbed.weight.shape[0]
+        cond = self.get_condition(r)
+        emb = ops.gather_rows(self.docEmbed.weight, s.reshape(-1), group=S)
+        u_emb = self._user_rows(u, B)
+        pmu, plv = self._prior_from(cond, u_emb)
+        z_mu, z_logvar = self.encode(emb, cond, u_emb)
+        if eps is None:  # in-kernel Philox; a data-parallel caller pins the stream position explicitly
+            off = self._next_offset(B * self.latent_size) if eps_offset is None else int(eps_offset)
+            z, self._last_eps = ops.reparam(z_mu, z_logvar, None, seed=self.rng_seed, offset=off)
+        else:
+            z = self.reparametrize(z_mu, z_logvar, eps)
+        true_pivot = s[:, 0].contiguous()
+        if self.TRAIN_RULE == "gt":
+            self.last_pivot = true_pivot
+            pivot_emb = ops.gather_rows(self.docEmbed.weight, true_pivot)
+            rx = self._complete(z, cond, u_emb, pivot_emb)
+        else:
+            rx = self.decode(z, cond, u_emb=u_emb, true_pivot=true_pivot)
+        keep_prob = 1.0 if n_neg is None else float(n_neg) / N
+        if keep_prob > 1.0:
+            raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
+        rec = ops.catalog_ce(rx.reshape(-1, self.feature_size), self.catalog_table(), s.reshape(-1), keep_prob,
+                             mask_seed, row_offset * S, keep_mask, self.catalog_precision, inv_count)
+        k = ops.kld(z_mu, z_logvar, pmu, plv)
+        return rec + beta * k, rec, k
+
+    def recommend(self, r, u=None, return_item=False, random_pivot=False, eps=None):
+        B = r.shape[0]
+        cond = self.get_condition(r)
+        u_emb = self._user_rows(u, B)
+        z_mu, z_logvar = self._prior_from(cond, u_emb)
+        z = self.reparametrize(z_mu, z_logvar, eps)
+        rx = self.decode(z, cond, u_emb)
+        if return_item:
+            return self.get_recommended_item(rx.reshape(-1, self.feature_size)), z_mu
+        return rx, z_mu
+
+    def log(self, logger):
+        logger.log("\tfeature size: " + str(self.feature_size))
+        logger.log("\tslate size: " + str(self.slate_size))
+        logger.log("\tz size: " + str(self.latent_size))
+        logger.log("\tcondition size: " + str(self.condition_size))
+        logger.log("\tuser is ignored: " + str(self.noUser))
+        logger.log("\tencoder struct: " + str(self.encoderStruct))
+        logger.log("\tpsm struct: " + str(self.psmStruct))
+        logger.log("\tscm struct: " + str(self.scmStruct))
+        logger.log("\tprior struct: " + str(self.priorStruct))
+        logger.log("\tdevice: " + str(self.device))
+
+
+def _variant(name, train_rule, infer_rule, doc):
+    return type(name, (UserPivotCVAE,), {"TRAIN_RULE": train_rule, "INFER_RULE": infer_rule, "__doc__": doc,
+                                         "__module__": __name__})
+
+
+UserPivotCVAE2 = _variant("UserPivotCVAE2", "pt", "pi", "best pivot in training and inference")
+UserPivotCVAE_PrePermute = _variant("UserPivotCVAE_PrePermute", "spt", "pi", "sampled pivot in training, best at inference")
+UserPivotCVAE_PrePermute2 = _variant("UserPivotCVAE_PrePermute2", "sgt", "pi", "sampled ground truth in training, best at inference")
+UserPivotCVAE_PrePermute3 = _variant("UserPivotCVAE_PrePermute3", "gt", "spi", "ground truth in training, sampled at inference")
+UserPivotCVAE_PrePermute4 = _variant("UserPivotCVAE_PrePermute4", "pt", "spi", "best pivot in training, sampled at inference")
+UserPivotCVAE_PrePermute5 = _variant("UserPivotCVAE_PrePermute5", "spt", "spi", "sampled pivot in training and inference")
+UserPivotCVAE_PrePermute6 = _variant("UserPivotCVAE_PrePermute6", "sgt", "spi", "sampled ground truth in training, sampled at inference")
+
+PIVOTCVAE_MODELS = {
+    "pivotcvae_gt_pi": UserPivotCVAE, "pivotcvae_pt_pi": UserPivotCVAE2,
+    "pivotcvae_spt_pi": UserPivotCVAE_PrePermute, "pivotcvae_sgt_pi": UserPivotCVAE_PrePermute2,
+    "pivotcvae_gt_spi": UserPivotCVAE_PrePermute3, "pivotcvae_pt_spi": UserPivotCVAE_PrePermute4,
+    "pivotcvae_spt_spi": UserPivotCVAE_PrePermute5, "pivotcvae_sgt_spi": UserPivotCVAE_PrePermute6,
+}
+
+# BASELINE.json's north_star says "models.pivotcvae.PivotCVAE": an alias of the benchmark variant
+PivotCVAE = UserPivotCVAE

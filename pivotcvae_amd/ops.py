@@ -1,0 +1,449 @@
+"""Host-side operators: thin autograd wrappers over the C ABI (include/pcvae.h).
+
+Every function takes ROCm tensors, marshals raw pointers + the current HIP stream into
+libpcvae_hip.so and returns tensors allocated by torch's caching allocator.  Backward passes are
+hand-written (they call the backward kernels); nothing here falls back to eager PyTorch math.
+"""
+import torch
+
+from . import _hip
+from ._hip import ACT_LEAKY, ACT_NONE, PREC_BF16, PREC_BF16X3, PREC_F32, check, lib, ptr, require_device, stream
+
+F32 = torch.float32
+
+
+def _c2d(t):
+    """2-D fp32 view with contiguous rows (copy only if the layout forces it)."""
+    if t.dtype != F32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    if t.dim() != 2:
+        raise ValueError(f"expected a 2-D tensor, got {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+# ------------------------------------------------------------------------------ K1 / K2 / concat
+def gather_rows(table, idx, out=None, group=1):
+    """out[i // group, (i % group) * D : ...] = table[idx[i]]   (nn.Embedding lookup, frozen table).
+
+    ``out`` may be a column window of a wider buffer (the torch.cat of the reference disappears).
+    """
+    require_device(table, idx, out)
+    idx = idx.reshape(-1)
+    if idx.dtype != torch.int64:
+        idx = idx.to(torch.int64)
+    idx = idx.contiguous()
+    n, D = idx.numel(), table.shape[1]
+    if n % group:
+        raise ValueError("gather_rows: index count not a multiple of group")
+    if out is None:
+        out = torch.empty(n // group, group * D, dtype=F32, device=table.device)
+    check(lib().pcvae_gather_rows(ptr(table, F32), table.shape[0], D, ptr(idx), n, group, ptr(out, F32), _ld(out),
+                                  stream()), "gather_rows")
+    return out
+
+
+def condition(r, S, out=None):
+    """one-hot of the click count, [B, S+1] (models/cvae.py:85-92)."""
+    require_device(r, out)
+    r = r.to(F32).contiguous()
+    B = r.shape[0]
+    if out is None:
+        out = torch.empty(B, S + 1, dtype=F32, device=r.device)
+    check(lib().pcvae_condition(ptr(r, F32), B, S, ptr(out, F32), _ld(out), stream()), "condition")
+    return out
+
+
+def copy2d(src, dst):
+    require_device(src, dst)
+    src = _c2d(src)
+    check(lib().pcvae_copy2d(ptr(src, F32), _ld(src), ptr(dst, F32), _ld(dst), src.shape[0], src.shape[1], stream()),
+          "copy2d")
+    return dst
+
+
+class _Concat(torch.autograd.Function):
+    """torch.cat(parts, 1) as strided copies into one buffer; backward hands out column windows."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        require_device(*parts)
+        B = parts[0].shape[0]
+        widths = [p.shape[1] for p in parts]
+        out = torch.empty(B, sum(widths), dtype=F32, device=parts[0].device)
+        c = 0
+        for p, w in zip(parts, widths):
+            copy2d(p, out[:, c:c + w])
+            c += w
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, c = [], 0
+        for i, w in enumerate(ctx.widths):
+            outs.append(g[:, c:c + w] if ctx.needs_input_grad[i] else None)
+            c += w
+        return tuple(outs)
+
+
+def concat(parts):
+    return _Concat.apply(*parts)
+
+
+# ------------------------------------------------------------------------------------------- K3
+def linear_fwd_raw(x, W, b, act, out=None):
+    x = _c2d(x)
+    M, K = x.shape
+    N = W.shape[0]
+    if W.shape[1] != K:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {W.shape[1]}x{N})")
+    if out is None:
+        out = torch.empty(M, N, dtype=F32, device=x.device)
+    check(lib().pcvae_linear_fwd(ptr(x, F32), _ld(x), ptr(W, F32), _ld(W), ptr(b, F32) if b is not None else None,
+                                 ptr(out, F32), _ld(out), M, N, K, act, stream()), "linear_fwd")
+    return out
+
+
+def linear_bwd_input_raw(gy, W, xact=None, out=None):
+    gy = _c2d(gy)
+    M, N = gy.shape
+    K = W.shape[1]
+    if out is None:
+        out = torch.empty(M, K, dtype=F32, device=gy.device)
+    check(lib().pcvae_linear_bwd_input(ptr(gy, F32), _ld(gy), ptr(W, F32), _ld(W),
+                                       ptr(xact, F32) if xact is not None else None,
+                                       _ld(xact) if xact is not None else 0, ptr(out, F32), _ld(out), M, N, K,
+                                       stream()), "linear_bwd_input")
+    return out
+
+
+def linear_bwd_weight_raw(gy, x, dW, db):
+    """dW += gy^T x ; db += colsum(gy)  (accumulating into the given buffers)."""
+    gy, x = _c2d(gy), _c2d(x)
+    M, N = gy.shape
+    K = x.shape[1]
+    check(lib().pcvae_linear_bwd_weight(ptr(gy, F32), _ld(gy), ptr(x, F32), _ld(x), ptr(dW, F32), _ld(dW),
+                                        ptr(db, F32) if db is not None else None, M, N, K, stream()),
+          "linear_bwd_weight")
+
+
+def leaky_bwd_(g, y):
+    check(lib().pcvae_leaky_bwd(ptr(g, F32), _ld(g), ptr(y, F32), _ld(y), g.shape[0], g.shape[1], stream()),
+          "leaky_bwd")
+    return g
+
+
+class _MLP(torch.autograd.Function):
+    """A stack of Linear(+LeakyReLU) layers as one autograd node.
+
+    forward keeps the activated outputs; backward walks the stack once: LeakyReLU' of an inner layer is
+    fused into the epilogue of the input-gradient GEMM of the layer above it.
+    """
+
+    @staticmethod
+    def forward(ctx, x, last_linear, *params):
+        require_device(x, *params)
+        n = len(params) // 2
+        x = _c2d(x)
+        acts = [x]
+        h = x
+        for i in range(n):
+            act = ACT_NONE if (last_linear and i == n - 1) else ACT_LEAKY
+            h = linear_fwd_raw(h, params[2 * i], params[2 * i + 1], act)
+            acts.append(h)
+        ctx.last_linear = last_linear
+        ctx.n = n
+        ctx.save_for_backward(*acts, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, params = saved[: n + 1], saved[n + 1:]
+        g = _c2d(g)
+        if not ctx.last_linear:  # the top layer is activated: apply its LeakyReLU' explicitly
+            g = leaky_bwd_(g.clone(), acts[n])
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            W, b = params[2 * i], params[2 * i + 1]
+            if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
+                dW = torch.zeros_like(W)
+                db = torch.zeros_like(b)
+                linear_bwd_weight_raw(g, acts[i], dW, db)
+                grads[2 * i], grads[2 * i + 1] = dW, db
+            if i > 0:
+                g = linear_bwd_input_raw(g, W, xact=acts[i])  # acts[i] is layer i-1's activated output
+            elif ctx.needs_input_grad[0]:
+                g = linear_bwd_input_raw(g, W, xact=None)
+            else:
+                g = None
+        return (g, None) + tuple(grads)
+
+
+def mlp(x, layers, last_linear):
+    """layers: list of (weight [out,in], bias [out])."""
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    return _MLP.apply(x, last_linear, *flat)
+
+
+class _DenseScores(torch.autograd.Function):
+    """p = rx @ E^T with E frozen (models/pivotcvae.py:274); used when the caller wants the dense logits."""
+
+    @staticmethod
+    def forward(ctx, rx, E):
+        require_device(rx, E)
+        ctx.save_for_backward(E)
+        return linear_fwd_raw(rx, E, None, ACT_NONE)
+
+    @staticmethod
+    def backward(ctx, g):
+        (E,) = ctx.saved_tensors
+        return linear_bwd_input_raw(g, E), None
+
+
+def dense_scores(rx, E):
+    return _DenseScores.apply(rx, E)
+
+
+# ------------------------------------------------------------------------------------------- K4
+class _Reparam(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps, seed, offset):
+        require_device(mu, logvar, eps)
+        mu, logvar = _c2d(mu).contiguous(), _c2d(logvar).contiguous()
+        B, Z = mu.shape
+        z = torch.empty(B, Z, dtype=F32, device=mu.device)
+        eps_used = torch.empty(B, Z, dtype=F32, device=mu.device)
+        if eps is not None:
+            eps = eps.to(F32).contiguous()
+        check(lib().pcvae_reparam_fwd(ptr(mu, F32), ptr(logvar, F32), ptr(eps, F32) if eps is not None else None,
+                                      seed, offset, ptr(z, F32), Z, ptr(eps_used, F32), B, Z, stream()),
+              "reparam_fwd")
+        ctx.save_for_backward(eps_used, logvar)
+        ctx.mark_non_differentiable(eps_used)
+        return z, eps_used
+
+    @staticmethod
+    def backward(ctx, gz, _geps):
+        eps, logvar = ctx.saved_tensors
+        gz = _c2d(gz)
+        B, Z = eps.shape
+        dmu = torch.zeros_like(eps)
+        dlv = torch.zeros_like(eps)
+        check(lib().pcvae_reparam_bwd(ptr(gz, F32), _ld(gz), ptr(eps, F32), ptr(logvar, F32), ptr(dmu, F32),
+                                      ptr(dlv, F32), B, Z, stream()), "reparam_bwd")
+        return dmu, dlv, None, None, None
+
+
+def reparam(mu, logvar, eps=None, seed=0, offset=0):
+    """-> (z, eps_used).  eps=None draws N(0,1) with the in-kernel Philox stream (seed, offset)."""
+    return _Reparam.apply(mu, logvar, eps, int(seed), int(offset))
+
+
+# ------------------------------------------------------------------------------------------- K7
+class _KLD(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, lv, pmu, plv):
+        require_device(mu, lv, pmu, plv)
+        mu, lv, pmu, plv = (t.contiguous() for t in (mu, lv, pmu, plv))
+        out = torch.empty((), dtype=F32, device=mu.device)
+        check(lib().pcvae_kld_fwd(ptr(mu, F32), ptr(lv, F32), ptr(pmu, F32), ptr(plv, F32), mu.numel(), ptr(out, F32),
+                                  stream()), "kld_fwd")
+        ctx.save_for_backward(mu, lv, pmu, plv)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, lv, pmu, plv = ctx.saved_tensors
+        g = g.contiguous()
+        outs = [torch.zeros_like(mu) if ctx.needs_input_grad[i] else None for i in range(4)]
+        check(lib().pcvae_kld_bwd(ptr(mu, F32), ptr(lv, F32), ptr(pmu, F32), ptr(plv, F32), mu.numel(), ptr(g, F32), 1.0,
+                                  *(ptr(o, F32) if o is not None else None for o in outs), stream()), "kld_bwd")
+        return tuple(outs)
+
+
+def kld(mu, logvar, pmu, plogvar):
+    """-1/2 sum(1 + lv - plv - (exp(lv) + (mu - pmu)^2) / exp(plv)) as a 0-d tensor."""
+    return _KLD.apply(mu, logvar, pmu, plogvar)
+
+
+# -------------------------------------------------------------------------------------- K5 / K6
+class CatalogTable:
+    """The frozen item table E[N, D] plus (lazily) its bf16 hi / lo copies for the MFMA bf16 modes."""
+
+    def __init__(self, weight):
+        self.weight = weight
+        self._ver = None
+        self._hi = self._lo = None
+
+    def operands(self, prec):
+        w = self.weight
+        if prec == PREC_F32:
+            return w, None
+        key = (w.data_ptr(), w._version, tuple(w.shape))
+        if self._ver != key:
+            w32 = w.detach().contiguous()
+            hi = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
+            lo = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
+            check(lib().pcvae_split_bf16(ptr(w32, F32), w32.numel(), ptr(hi), ptr(lo), stream()), "split_bf16")
+            self._hi, self._lo, self._ver = hi, lo, key
+        return self._hi, (self._lo if prec == PREC_BF16X3 else None)
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes):
+    """Grow-only scratch buffer per device (the C ABI never allocates)."""
+    buf = _ws_cache.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[device] = buf
+    return buf
+
+
+def _as_table(E):
+    return E if isinstance(E, CatalogTable) else CatalogTable(E)
+
+
+def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32,
+                   want_dx=True):
+    """-> (nll [R], lse [R], dx [R, D] or None); see pcvae_catalog_ce in include/pcvae.h."""
+    table = _as_table(table)
+    require_device(rx, table.weight, target, keep_mask)
+    rx = _c2d(rx).contiguous()
+    R, D = rx.shape
+    N = table.weight.shape[0]
+    target = target.reshape(-1).to(torch.int64).contiguous()
+    if target.numel() != R:
+        raise ValueError("catalog_ce: one target per row expected")
+    if keep_mask is not None:
+        keep_mask = keep_mask.to(torch.uint8).contiguous()
+        if tuple(keep_mask.shape) != (R, N):
+            raise ValueError("catalog_ce: keep_mask must be [R, N]")
+    E, E_lo = table.operands(prec)
+    nll = torch.empty(R, dtype=F32, device=rx.device)
+    lse = torch.empty(R, dtype=F32, device=rx.device)
+    dx = torch.empty(R, D, dtype=F32, device=rx.device) if want_dx else None
+    nbytes = lib().pcvae_catalog_ws_bytes(R, N, D, 1 if want_dx else 0)
+    ws = _workspace(rx.device, nbytes)
+    check(lib().pcvae_catalog_ce(ptr(rx, F32), R, ptr(E), ptr(E_lo), N, D, prec, ptr(target), float(keep_prob),
+                                 int(seed), int(row_offset), ptr(keep_mask), ptr(nll, F32), ptr(lse, F32), ptr(dx),
+                                 ptr(ws), ws.numel(), stream()), "catalog_ce")
+    return nll, lse, dx
+
+
+class _CatalogCE(torch.autograd.Function):
+    """mean-reduced (times ``inv_count``) full-catalog softmax CE; backward = saved direction * upstream."""
+
+    @staticmethod
+    def forward(ctx, rx, table, target, keep_prob, seed, row_offset, keep_mask, prec, inv_count):
+        want_dx = rx.requires_grad
+        nll, _lse, dx = catalog_ce_raw(rx.detach(), table, target, keep_prob, seed, row_offset, keep_mask, prec, want_dx)
+        out = torch.empty((), dtype=F32, device=rx.device)
+        check(lib().pcvae_sum(ptr(nll, F32), nll.numel(), float(inv_count), ptr(out, F32), stream()), "sum")
+        ctx.inv_count = float(inv_count)
+        if want_dx:
+            ctx.save_for_backward(dx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(dx)
+        check(lib().pcvae_scale_rows(ptr(dx, F32), _ld(dx), ptr(out, F32), _ld(out), dx.shape[0], dx.shape[1],
+                                     ptr(g, F32), ctx.inv_count, stream()), "scale_rows")
+        return (out,) + (None,) * 8
+
+
+def catalog_ce(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32, inv_count=None):
+    """CrossEntropyLoss(downsample(rx @ E^T), target) without the [R, N] logits (train_generative.py:59).
+
+    ``inv_count`` defaults to 1/R (the 'mean'); data-parallel ranks pass 1/(R_local * world_size).
+    """
+    R = rx.shape[0]
+    return _CatalogCE.apply(rx, _as_table(table), target, keep_prob, seed, row_offset, keep_mask, prec,
+                            (1.0 / R) if inv_count is None else inv_count)
+
+
+def catalog_argmax(x, table, prec=PREC_F32, return_best=False):
+    """first-index argmax_n <x_r, E_n> (models/cvae.py:97-101) -> int64 [R]."""
+    table = _as_table(table)
+    require_device(x, table.weight)
+    x = _c2d(x.detach()).contiguous()
+    R, D = x.shape
+    N = table.weight.shape[0]
+    E, E_lo = table.operands(prec)
+    idx = torch.empty(R, dtype=torch.int64, device=x.device)
+    best = torch.empty(R, dtype=F32, device=x.device) if return_best else None
+    nbytes = lib().pcvae_catalog_ws_bytes(R, N, D, 0)
+    ws = _workspace(x.device, nbytes)
+    check(lib().pcvae_catalog_argmax(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, prec, ptr(idx), ptr(best), ptr(ws),
+                                     ws.numel(), stream()), "catalog_argmax")
+    return (idx, best) if return_best else idx
+
+
+def catalog_sample(x, table, seed=0, row_offset=0, prec=PREC_F32):
+    """idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) (models/pivotcvae.py:349-351) via in-kernel Gumbel-max."""
+    table = _as_table(table)
+    require_device(x, table.weight)
+    x = _c2d(x.detach()).contiguous()
+    R, D = x.shape
+    N = table.weight.shape[0]
+    E, E_lo = table.operands(prec)
+    idx = torch.empty(R, dtype=torch.int64, device=x.device)
+    ws = _workspace(x.device, lib().pcvae_catalog_ws_bytes(R, N, D, 0))
+    check(lib().pcvae_catalog_sample(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, prec, int(seed), int(row_offset),
+                                     ptr(idx), ptr(ws), ws.numel(), stream()), "catalog_sample")
+    return idx
+
+
+# ------------------------------------------------------------------------------------------- K9
+class _CandidateScores(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rx, E, cand):
+        require_device(rx, E, cand)
+        rx = _c2d(rx).contiguous()
+        R, D = rx.shape
+        cand = cand.reshape(R, -1).to(torch.int64).contiguous()
+        Cn = cand.shape[1]
+        p = torch.empty(R, Cn, dtype=F32, device=rx.device)
+        check(lib().pcvae_candidate_scores(ptr(rx, F32), R, ptr(E, F32), E.shape[0], D, ptr(cand), Cn, ptr(p, F32),
+                                           stream()), "candidate_scores")
+        ctx.save_for_backward(E, cand)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        E, cand = ctx.saved_tensors
+        g = _c2d(g).contiguous()
+        R, Cn = g.shape
+        D = E.shape[1]
+        drx = torch.empty(R, D, dtype=F32, device=g.device)
+        check(lib().pcvae_candidate_scores_bwd(ptr(g, F32), R, ptr(E, F32), E.shape[0], D, ptr(cand), Cn,
+                                               ptr(drx, F32), stream()), "candidate_scores_bwd")
+        return drx, None, None
+
+
+def candidate_scores(rx, E, cand):
+    """p[r, c] = <E[cand[r, c]], rx_r> (models/pivotcvae.py:265-271)."""
+    return _CandidateScores.apply(rx, E, cand)
+
+
+# ------------------------------------------------------------------------------------------- K8
+def adam_step_(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+    require_device(p, g, m, v)
+    check(lib().pcvae_adam_step(ptr(p, F32), ptr(g, F32), ptr(m, F32), ptr(v, F32), p.numel(), lr, b1, b2, eps, step,
+                                grad_scale, stream()), "adam_step")

@@ -1,0 +1,52 @@
+"""Flat-buffer Adam (K8) - the optimiser of reference train_generative.py:103 (torch.optim.Adam, defaults).
+
+All trainable parameters are re-homed into ONE contiguous fp32 buffer (their nn.Parameter objects, names and
+state_dict keys are unchanged: each becomes a view), and so are their gradients.  One step is then one
+memset + one HIP kernel, and data parallelism needs exactly one all-reduce over the gradient buffer.
+
+Parameters that never receive a gradient (the PSM stack) keep a zero gradient; Adam with
+g = 0, m = 0, v = 0 leaves them bit-identical, which is what the reference's "skip grad None" does.
+"""
+import torch
+
+from . import ops
+
+
+class FlatAdam:
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+        self.t = 0
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, g in zip(self.params, self._grad_views()):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g  # someone set it to None / replaced it: re-attach the flat view
+
+    def _grad_views(self):
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            yield self.grad[off:off + n].view(p.shape)
+            off += n
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps,
+                       grad_scale)

@@ -1,0 +1,102 @@
+"""Host-side mirror of the hot part of reference train_generative.py (downsample :36-42, get_gen_loss :44-65,
+the optimisation step :120-137) on top of the HIP path.
+
+Two ways in:
+  * ``get_gen_loss(batch_data, model, lossFun, beta, n_neg)`` - same signature and return value as the
+    reference function; the mask-train branch goes through ``model.loss`` (fused full-catalog CE: no
+    [B*S, N] tensor), so it also works where the reference cannot (N = 1M: 328 GB of logits).
+  * ``Trainer`` - zero_grad / loss / backward / (all-reduce) / Adam as one object, single GPU or one
+    process per GPU over RCCL.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .optim import FlatAdam
+
+
+def downsample(pred, slate, n_neg=1000.0):
+    """Reference semantics on a DENSE logits tensor (small catalogs only): mask = onehot(target) OR
+    Bernoulli(n_neg / N); masked-out logits become 0.  Kept for callers that hold a dense ``pred``;
+    the fused path applies the same rule inside the catalog kernel."""
+    if n_neg > pred.shape[1]:
+        raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {pred.shape[1]}")
+    mask = torch.zeros_like(pred)
+    mask.scatter_(1, slate.reshape(-1, 1), 1)
+    mask = mask + torch.bernoulli(torch.ones_like(pred) * (n_neg / pred.shape[1]))
+    mask[mask == 2] = 1
+    return pred * mask
+
+
+def _batch_to_device(batch_data, device):
+    slates = torch.as_tensor(np.asarray(batch_data["slates"]), dtype=torch.long).to(device)
+    users = torch.as_tensor(np.asarray(batch_data["users"]), dtype=torch.long).to(device)
+    targets = torch.as_tensor(np.asarray(batch_data["responses"])).to(torch.float).to(device)
+    return slates, users, targets
+
+
+def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None):
+    """-> (loss, recLoss, KLD), as reference get_gen_loss.  ``lossFun`` is only used on the candidate path."""
+    slates, users, targets = _batch_to_device(batch_data, model.device)
+    if model.candidateFlag:
+        pMu, pLogvar = model.get_prior(targets, users)
+        cand = torch.as_tensor(np.asarray(batch_data["sample_candidates"]), dtype=torch.long).to(model.device)
+        tgt = torch.as_tensor(np.asarray(batch_data["sample_targets"]), dtype=torch.long).to(model.device)
+        pred, _rx, _z, _emb, mu, logvar = model.forward(slates, targets, candidates=cand, u=users, eps=eps)
+        recLoss = lossFun(pred, tgt.reshape(-1))
+        KLD = ops.kld(mu, logvar, pMu, pLogvar)
+        return recLoss + beta * KLD, recLoss, KLD
+    N = model.docEmbed.weight.shape[0]
+    return model.loss(slates, targets, users, beta, n_neg=None if n_neg == N else n_neg, eps=eps)
+
+
+class Trainer:
+    """One optimisation step of reference train_generative.py:124-134, data-parallel aware.
+
+    world_size > 1: every rank holds a replica, takes ``B_global / world_size`` slates, scales its reconstruction
+    term by 1/world_size (it is a MEAN over rows, the KL is a SUM: SURVEY.md 8e), and the flat gradient buffer
+    is summed with ONE all-reduce (RCCL over xGMI on the GPUs).  ``loss_fn(model, s, r, u, **kw)`` is
+    injectable so the collective logic can be exercised on CPU with gloo in tests.
+    """
+
+    def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None):
+        import torch.distributed as dist
+        self.model, self.beta, self.n_neg = model, float(beta), n_neg
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.pg = process_group
+        self.world = self.dist.get_world_size(process_group) if self.dist else 1
+        self.rank = self.dist.get_rank(process_group) if self.dist else 0
+        self.opt = optimizer if optimizer is not None else FlatAdam(model, lr)
+        self.loss_fn = loss_fn or (lambda m, s, r, u, **kw: m.loss(s, r, u, **kw))
+        self.global_step = 0
+
+    def shard(self, *tensors):
+        """Contiguous shard of a global batch for this rank (+ its offset in the global batch)."""
+        B = tensors[0].shape[0]
+        if B % self.world:
+            raise ValueError(f"global batch {B} not divisible by world size {self.world}")
+        per = B // self.world
+        lo = self.rank * per
+        return [t[lo:lo + per] for t in tensors], lo
+
+    def step(self, s, r, u, eps=None, global_batch=None, row_offset=0):
+        """s, r, u: THIS rank's shard.  Returns (loss, recLoss, KLD) as device scalars of the GLOBAL batch
+        (after a 3-float all-reduce when world_size > 1); nothing is synchronised with the host."""
+        B, S = s.shape
+        W = self.world
+        gb = global_batch if global_batch is not None else B * W
+        Z = self.model.latent_size
+        self.opt.zero_grad()
+        loss, rec, kld = self.loss_fn(self.model, s, r, u, beta=self.beta, n_neg=self.n_neg, eps=eps,
+                                      row_offset=row_offset, inv_count=1.0 / (B * S * W),
+                                      eps_offset=(self.global_step * gb + row_offset) * Z,
+                                      mask_seed=self.global_step)
+        loss.backward()
+        if W > 1:
+            self.dist.all_reduce(self.opt.grad, group=self.pg)  # SUM: one collective per step
+            stats = torch.stack([loss.detach(), rec.detach(), kld.detach()])
+            self.dist.all_reduce(stats, group=self.pg)
+            loss, rec, kld = stats[0], stats[1], stats[2]
+        self.opt.step()
+        self.global_step += 1
+        return loss.detach(), rec.detach(), kld.detach()

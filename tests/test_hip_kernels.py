@@ -1,0 +1,323 @@
+"""-m gpu: every C-ABI kernel against the oracle on the same seeded inputs (through ctypes -> libpcvae_hip.so).
+
+Tolerances (fp32 path): GEMM-class results rtol 1e-5 (different summation order from the CPU BLAS),
+catalog CE nll/lse rtol 2e-6 and gradient 2e-5 against the double-precision C oracle, greedy ids BIT-EXACT.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import catalog_oracle as co
+from oracle import pivotcvae_oracle as orc
+from tests import philox_ref
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pivotcvae_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def unit_rows(N, D, seed=0):
+    return orc.normalize_rows(rnd(N, D, seed=seed))
+
+
+# ------------------------------------------------------------------------------------------ K1/K2
+@pytest.mark.parametrize("D,group,pad", [(16, 1, 0), (128, 10, 0), (32, 5, 7), (20, 3, 1), (256, 1, 0)])
+def test_gather_rows(ops, D, group, pad):
+    N, B = 1000, 37
+    table = rnd(N, D, seed=1)
+    idx = torch.randint(0, N, (B * group,), generator=torch.Generator().manual_seed(2))
+    idx[0], idx[-1] = 0, N - 1
+    buf = torch.full((B, group * D + pad), -7.0, device=DEV)
+    out = ops.gather_rows(table.to(DEV), idx.to(DEV), out=buf[:, : group * D] if pad else None, group=group)
+    want = table[idx].reshape(B, group * D)
+    assert torch.equal(out.cpu(), want)
+    if pad:
+        assert torch.all(buf[:, group * D:] == -7.0)  # neighbours of the window untouched
+
+
+def test_gather_empty_and_errors(ops):
+    table = rnd(10, 16).to(DEV)
+    out = ops.gather_rows(table, torch.zeros(0, dtype=torch.long, device=DEV))
+    assert out.shape == (0, 16)
+    with pytest.raises(RuntimeError):
+        ops.gather_rows(rnd(10, 16), torch.zeros(1, dtype=torch.long))  # CPU tensors: loud failure, no fallback
+
+
+def test_condition(ops):
+    r = (rnd(64, 5, seed=3) > 0).float()
+    r[0], r[1] = 0, 1
+    assert torch.equal(ops.condition(r.to(DEV), 5).cpu(), orc.condition(r, 5))
+
+
+def test_concat_and_backward(ops):
+    a, b, c = rnd(9, 4, seed=1), rnd(9, 6, seed=2), rnd(9, 16, seed=3)
+    ad = a.to(DEV).requires_grad_(True)
+    out = ops.concat([ad, b.to(DEV), c.to(DEV)])
+    assert torch.equal(out.cpu(), torch.cat([a, b, c], 1))
+    w = rnd(9, 26, seed=4)
+    (out * w.to(DEV)).sum().backward()
+    assert torch.equal(ad.grad.cpu(), w[:, :4])
+
+
+# --------------------------------------------------------------------------------------------- K3
+@pytest.mark.parametrize("M,K,N", [(7, 102, 24), (64, 16, 64), (300, 1419, 256), (129, 283, 1152), (5, 24, 4)])
+@pytest.mark.parametrize("last_linear", [True, False])
+def test_mlp_forward_backward(ops, M, K, N, last_linear):
+    H = 48
+    x = rnd(M, K, seed=1)
+    Ws = [rnd(H, K, seed=2, scale=0.3), rnd(H, H, seed=3, scale=0.3), rnd(N, H, seed=4, scale=0.3)]
+    bs = [rnd(H, seed=5), rnd(H, seed=6), rnd(N, seed=7)]
+    gout = rnd(M, N, seed=8)
+
+    def ref():
+        xs = x.clone().requires_grad_(True)
+        ps = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in zip(Ws, bs)]
+        h = xs
+        for i, (w, b) in enumerate(ps):
+            h = h @ w.t() + b
+            if not (last_linear and i == 2):
+                h = torch.nn.functional.leaky_relu(h, 0.01)
+        (h * gout).sum().backward()
+        return h, xs.grad, ps
+
+    want, wgx, wps = ref()
+    xd = x.to(DEV).requires_grad_(True)
+    pd = [(w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for w, b in zip(Ws, bs)]
+    got = ops.mlp(xd, pd, last_linear)
+    (got * gout.to(DEV)).sum().backward()
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), wgx, rtol=1e-4, atol=1e-5)
+    for (w, b), (rw, rb) in zip(pd, wps):
+        torch.testing.assert_close(w.grad.cpu(), rw.grad, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(b.grad.cpu(), rb.grad, rtol=1e-4, atol=2e-5)
+
+
+def test_linear_on_column_windows(ops):
+    """inputs / outputs may be column windows of wider buffers (ld > width)."""
+    big = rnd(33, 50, seed=1).to(DEV)
+    W, b = rnd(20, 30, seed=2).to(DEV), rnd(20, seed=3).to(DEV)
+    outbuf = torch.zeros(33, 64, device=DEV)
+    ops.linear_fwd_raw(big[:, 5:35], W, b, 0, out=outbuf[:, 8:28])
+    want = big[:, 5:35].cpu() @ W.cpu().t() + b.cpu()
+    torch.testing.assert_close(outbuf[:, 8:28].cpu(), want, rtol=1e-5, atol=1e-5)
+    assert torch.all(outbuf[:, :8] == 0) and torch.all(outbuf[:, 28:] == 0)
+
+
+def test_dense_scores(ops):
+    rx, E = rnd(35, 16, seed=1), unit_rows(203, 16, seed=2)
+    rd = rx.to(DEV).requires_grad_(True)
+    p = ops.dense_scores(rd, E.to(DEV))
+    torch.testing.assert_close(p.cpu(), rx @ E.t(), rtol=1e-5, atol=1e-6)
+    g = rnd(35, 203, seed=3)
+    (p * g.to(DEV)).sum().backward()
+    torch.testing.assert_close(rd.grad.cpu(), g @ E, rtol=1e-5, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------- K4
+def test_reparam_with_given_eps(ops):
+    mu, lv, eps = rnd(50, 16, seed=1), rnd(50, 16, seed=2), torch.randn(50, 16, generator=torch.Generator().manual_seed(3))
+    md, ld = mu.to(DEV).requires_grad_(True), lv.to(DEV).requires_grad_(True)
+    z, used = ops.reparam(md, ld, eps.to(DEV))
+    torch.testing.assert_close(z.cpu(), orc.reparametrize(mu, lv, eps), rtol=1e-6, atol=1e-6)
+    assert torch.equal(used.cpu(), eps)
+    g = rnd(50, 16, seed=4)
+    (z * g.to(DEV)).sum().backward()
+    torch.testing.assert_close(md.grad.cpu(), g, rtol=0, atol=0)
+    torch.testing.assert_close(ld.grad.cpu(), g * eps * 0.5 * torch.exp(0.5 * lv), rtol=1e-5, atol=1e-6)
+
+
+def test_reparam_philox_stream(ops):
+    B, Z = 8192, 16
+    mu, lv = torch.zeros(B, Z, device=DEV), torch.zeros(B, Z, device=DEV)
+    z1, e1 = ops.reparam(mu, lv, None, seed=7, offset=0)
+    z2, e2 = ops.reparam(mu, lv, None, seed=7, offset=0)
+    assert torch.equal(e1, e2) and torch.equal(z1, e1)  # deterministic; z = eps when mu=0, logvar=0
+    e = e1.cpu().double()
+    assert abs(e.mean().item()) < 0.01 and abs(e.std().item() - 1) < 0.01
+    assert abs((e ** 3).mean().item()) < 0.03 and abs((e ** 4).mean().item() - 3) < 0.1
+    # a shard that starts at slate 100 sees exactly the stream the full batch saw there (DP independence)
+    _, es = ops.reparam(mu[100:300], lv[100:300], None, seed=7, offset=100 * Z)
+    assert torch.equal(es, e1[100:300])
+    _, e3 = ops.reparam(mu, lv, None, seed=8, offset=0)
+    assert not torch.equal(e3, e1)
+
+
+# --------------------------------------------------------------------------------------------- K7
+def test_kld_forward_backward(ops):
+    ts = [rnd(300, 16, seed=i) for i in range(4)]
+    ref = [t.clone().requires_grad_(True) for t in ts]
+    k = orc.kld(*ref)
+    (k * 0.37).backward()
+    dv = [t.to(DEV).requires_grad_(True) for t in ts]
+    kd = ops.kld(*dv)
+    (kd * 0.37).backward()
+    np.testing.assert_allclose(kd.item(), k.item(), rtol=2e-6)
+    for a, b in zip(dv, ref):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-5, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------- K8
+def test_adam_matches_oracle(ops):
+    n = 5000
+    p0, sd = rnd(n, seed=1), None
+    state = {}
+    pd = p0.to(DEV).clone()
+    md, vd = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    sd = {"w": p0.clone()}
+    for t in range(1, 6):
+        g = rnd(n, seed=10 + t, scale=0.1)
+        sd = orc.adam_step(sd, {"w": g}, state, 3e-4)
+        ops.adam_step_(pd, g.to(DEV), md, vd, 3e-4, t)
+        torch.testing.assert_close(pd.cpu(), sd["w"], rtol=1e-6, atol=1e-7)
+    # zero gradient leaves parameters bit-identical (what "skip grad None" means for the PSM)
+    before = pd.clone()
+    m0, v0 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ops.adam_step_(pd, torch.zeros(n, device=DEV), m0, v0, 3e-4, 1)
+    assert torch.equal(pd, before)
+
+
+# ---------------------------------------------------------------------------------------- K5 / K6
+CAT_SHAPES = [(35, 203, 16), (50, 321, 32), (130, 1000, 64), (257, 4099, 128), (40, 2500, 256), (128, 64, 32)]
+
+
+@pytest.mark.parametrize("R,N,D", CAT_SHAPES)
+def test_catalog_ce_full_softmax(ops, R, N, D):
+    rx, E = rnd(R, D, seed=1, scale=2.0), unit_rows(N, D, seed=2)
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    tgt[0], tgt[-1] = 0, N - 1
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV))
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    nll2, _, none = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), want_dx=False)
+    assert none is None and torch.equal(nll2, nll)  # loss-only variant is the same arithmetic
+
+
+@pytest.mark.parametrize("R,N,D", [(35, 203, 16), (130, 1000, 64), (64, 4099, 128)])
+def test_catalog_ce_explicit_mask(ops, R, N, D):
+    rx, E = rnd(R, D, seed=4, scale=2.0), unit_rows(N, D, seed=5)
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(6))
+    keep = (torch.rand(R, N, generator=torch.Generator().manual_seed(7)) < 0.25).to(torch.uint8)
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), keep_mask=keep.to(DEV))
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy(), keep.numpy())
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("R,N,D,p", [(35, 203, 16, 0.3), (130, 4099, 64, 0.05)])
+def test_catalog_ce_philox_mask_is_the_documented_stream(ops, R, N, D, p):
+    """In-kernel Bernoulli mask == the host restatement of the same Philox stream -> exact CE check."""
+    rx, E = rnd(R, D, seed=8, scale=2.0), unit_rows(N, D, seed=9)
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(10))
+    seed, off = 1234567, 1000
+    nll, _, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), keep_prob=p, seed=seed, row_offset=off)
+    keep = philox_ref.keep_mask(R, N, p, seed, off)
+    assert abs(keep.mean() - p) < 4 * np.sqrt(p * (1 - p) / keep.size) + 1e-3
+    wn, _, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy(), keep)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    # sharding independence: rows [10, 20) as their own call with row_offset + 10
+    nll_s, _, _ = ops.catalog_ce_raw(rx[10:20].to(DEV), E.to(DEV), tgt[10:20].to(DEV), keep_prob=p, seed=seed,
+                                     row_offset=off + 10)
+    assert torch.equal(nll_s, nll[10:20])
+
+
+def test_catalog_ce_autograd_mean(ops):
+    R, N, D = 70, 500, 32
+    rx, E = rnd(R, D, seed=1, scale=2.0), unit_rows(N, D, seed=2)
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    rr = rx.clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(rr @ E.t(), tgt)
+    (want * 1.7).backward()
+    rd = rx.to(DEV).requires_grad_(True)
+    got = ops.catalog_ce(rd, E.to(DEV), tgt.to(DEV))
+    (got * 1.7).backward()
+    np.testing.assert_allclose(got.item(), want.item(), rtol=2e-6)
+    torch.testing.assert_close(rd.grad.cpu(), rr.grad, rtol=2e-5, atol=1e-7)
+
+
+def test_catalog_ce_extreme_logits(ops):
+    """online-softmax rescale branch: one row's maximum jumps late in the catalog, logits up to +-60."""
+    R, N, D = 64, 2048, 32
+    E = unit_rows(N, D, seed=2)
+    rx = rnd(R, D, seed=1, scale=0.1)
+    rx[3] = E[N - 5] * 60.0   # max found in the very last tile
+    rx[4] = E[40] * 60.0      # max found in the second tile
+    rx[5] = -E[77] * 50.0     # most logits strongly negative
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV))
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=3e-6, atol=3e-6)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=3e-6, atol=2e-5)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=5e-5, atol=5e-6)
+
+
+@pytest.mark.parametrize("R,N,D", CAT_SHAPES + [(300, 20000, 32)])
+def test_catalog_argmax_bit_exact(ops, R, N, D):
+    x, E = rnd(R, D, seed=11, scale=2.0), unit_rows(N, D, seed=12)
+    idx, best = ops.catalog_argmax(x.to(DEV), E.to(DEV), return_best=True)
+    wi, wb = co.argmax(x.numpy(), E.numpy())
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)  # ids bit-exact
+    np.testing.assert_array_equal(best.cpu().numpy(), wb)  # and so is the winning score (same fmaf chain)
+
+
+def test_catalog_argmax_ties_pick_lowest_index(ops):
+    N, D = 3000, 32
+    E = unit_rows(N, D, seed=1)
+    dup = [7, 38, 1500, 2999]      # identical rows in different lane halves / tiles / splits
+    E[dup] = E[7]
+    x = torch.stack([E[7] * 3.0, E[7] * 0.5, rnd(D, seed=2)])
+    idx = ops.catalog_argmax(x.to(DEV), E.to(DEV)).cpu().numpy()
+    wi, _ = co.argmax(x.numpy(), E.numpy())
+    np.testing.assert_array_equal(idx, wi)
+    assert idx[0] == 7 and idx[1] == 7
+
+
+def test_catalog_sample_distribution(ops):
+    """Categorical(sigmoid(scores)) by Gumbel-max: empirical frequencies match the probabilities."""
+    N, D, R = 40, 16, 20000
+    E = unit_rows(N, D, seed=1)
+    q = rnd(1, D, seed=2, scale=3.0)
+    probs = torch.sigmoid(q @ E.t()).reshape(-1)
+    probs = (probs / probs.sum()).numpy()
+    idx = ops.catalog_sample(q.expand(R, D).contiguous().to(DEV), E.to(DEV), seed=5).cpu().numpy()
+    freq = np.bincount(idx, minlength=N) / R
+    assert np.abs(freq - probs).max() < 5 * np.sqrt(probs.max() / R)
+    idx2 = ops.catalog_sample(q.expand(R, D).contiguous().to(DEV), E.to(DEV), seed=5).cpu().numpy()
+    np.testing.assert_array_equal(idx, idx2)
+
+
+# --------------------------------------------------------------------------------------------- K9
+def test_candidate_scores(ops):
+    R, N, D, Cn = 35, 203, 16, 13
+    rx, E = rnd(R, D, seed=1), unit_rows(N, D, seed=2)
+    cand = torch.randint(0, N, (R, Cn), generator=torch.Generator().manual_seed(3))
+    rd = rx.to(DEV).requires_grad_(True)
+    p = ops.candidate_scores(rd, E.to(DEV), cand.to(DEV))
+    want = torch.bmm(E[cand], rx.reshape(R, D, 1)).reshape(R, Cn)
+    torch.testing.assert_close(p.cpu(), want, rtol=1e-5, atol=1e-6)
+    g = rnd(R, Cn, seed=4)
+    (p * g.to(DEV)).sum().backward()
+    torch.testing.assert_close(rd.grad.cpu(), torch.einsum("rc,rcd->rd", g, E[cand]), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------- argument validation
+def test_bad_arguments_are_rejected_before_launch(ops):
+    rx = rnd(8, 24).to(DEV)  # D=24 unsupported by the catalog kernels
+    E = rnd(50, 24).to(DEV)
+    with pytest.raises(RuntimeError, match="unsupported D"):
+        ops.catalog_ce_raw(rx, E, torch.zeros(8, dtype=torch.long, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd_raw(rnd(4, 8).to(DEV), rnd(3, 9).to(DEV), None, 0)

@@ -1,0 +1,152 @@
+"""-m gpu: the product modules (pivotcvae_amd.models.*) against the goldens minted from the reference.
+
+fp32 path.  Tolerances: forward tensors rtol 1e-5 / atol 1e-5; ELBO terms 1e-4 relative (the north-star
+bound; observed ~1e-6); gradients rtol 2e-4; parameters after Adam steps rtol 1e-4 + atol 3e-6 (Adam divides
+by sqrt(v) ~ |g|, so an early step amplifies gradient rounding); greedy item / pivot ids BIT-EXACT.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import DEV, build_from_golden, close, dev
+from tests.helpers import load, model_cases
+
+pytestmark = pytest.mark.gpu
+CASES = model_cases()
+
+
+def _override(model, g, key):
+    if hasattr(model, "pivot_override"):
+        model.pivot_override = dev(g.t(key)) if g.has(key) else None
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_six_tuple_and_prior(name):
+    g = load(name)
+    m = build_from_golden(g)
+    _override(m, g, "fwd/pivot_sample")
+    with torch.no_grad():
+        p, rx, z, emb, mu, lv = m.forward(dev(g.t("s")), dev(g.t("r")), u=dev(g.t("u")), eps=dev(g.t("fwd/eps")))
+        pmu, plv = m.get_prior(dev(g.t("r")), dev(g.t("u")))
+        cond = m.get_condition(dev(g.t("r")))
+    assert torch.equal(emb.cpu(), g.t("fwd/emb"))      # a gather is a copy: exact
+    assert torch.equal(cond.cpu(), g.t("fwd/cond"))
+    for got, key in ((p, "p"), (rx, "rx"), (z, "z"), (mu, "z_mu"), (lv, "z_logvar"), (pmu, "pMu"), (plv, "pLogvar")):
+        want = g.t("fwd/" + key)
+        assert tuple(got.shape) == tuple(want.shape), key
+        close(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("mode", ["full", "part"])
+def test_fused_loss_and_gradients(name, mode):
+    g = load(name)
+    m = build_from_golden(g)
+    _override(m, g, f"{mode}/pivot_sample")
+    keep = None
+    if mode == "part":
+        keep = dev(g.t("part/neg_sample"))
+    loss, rec, kld = m.loss(dev(g.t("s")), dev(g.t("r")), dev(g.t("u")), g.meta["beta"],
+                            eps=dev(g.t(f"{mode}/eps")), keep_mask=keep)
+    loss.backward()
+    np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], g.a[f"{mode}/loss"], rtol=1e-4)
+    prefix = "grad" if mode == "full" else "part/grad"
+    want = g.sub(prefix)
+    for k, prm in m.named_parameters():
+        if k in want:
+            close(prm.grad, want[k], rtol=2e-4, atol=2e-6)
+        else:  # frozen tables and the PSM stack never get a gradient
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+    assert sorted(k for k in g.meta["none_grads"]) == sorted(
+        k for k, prm in m.named_parameters() if k not in want)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_trainer_three_adam_steps(name):
+    from pivotcvae_amd.train_generative import Trainer
+    g = load(name)
+    m = build_from_golden(g)
+    tr = Trainer(m, lr=g.meta["lr"], beta=g.meta["beta"], n_neg=None)
+    s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
+    for step in range(3):
+        _override(m, g, f"adam/pivot_sample{step}")
+        loss, rec, kld = tr.step(s, r, u, eps=dev(g.t(f"adam/eps{step}")))
+        np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], g.a[f"adam/loss{step}"], rtol=1e-4)
+        if step in (0, 2):
+            sd = m.state_dict()
+            for k, v in g.sub(f"adam/step{step + 1}").items():
+                close(sd[k], v, rtol=1e-4, atol=3e-6)
+    for k in g.meta["none_grads"]:  # PSM + tables bit-identical after training
+        assert torch.equal(m.state_dict()[k].cpu(), g.sd[k]), k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_recommend_greedy_ids_bit_exact(name):
+    g = load(name)
+    m = build_from_golden(g)
+    _override(m, g, "rec/pivot_sample")
+    u = None if g.meta["no_user"] else dev(g.t("u"))
+    with torch.no_grad():
+        items, mu = m.recommend(dev(g.t("rec/r")), u, return_item=True, eps=dev(g.t("rec/eps")))
+        rx, _ = m.recommend(dev(g.t("rec/r")), u, return_item=False, eps=dev(g.t("rec/eps")))
+    assert g.a["rec/item_margin"].min() > 1e-5  # these rows are not near-ties: ids must match exactly
+    np.testing.assert_array_equal(items.cpu().numpy(), g.a["rec/items"])
+    close(mu, g.t("rec/z_mu"), rtol=1e-5, atol=1e-6)
+    assert tuple(rx.shape) == tuple(g.a["rec/rx"].shape)
+    close(rx, g.t("rec/rx"), rtol=1e-5, atol=1e-5)
+    if g.has("rec/pivot"):
+        np.testing.assert_array_equal(m.last_pivot.cpu().numpy(), g.a["rec/pivot"])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_candidate_path(name):
+    from pivotcvae_amd.train_generative import get_gen_loss
+    g = load(name)
+    m = build_from_golden(g)
+    _override(m, g, "cand/pivot_sample")
+    m.candidateFlag = True
+    batch = {"slates": g.a["s"], "users": g.a["u"], "responses": g.a["r"],
+             "sample_candidates": g.a["cand/candidates"], "sample_targets": g.a["cand/targets"]}
+    loss, rec, kld = get_gen_loss(batch, m, torch.nn.CrossEntropyLoss(), g.meta["beta"], eps=dev(g.t("cand/eps")))
+    loss.backward()
+    np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], g.a["cand/loss"], rtol=1e-4)
+    for k, v in g.sub("cand/grad").items():
+        close(dict(m.named_parameters())[k].grad, v, rtol=2e-4, atol=2e-6)
+    with torch.no_grad():
+        p = m.forward(dev(g.t("s")), dev(g.t("r")), candidates=dev(g.t("cand/candidates")), u=dev(g.t("u")),
+                      eps=dev(g.t("cand/eps")))[0]
+    close(p, g.t("cand/p"), rtol=1e-5, atol=1e-5)
+
+
+def test_reference_style_get_gen_loss_dense_path():
+    """The reference's own get_gen_loss recipe (dense p + downsample + CrossEntropyLoss) on our forward()."""
+    from pivotcvae_amd.train_generative import downsample
+    g = load("pivotcvae_gt_pi_user")
+    m = build_from_golden(g)
+    s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
+    pmu, plv = m.get_prior(r, u)
+    pred, _, _, _, mu, lv = m.forward(s, r, u=u, eps=dev(g.t("full/eps")))
+    rec = torch.nn.CrossEntropyLoss()(downsample(pred, s, n_neg=g.meta["N"]), s.reshape(-1))
+    KLD = -0.5 * torch.sum(1 + lv - plv - (lv.exp() + (mu - pmu).pow(2)) / plv.exp())
+    loss = rec + g.meta["beta"] * KLD
+    loss.backward()
+    np.testing.assert_allclose([loss.item(), rec.item(), KLD.item()], g.a["full/loss"], rtol=1e-4)
+    want = g.sub("grad")
+    for k, prm in m.named_parameters():
+        if k in want:
+            close(prm.grad, want[k], rtol=2e-4, atol=2e-6)
+    with pytest.raises(RuntimeError):
+        downsample(pred, s, n_neg=g.meta["N"] + 1)
+
+
+def test_pickle_round_trip_and_device_attr(tmp_path):
+    g = load("pivotcvae_gt_pi_user")
+    m = build_from_golden(g)
+    path = tmp_path / "model.pt"
+    torch.save(m, open(path, "wb"))
+    m2 = torch.load(open(path, "rb"), weights_only=False)
+    m2.to("cpu")
+    m2.device = "cpu"  # reference train_generative.py:211-212
+    assert m2.docEmbed.weight.device.type == "cpu"
+    for k, v in m.state_dict().items():
+        assert torch.equal(v.cpu(), m2.state_dict()[k])

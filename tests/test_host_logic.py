@@ -1,0 +1,150 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol include/pcvae.h
+declares, the module surface mirrors the reference, shapes are validated, and nothing falls back to the CPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import pivotcvae_amd as pa
+from pivotcvae_amd import _hip
+from pivotcvae_amd.models.listcvae import UserListCVAEWithPrior
+from tests import philox_ref
+from tests.helpers import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "pcvae.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcvae_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_hip.LIB_PATH), "run `python -m pivotcvae_amd.build` (or __graft_entry__.build())"
+    handle = ctypes.CDLL(_hip.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in include/pcvae.h but not exported"
+    assert sorted(_hip.SIGNATURES) == syms  # the ctypes table mirrors the header one to one
+    assert _hip.lib().pcvae_abi_version() == 1
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    """EINVAL paths return before any HIP call, so they are testable here."""
+    L = _hip.lib()
+    assert L.pcvae_catalog_ws_bytes(0, 10, 16, 1) == 0
+    assert L.pcvae_catalog_ws_bytes(81920, 1000000, 128, 1) > 81920 * 128 * 4
+    rc = L.pcvae_gather_rows(None, 10, 16, None, 1, 1, None, 16, None)
+    assert rc == -1 and b"null" in L.pcvae_last_error()
+    rc = L.pcvae_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None)
+    assert rc == -1
+
+
+def _tables(N=50, NU=7, D=16):
+    return torch.nn.Embedding(N, D), torch.nn.Embedding(NU, D)
+
+
+def test_registry_and_constructor_contract():
+    assert list(pa.PIVOTCVAE_MODELS) == ["pivotcvae_gt_pi", "pivotcvae_pt_pi", "pivotcvae_spt_pi", "pivotcvae_sgt_pi",
+                                         "pivotcvae_gt_spi", "pivotcvae_pt_spi", "pivotcvae_spt_spi",
+                                         "pivotcvae_sgt_spi"]
+    rules = {k: (c.TRAIN_RULE, c.INFER_RULE) for k, c in pa.PIVOTCVAE_MODELS.items()}
+    assert all(k == f"pivotcvae_{t}_{i}" for k, (t, i) in rules.items())
+    assert pa.PivotCVAE is pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"]
+    e, u = _tables()
+    good = dict(enc=[102, 24, 24], psm=[26, 24, 24, 16], scm=[42, 24, 24, 64], prior=[22, 12, 12])
+    m = pa.UserPivotCVAE(e, u, 5, 16, 4, 6, good["enc"], good["psm"], good["scm"], good["prior"], False, "cpu")
+    for attr in ("device", "candidateFlag", "slate_size", "feature_size", "latent_size", "condition_size", "noUser",
+                 "docEmbed", "userEmbed", "forward", "recommend", "generate", "get_prior", "encode", "decode",
+                 "pick_pivot", "reparametrize", "get_condition", "get_recommended_item", "sample_encoding", "log",
+                 "loss"):
+        assert hasattr(m, attr), attr
+    assert m.candidateFlag is False and m.noUser is False
+    # struct asserts of the reference (models/pivotcvae.py:58-71)
+    for key, bad in (("enc", [101, 24, 24]), ("psm", [26, 24, 24, 15]), ("scm", [42, 24, 24, 63]), ("prior", [21, 12])):
+        st = dict(good)
+        st[key] = bad
+        with pytest.raises(AssertionError):
+            pa.UserPivotCVAE(e, u, 5, 16, 4, 6, st["enc"], st["psm"], st["scm"], st["prior"], False, "cpu")
+    with pytest.raises(AssertionError):  # no_user changes every expected width
+        pa.UserPivotCVAE(e, None, 5, 16, 4, 6, good["enc"], good["psm"], good["scm"], good["prior"], True, "cpu")
+    with pytest.raises(NotImplementedError):
+        pa.UserPivotCVAE(e, u, 5, 16, 4, 6, good["enc"], good["psm"], good["scm"], good["prior"], False, "cpu",
+                         fine_tune=True)
+
+
+@pytest.mark.parametrize("name", ["pivotcvae_gt_pi_user", "pivotcvae_gt_pi_nouser", "listcvae_user", "listcvae_nouser"])
+def test_state_dict_keys_match_reference(name):
+    g = load(name)
+    m, st = g.meta, g.meta["structs"]
+    doc = torch.nn.Embedding.from_pretrained(g.t("raw_doc"))
+    usr = torch.nn.Embedding.from_pretrained(g.t("raw_user"))
+    if m["model"] == "listcvae":
+        model = UserListCVAEWithPrior(doc, None if m["no_user"] else usr, m["S"], m["D"], m["Z"], m["S"] + 1,
+                                      st["enc"], st["dec"], st["prior"], m["no_user"], "cpu")
+    else:
+        model = pa.PIVOTCVAE_MODELS[m["model"]](doc, None if m["no_user"] else usr, m["S"], m["D"], m["Z"], m["S"] + 1,
+                                               st["enc"], st["psm"], st["scm"], st["prior"], m["no_user"], "cpu")
+    assert list(model.state_dict().keys()) == list(g.sd.keys())
+    for k, v in model.state_dict().items():
+        assert tuple(v.shape) == tuple(g.sd[k].shape), k
+    # G1: tables are row-normalised copies, frozen
+    torch.testing.assert_close(model.docEmbed.weight, g.t("sd/docEmbed.weight"), rtol=2e-6, atol=2e-7)
+    assert not model.docEmbed.weight.requires_grad
+    model.load_state_dict(g.sd)  # reference checkpoints load
+    trainable = sorted(k for k, p in model.named_parameters() if p.requires_grad)
+    assert trainable == sorted(k for k in g.sd if not k.startswith(("docEmbed", "userEmbed")))
+
+
+def test_no_cpu_fallback():
+    e, u = _tables()
+    m = pa.UserPivotCVAE(e, u, 5, 16, 4, 6, [102, 24, 24], [26, 24, 24, 16], [42, 24, 24, 64], [22, 12, 12], False, "cpu")
+    s = torch.zeros(2, 5, dtype=torch.long)
+    r = torch.zeros(2, 5)
+    uu = torch.zeros(2, 1, dtype=torch.long)
+    for call in (lambda: m.forward(s, r, u=uu), lambda: m.recommend(r, uu), lambda: m.get_prior(r, uu),
+                 lambda: m.loss(s, r, uu, 0.001)):
+        with pytest.raises(RuntimeError, match="ROCm device only"):
+            call()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pivotcvae_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, f
+                assert "/root/reference" not in text, f
+
+
+def test_philox_reference_vectors():
+    """Philox4x32-10 known-answer tests (Random123 kat_vectors) pin the host restatement of the RNG."""
+    out = philox_ref.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(x) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    out = philox_ref.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff)
+    assert [int(x) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    out = philox_ref.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(x) for x in out] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    k = philox_ref.keep_mask(64, 4096, 0.1, 99)
+    assert abs(k.mean() - 0.1) < 0.005
+
+
+def test_flat_adam_views_keep_names_and_storage():
+    from pivotcvae_amd.optim import FlatAdam
+    e, u = _tables()
+    m = pa.UserPivotCVAE(e, u, 5, 16, 4, 6, [102, 24, 24], [26, 24, 24, 16], [42, 24, 24, 64], [22, 12, 12], False, "cpu")
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    opt = FlatAdam(m, 1e-3)
+    assert list(m.state_dict().keys()) == list(before.keys())
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    n = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert opt.flat.numel() == n == opt.grad.numel()
+    p0 = next(p for p in m.parameters() if p.requires_grad)
+    assert p0.data_ptr() == opt.flat.data_ptr() and p0.grad.data_ptr() == opt.grad.data_ptr()
