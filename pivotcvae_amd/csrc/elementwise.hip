@@ -62,12 +62,12 @@ __global__ void __launch_bounds__(256) gather_rows_scalar_kernel(const float* __
 
 extern "C" int pcvae_gather_rows(const float* table, int64_t n_rows, int D, const int64_t* idx, int64_t n_idx,
                                  int group, float* out, int64_t out_ld, pcvae_stream_t stream) {
+    if (n_idx == 0) return PCVAE_OK;  // empty batch: nothing to do (pointers may be null)
     PCVAE_REQUIRE(table && idx && out, "gather_rows: null pointer");
     PCVAE_REQUIRE(D > 0 && n_rows > 0 && group > 0, "gather_rows: bad D/n_rows/group (%d, %lld, %d)", D,
                   (long long)n_rows, group);
     PCVAE_REQUIRE(out_ld >= (int64_t)group * D, "gather_rows: out_ld %lld < group*D %lld", (long long)out_ld,
                   (long long)group * D);
-    if (n_idx == 0) return PCVAE_OK;
     const bool vec = (D % 4 == 0) && (out_ld % 4 == 0) && (((uintptr_t)out) % 16 == 0) && (((uintptr_t)table) % 16 == 0);
     if (vec) {
         const int chunks = D / 4;

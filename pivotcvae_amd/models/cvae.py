@@ -27,13 +27,13 @@ class BaseCVAE(nn.Module):
         self.latent_size = latent_size
         self.noUser = no_user
         self.device = device
-        with torch.no_grad():
-            self.docEmbed = nn.Embedding(embeddings.weight.shape[0], embeddings.weight.shape[1])
-            self.docEmbed.weight.data.copy_(_normalized_rows(embeddings.weight.detach().float()))
+        with torch.no_grad():  # fresh, row-normalised, frozen copies (built where the source table lives)
+            w = _normalized_rows(embeddings.weight.detach().float())
+            self.docEmbed = nn.Embedding(w.shape[0], w.shape[1], _weight=w.contiguous())
             self.docEmbed.weight.requires_grad = False
             if not no_user:
-                self.userEmbed = nn.Embedding(u_embeddings.weight.shape[0], u_embeddings.weight.shape[1])
-                self.userEmbed.weight.data.copy_(_normalized_rows(u_embeddings.weight.detach().float()))
+                w = _normalized_rows(u_embeddings.weight.detach().float())
+                self.userEmbed = nn.Embedding(w.shape[0], w.shape[1], _weight=w.contiguous())
                 self.userEmbed.weight.requires_grad = False
         # precision of the [R,D]x[D,N] catalog contraction: "f32" (exact), "bf16x3", "bf16"
         self.catalog_precision = PREC_F32

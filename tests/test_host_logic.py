@@ -39,7 +39,7 @@ def test_host_side_argument_checks_need_no_gpu():
     L = _hip.lib()
     assert L.pcvae_catalog_ws_bytes(0, 10, 16, 1) == 0
     assert L.pcvae_catalog_ws_bytes(81920, 1000000, 128, 1) > 81920 * 128 * 4
-    rc = L.pcvae_gather_rows(None, 10, 16, None, 1, 1, None, 16, None)
+    rc = L.pcvae_gather_rows(None, 10, 16, None, 1, 1, None, 16, None)  # n_idx = 1
     assert rc == -1 and b"null" in L.pcvae_last_error()
     rc = L.pcvae_adam_step(None, None, None, None, 10, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None)
     assert rc == -1
