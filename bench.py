@@ -37,7 +37,7 @@ CONFIGS = {
 Z, H, HP, N_USER = 16, 256, 128, 10_000
 BETA, LR = 0.001, 3e-4
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}
 
 
 def structs(S, D):
@@ -109,8 +109,9 @@ def cpu_baseline_and_parity(model, st, cfg, dtype):
             "sample": f"oracle/pivotcvae_oracle.py train step (dense [{Bs * cfg['S']},{cfg['N']}] logits + CE + KL + "
                       f"backward + Adam), B={Bs} slates of the same workload, {steps} steps, {dt:.2f} s/step"}
     parity = {"loss_rel_err": rel(hl.item(), ol), "recLoss_rel_err": rel(hrec.item(), orec),
-              "KLD_rel_err": rel(hkld.item(), okld), "tolerance": 1e-4 if dtype != "bf16" else 2e-2,
+              "KLD_rel_err": rel(hkld.item(), okld), "tolerance": 1e-4,
               "sample": f"B={Bs}, same eps, HIP {dtype} vs CPU oracle"}
+    parity["within_tolerance"] = max(parity["loss_rel_err"], parity["recLoss_rel_err"], parity["KLD_rel_err"]) <= 1e-4
     return base, parity
 
 
@@ -120,7 +121,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="4", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x3"])
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
+                    help="arithmetic of the catalog contraction: bf16 MFMA inputs with fp32 accumulate (default; ELBO "
+                         "parity with the fp32 oracle is measured live in the 'parity' block) or exact f32 MFMA")
     ap.add_argument("--n_neg", type=int, default=None, help="default: N (full-catalog softmax)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -1,5 +1,6 @@
 // extern "C" entry points of the catalog kernels: argument validation + precision dispatch.
 #include "catalog_plan.h"
+#include <algorithm>
 
 using namespace pcvae;
 
@@ -7,11 +8,15 @@ static bool supported_d(int D) { return D == 16 || D == 32 || D == 64 || D == 12
 
 extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_dx) {
     if (R <= 0 || N <= 0 || D <= 0) return 0;
-    const CatalogPlan pl = catalog_plan(R, N, D);
-    const size_t rows = (size_t)pl.nsplit * (size_t)R;
-    size_t ce = rows * 2 * sizeof(float) + (want_dx ? rows * (size_t)D * sizeof(float) : 0);
-    size_t am = (rows + 1) * sizeof(float) + rows * sizeof(int64_t) + 16;
-    return (ce > am ? ce : am) + 256;
+    size_t need = 0;
+    for (int prec : {PCVAE_PREC_F32, PCVAE_PREC_BF16}) {  // one answer valid for every precision mode
+        const CatalogPlan pl = catalog_plan(R, N, D, prec);
+        const size_t rows = (size_t)pl.nsplit * (size_t)R;
+        const size_t ce = rows * 2 * sizeof(float) + (want_dx ? rows * (size_t)D * sizeof(float) : 0);
+        const size_t am = (rows + 1) * sizeof(float) + rows * sizeof(int64_t) + 16;
+        need = std::max(need, std::max(ce, am));
+    }
+    return need + 256;
 }
 
 extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
@@ -33,6 +38,11 @@ extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const
         (void)E_lo;
         return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E), N, D, target, keep_prob, seed, row_offset,
                               keep_mask, nll, lse, dx, ws, as_stream(stream));
+    }
+    if (prec == PCVAE_PREC_BF16) {
+        (void)E_lo;
+        return catalog_ce_bf16(rx, R, reinterpret_cast<const uint16_t*>(E), N, D, target, keep_prob, seed, row_offset,
+                               keep_mask, nll, lse, dx, ws, as_stream(stream));
     }
     set_error("catalog_ce: precision mode %d not available in this build", prec);
     return PCVAE_EINVAL;

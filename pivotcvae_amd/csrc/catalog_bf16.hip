@@ -1,0 +1,377 @@
+// K5 on the bf16 matrix cores: fused full-catalog softmax cross-entropy (loss + gradient direction in ONE
+// streaming pass) with v_mfma_f32_32x32x16_bf16, fp32 accumulate (gfx950).
+//
+// Same algorithm as catalog_f32.hip (flash-attention with K = V = E, split over catalog ranges, merged by a
+// deterministic log-sum-exp kernel) re-tiled for the 16x faster bf16 pipe, where the softmax VALU work and
+// the LDS/L2 feed - not the MFMA - are the things to budget:
+//
+//   * workgroup = 8 waves = 256 rows of rx; wave w owns rows 32w..32w+31 for the whole catalog range and
+//     keeps them in registers as bf16 B fragments, pre-multiplied by log2(e) so exp is a bare v_exp_f32;
+//     two waves share a SIMD, so one wave's softmax VALU runs under its partner's MFMAs;
+//   * the bf16 copy of E streams through LDS in 128-item chunks (32 KB, double buffered) filled by
+//     global_load_lds_dwordx4 (no staging VGPRs, asynchronous); the LDS image keeps 2*D-byte rows and
+//     XOR-swizzles the 16-byte chunks with ((row&3)<<2 | (row>>2)&3) on the SOURCE address, which makes both
+//     the row reads (ds_read_b128, logits A operand) and the transposed reads (ds_read_b64_tr_b16, E^T A
+//     operand of the gradient chain) bank-conflict free on one image;
+//   * logits are produced "swapped" (C[n][r]) with the running max folded into the accumulator's initial
+//     value (acc = -m), so per element the epilogue is max3 / exp2 / add / cvt; the max is raised lazily
+//     (only when a tile exceeds it by more than 2^8), keeping the O(D) rescale of the U accumulator rare;
+//   * exp2 values converted pairwise to bf16 are, in place, the B operand of U^T[d][r] += E^T[d][n] P[n][r].
+//
+// Numerics: bf16 inputs (round-to-nearest-even), fp32 accumulation, softmax statistics in fp32.  Against
+// the fp32 reference the per-logit error is ~2^-9 relative per product and zero-mean, so the ELBO terms of
+// a batch agree to ~1e-6 while individual gradients agree to ~1e-3 (tests/test_hip_bf16.py).
+#include "catalog_plan.h"
+
+using namespace pcvae;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+enum { MASK_NONE = 0, MASK_PHILOX = 1, MASK_BYTES = 2 };
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kRaiseThr = 8.0f;  // raise the running max when a tile exceeds it by more than 2^8
+constexpr int BN = 128;            // catalog items per LDS chunk
+constexpr int ROWS_WG = 256;
+
+struct CatParamsB {
+    const float* rx;        // [R, D] fp32
+    const uint16_t* E;      // [N, D] bf16 bits
+    const int64_t* target;  // [R]
+    const uint8_t* keep;    // [R, N] or null
+    uint32_t keep_thresh;
+    uint64_t seed, row_offset;
+    int64_t R, N;
+    int nrb, nsplit, tiles_per_split, ntiles;  // tiles = 32-item subtiles; tiles_per_split % 4 == 0
+    float* pm;              // [nsplit][R] running max, log2 domain
+    float* pl;              // [nsplit][R]
+    float* pU;              // [nsplit][R][D]
+};
+
+template <int D>
+struct GeoB {
+    static constexpr int RB = 2 * D;          // bytes per table row
+    static constexpr int CPR = D / 8;         // 16-byte chunks per row
+    static constexpr int KS = D / 16;         // k-steps of the logits chain
+    static constexpr int NDB = D / 32;        // 32-wide d blocks of the U accumulator
+    static constexpr int CHUNK_BYTES = BN * RB;
+    static constexpr int PIECES = CHUNK_BYTES / 1024;  // 1 KiB global_load_lds pieces per chunk
+    static constexpr int ROWS_PER_PIECE = 1024 / RB;
+};
+
+// 16-byte-chunk swizzle of the LDS image (an involution on the chunk index of one row)
+template <int D>
+__device__ __forceinline__ int swz_chunk(int row, int c) {
+    if (D >= 128) return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    return c ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));  // D == 64: two rows per 256-B bank row
+}
+
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int col) {  // byte offset of element (row, col) in a chunk image
+    return row * GeoB<D>::RB + (swz_chunk<D>(row, col >> 3) << 4) + ((col & 7) << 1);
+}
+
+// issue the global->LDS copy of one 128-item chunk (asynchronous; completed by the next __syncthreads)
+template <int D>
+__device__ __forceinline__ void stage_chunk(const uint16_t* __restrict__ E, int64_t N, int64_t n0, char* buf) {
+    using G = GeoB<D>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < G::PIECES / 8; ++i) {
+        const int pc = wave * (G::PIECES / 8) + i;
+        const int row = pc * G::ROWS_PER_PIECE + (lane * 16) / G::RB;   // LDS destination is lane-linear
+        const int cdst = ((lane * 16) % G::RB) >> 4;
+        const int csrc = swz_chunk<D>(row, cdst);                        // swizzle on the SOURCE address
+        int64_t n = n0 + row;
+        n = n < N ? n : N - 1;                                           // ragged tail: clamp, masked later
+        const char* src = reinterpret_cast<const char*>(E) + n * G::RB + (csrc << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + pc * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ int nloc(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+template <int D, int MASK, bool WANT_DX>
+__global__ void __launch_bounds__(512, 1) catalog_ce_bf16_kernel(CatParamsB p) {
+    using G = GeoB<D>;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* buf0 = smem;
+    char* buf1 = smem + G::CHUNK_BYTES;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / p.nrb, rb = logical % p.nrb;
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int n_chunks = (t_end - t_beg + 3) / 4;
+
+    const int64_t r = (int64_t)rb * ROWS_WG + wave * 32 + li;
+    const bool row_ok = r < p.R;
+    const int64_t rl = row_ok ? r : p.R - 1;
+
+    stage_chunk<D>(p.E, p.N, (int64_t)t_beg * 32, buf0);
+
+    // B operand of the logits chain: lane (row li, half h) holds bf16(rx[row][16s + 8h + j] * log2e), j = 0..7
+    bf16x8 xb[G::KS];
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h);
+        const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h + 4);
+        xb[s][0] = (__bf16)(v0.x * kLog2e); xb[s][1] = (__bf16)(v0.y * kLog2e);
+        xb[s][2] = (__bf16)(v0.z * kLog2e); xb[s][3] = (__bf16)(v0.w * kLog2e);
+        xb[s][4] = (__bf16)(v1.x * kLog2e); xb[s][5] = (__bf16)(v1.y * kLog2e);
+        xb[s][6] = (__bf16)(v1.z * kLog2e); xb[s][7] = (__bf16)(v1.w * kLog2e);
+    }
+
+    const int64_t tgt = (MASK != MASK_NONE) ? p.target[rl] : -1;
+    const uint64_t grow = p.row_offset + (uint64_t)rl;
+
+    f32x16 U[G::NDB];
+#pragma unroll
+    for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) U[b][i] = 0.f;
+    float m_run = 0.f, lsum = 0.f;
+    bool first = true;
+
+    // per-lane pieces of the LDS addresses
+    const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3;
+
+    __syncthreads();  // chunk 0 landed (the barrier drains the LDS-DMA)
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const char* cur = (c & 1) ? buf1 : buf0;
+        char* nxt = (c & 1) ? buf0 : buf1;
+        const int t0 = t_beg + 4 * c;
+        if (c + 1 < n_chunks) stage_chunk<D>(p.E, p.N, (int64_t)(t0 + 4) * 32, nxt);
+        const int nsub = min(4, t_end - t0);
+
+        for (int st = 0; st < nsub; ++st) {
+            const int nb = st * 32;                      // first LDS row of this 32-item subtile
+            const int64_t n0 = (int64_t)(t0 + st) * 32;  // first catalog item of this subtile
+
+            // ---- logits (log2 domain) minus the running max: acc starts at -m
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = -m_run;
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + lds_off<D>(nb + li, 16 * s + 8 * h));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc, 0, 0, 0);
+            }
+
+            bool kp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kp[i] = true;
+            if (MASK == MASK_PHILOX) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const uint64_t nbq = (uint64_t)(n0 + 8 * qq + 4 * h);
+                    const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(nbq >> 2),
+                                                     (uint32_t)(nbq >> 34) ^ 0x4D41534Bu, (uint32_t)p.seed,
+                                                     (uint32_t)(p.seed >> 32));
+                    const uint32_t u[4] = {ph.x, ph.y, ph.z, ph.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        kp[4 * qq + j] = (u[j] < p.keep_thresh) || ((int64_t)(n0 + 8 * qq + 4 * h + j) == tgt);
+                }
+            } else if (MASK == MASK_BYTES) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t n = n0 + nloc(i, h);
+                    kp[i] = (n == tgt) || (n < p.N && p.keep[rl * p.N + n] != 0);
+                }
+            }
+            if (MASK != MASK_NONE) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = kp[i] ? acc[i] : -m_run;  // masked-out logit is 0
+            }
+            if (n0 + 32 > p.N) {  // ragged last subtile (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (n0 + nloc(i, h) >= p.N) { acc[i] = -INFINITY; kp[i] = false; }
+            }
+
+            // ---- lazy running max, shared by the two lane halves of a row
+            float zmax = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) zmax = fmaxf(fmaxf(zmax, acc[i]), acc[i + 1]);
+            zmax = fmaxf(zmax, acc[15]);
+            zmax = fmaxf(zmax, __shfl_xor(zmax, 32, 64));
+            if (first) {
+                m_run = zmax;  // m_run was 0: acc holds the raw logits
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] -= zmax;
+                first = false;
+            } else if (__any(zmax > kRaiseThr)) {
+                const float shift = zmax > kRaiseThr ? zmax : 0.f;
+                const float alpha = exp2f(-shift);
+                lsum *= alpha;
+                if (WANT_DX) {
+#pragma unroll
+                    for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) U[b][i] *= alpha;
+                }
+                m_run += shift;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] -= shift;
+            }
+
+            // ---- numerators; bf16 pairs of them are the B operand of the gradient chain
+            float pk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(acc[i]);
+                lsum += e;
+                pk[i] = (MASK == MASK_NONE || kp[i]) ? e : 0.f;
+            }
+            if (WANT_DX) {
+                bf16x8 pb[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[ks][j] = (__bf16)pk[8 * ks + j];
+                // U^T[d][r] += sum_n E[n][d] P[n][r]; A operand = E^T fragments by transposed LDS reads:
+                // element j of lane (d, h) is E[16ks + 8(j>>2) + 4h + (j&3)][d]
+#pragma unroll
+                for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int col = 32 * b + 16 * (grp & 1) + 4 * pp;
+                        const int rowa = nb + 16 * ks + 4 * (grp >> 1) + q;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(cur + lds_off<D>(rowa, col)));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(cur + lds_off<D>(rowa + 8, col)));
+                        const s16x8 a16 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        U[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[ks], U[b], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();  // next chunk landed; everyone is done with `cur`
+    }
+
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (row_ok) {
+        const int64_t o = (int64_t)split * p.R + r;
+        if (h == 0) { p.pm[o] = m_run; p.pl[o] = ltot; }
+        if (WANT_DX) {
+#pragma unroll
+            for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int d0 = b * 32 + 8 * qq + 4 * h;
+                    *reinterpret_cast<float4*>(p.pU + o * D + d0) =
+                        make_float4(U[b][4 * qq], U[b][4 * qq + 1], U[b][4 * qq + 2], U[b][4 * qq + 3]);
+                }
+        }
+    }
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// one wave per row: merge split partials (log2 domain), target logit in the kernel's own arithmetic
+template <int D>
+__global__ void __launch_bounds__(256) catalog_ce_merge_bf16_kernel(CatParamsB p, float* __restrict__ nll,
+                                                                    float* __restrict__ lse, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    float M = -INFINITY;
+    for (int j = 0; j < p.nsplit; ++j) M = fmaxf(M, p.pm[(int64_t)j * p.R + r]);
+    float L = 0.f;
+    for (int j = 0; j < p.nsplit; ++j) L += p.pl[(int64_t)j * p.R + r] * exp2f(p.pm[(int64_t)j * p.R + r] - M);
+    const int64_t t = p.target[r];
+    const bool t_ok = t >= 0 && t < p.N;
+    float zt = 0.f;
+    if (t_ok)
+        for (int k = 0; k < D; ++k)
+            zt = fmaf(bf16_to_f32(p.E[t * D + k]), (float)(__bf16)(p.rx[r * D + k] * kLog2e), zt);
+    const float lse_r = (M + log2f(L)) * kLn2;
+    if (lane == 0) {
+        nll[r] = t_ok ? lse_r - zt * kLn2 : NAN;
+        if (lse) lse[r] = lse_r;
+    }
+    if (dx) {
+        const float invL = 1.f / L;
+        for (int d = lane; d < D; d += 64) {
+            float u = 0.f;
+            for (int j = 0; j < p.nsplit; ++j)
+                u += p.pU[((int64_t)j * p.R + r) * D + d] * exp2f(p.pm[(int64_t)j * p.R + r] - M);
+            dx[r * D + d] = t_ok ? u * invL - bf16_to_f32(p.E[t * D + d]) : NAN;
+        }
+    }
+}
+
+template <int D>
+int launch_ce_b(const CatParamsB& p, int mask_mode, bool want_dx, float* nll, float* lse, float* dx, hipStream_t st) {
+    using G = GeoB<D>;
+    const size_t lds = 2 * G::CHUNK_BYTES;
+    const dim3 grid((unsigned)(p.nrb * p.nsplit)), block(512);
+#define PCVAE_CEB(MASKV, DXV)                                                                                    \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_kernel<D, MASKV, DXV>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((catalog_ce_bf16_kernel<D, MASKV, DXV>), grid, block, lds, st, p);                    \
+    } while (0)
+    if (want_dx) {
+        if (mask_mode == MASK_NONE) PCVAE_CEB(MASK_NONE, true);
+        else if (mask_mode == MASK_PHILOX) PCVAE_CEB(MASK_PHILOX, true);
+        else PCVAE_CEB(MASK_BYTES, true);
+    } else {
+        if (mask_mode == MASK_NONE) PCVAE_CEB(MASK_NONE, false);
+        else if (mask_mode == MASK_PHILOX) PCVAE_CEB(MASK_PHILOX, false);
+        else PCVAE_CEB(MASK_BYTES, false);
+    }
+#undef PCVAE_CEB
+    int rc = check_launch("catalog_ce_bf16");
+    if (rc != PCVAE_OK) return rc;
+    hipLaunchKernelGGL((catalog_ce_merge_bf16_kernel<D>), dim3((unsigned)cdiv(p.R, 4)), dim3(256), 0, st, p, nll, lse,
+                       want_dx ? dx : nullptr);
+    return check_launch("catalog_ce_merge_bf16");
+}
+
+}  // namespace
+
+namespace pcvae {
+
+int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, const int64_t* target,
+                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,
+                    float* lse, float* dx, void* ws, hipStream_t st) {
+    const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16);
+    CatParamsB p{};
+    p.rx = rx; p.E = E; p.target = target; p.keep = keep_mask;
+    p.seed = seed; p.row_offset = row_offset; p.R = R; p.N = N;
+    p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
+    p.pm = reinterpret_cast<float*>(ws);
+    p.pl = p.pm + (int64_t)pl.nsplit * R;
+    p.pU = p.pl + (int64_t)pl.nsplit * R;
+    int mask_mode = MASK_NONE;
+    if (keep_mask) mask_mode = MASK_BYTES;
+    else if (keep_prob < 1.0f) {
+        mask_mode = MASK_PHILOX;
+        const double th = (double)keep_prob * 4294967296.0;
+        p.keep_thresh = th <= 0.0 ? 0u : (th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th);
+    }
+    switch (D) {
+        case 64: return launch_ce_b<64>(p, mask_mode, dx != nullptr, nll, lse, dx, st);
+        case 128: return launch_ce_b<128>(p, mask_mode, dx != nullptr, nll, lse, dx, st);
+        case 256: return launch_ce_b<256>(p, mask_mode, dx != nullptr, nll, lse, dx, st);
+    }
+    set_error("catalog_ce(bf16): unsupported D=%d (64, 128, 256; smaller tables use the f32 kernel)", D);
+    return PCVAE_EINVAL;
+}
+
+}  // namespace pcvae

@@ -428,7 +428,7 @@ namespace pcvae {
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,
                    float* lse, float* dx, void* ws, hipStream_t st) {
-    const CatalogPlan pl = catalog_plan(R, N, D);
+    const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);
     CatParams p{};
     p.rx = rx; p.E = E; p.target = target; p.keep = keep_mask;
     p.seed = seed; p.row_offset = row_offset; p.R = R; p.N = N;
@@ -456,7 +456,7 @@ int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D,
 
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,
                        uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st) {
-    const CatalogPlan pl = catalog_plan(R, N, D);
+    const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);
     CatParams p{};
     p.rx = x; p.E = E; p.R = R; p.N = N; p.seed = seed; p.row_offset = row_offset;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;

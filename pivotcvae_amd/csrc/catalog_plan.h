@@ -12,18 +12,23 @@ struct CatalogPlan {
     int tiles_per_split;
 };
 
-// Deterministic in (R, N, D) only - never in the device or the launch - so results are reproducible.
-static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D) {
+// Deterministic in (R, N, D, precision) only - never in the device or the launch - so results are reproducible.
+//   f32 kernels : 128-row workgroups (4 waves), 2 resident per CU, any tile count per range
+//   bf16 kernels: 256-row workgroups (8 waves), 1 resident per CU, ranges are whole 128-item LDS chunks
+static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     (void)D;
+    const bool f32 = prec == PCVAE_PREC_F32;
+    const int rows_wg = f32 ? 128 : 256;
+    const int quant = f32 ? 1 : 4;
     CatalogPlan p;
-    p.nrb = (int)cdiv(R, 128);
+    p.nrb = (int)cdiv(R, rows_wg);
     p.ntiles = (int)cdiv(N, 32);
-    // aim for >= 2048 workgroups (256 CUs x 2 resident x 4 rounds) but keep >= 16 tiles per range so
-    // the per-range prologue (rx load) and epilogue (partial write) stay amortised
-    int64_t want = cdiv(2048, p.nrb);
-    int64_t cap = std::max<int64_t>(1, p.ntiles / 16);
+    // aim for ~4 rounds of resident workgroups over the 256 CUs, but keep the ranges long enough that the
+    // per-range prologue (rx fragments) and epilogue (partial write-out) stay amortised
+    int64_t want = cdiv(f32 ? 2048 : 1024, p.nrb);
+    int64_t cap = std::max<int64_t>(1, p.ntiles / (f32 ? 16 : 64));
     int64_t ns = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, cap), 64));
-    p.tiles_per_split = (int)cdiv(p.ntiles, ns);
+    p.tiles_per_split = (int)(cdiv(cdiv(p.ntiles, ns), quant) * quant);
     p.nsplit = (int)cdiv(p.ntiles, p.tiles_per_split);
     return p;
 }
@@ -31,6 +36,9 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D) {
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,
                    float* lse, float* dx, void* ws, hipStream_t st);
+int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, const int64_t* target,
+                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,
+                    float* lse, float* dx, void* ws, hipStream_t st);
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,
                        uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st);
 

@@ -319,6 +319,13 @@ def _as_table(E):
     return E if isinstance(E, CatalogTable) else CatalogTable(E)
 
 
+BF16_DIMS = (64, 128, 256)  # the bf16 MFMA kernels exist for these widths; narrower tables are tiny: exact f32 path
+
+
+def effective_precision(prec, D):
+    return prec if (prec == PREC_F32 or D in BF16_DIMS) else PREC_F32
+
+
 def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32,
                    want_dx=True):
     """-> (nll [R], lse [R], dx [R, D] or None); see pcvae_catalog_ce in include/pcvae.h."""
@@ -334,6 +341,7 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
         keep_mask = keep_mask.to(torch.uint8).contiguous()
         if tuple(keep_mask.shape) != (R, N):
             raise ValueError("catalog_ce: keep_mask must be [R, N]")
+    prec = effective_precision(prec, D)
     E, E_lo = table.operands(prec)
     nll = torch.empty(R, dtype=F32, device=rx.device)
     lse = torch.empty(R, dtype=F32, device=rx.device)

@@ -1,0 +1,154 @@
+"""-m gpu: the bf16-MFMA catalog CE kernel (PCVAE_PREC_BF16).
+
+Two references:
+  * an EMULATION of the kernel's own arithmetic in torch on the CPU (bf16-rounded operands, fp32 products and
+    sums, log2-domain softmax): pins indexing / swizzle / split-merge logic tightly (lse, nll 2e-5;
+    gradient 4e-3 of its scale, the only un-modelled step being the bf16 rounding of the numerators);
+  * the fp32 C oracle: states what bf16 costs against the reference arithmetic (per-row nll |err| < 2.5e-2 at |rx| ~ 13,
+    batch-mean relative error < 1e-4 at R >= 2048, gradient direction within 2e-2 of its scale).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import catalog_oracle as co
+from oracle import pivotcvae_oracle as orc
+from tests import philox_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOG2E = 1.4426950408889634
+LN2 = 0.6931471805599453
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pivotcvae_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def emulate(rx, E, tgt, keep=None):
+    """kernel arithmetic, minus the bf16 rounding of the softmax numerators"""
+    xs = bf16r(rx * np.float32(LOG2E))
+    Eh = bf16r(E)
+    s2 = (xs.double() @ Eh.double().t()).float()           # log2-domain logits (products exact in fp32)
+    R, N = s2.shape
+    k = torch.ones(R, N, dtype=torch.bool) if keep is None else keep.bool().clone()
+    k[torch.arange(R), tgt] = True
+    z2 = torch.where(k, s2, torch.zeros_like(s2)).double()
+    m = z2.max(1, keepdim=True)[0]
+    e = torch.exp2(z2 - m)
+    L = e.sum(1, keepdim=True)
+    lse = ((m + torch.log2(L)) * LN2).squeeze(1)
+    nll = lse - z2[torch.arange(R), tgt] * LN2
+    pk = torch.where(k, e, torch.zeros_like(e)) / L
+    dx = pk @ Eh.double() - Eh.double()[tgt]
+    return nll.float(), lse.float(), dx.float()
+
+
+SHAPES = [(70, 1000, 64), (300, 4099, 128), (257, 9000, 128), (64, 333, 128), (600, 20000, 64)]
+
+
+@pytest.mark.parametrize("R,N,D", SHAPES)
+def test_bf16_ce_matches_its_own_arithmetic(ops, R, N, D):
+    from pivotcvae_amd._hip import PREC_BF16
+    rx, E = rnd(R, D, seed=1, scale=2.0), orc.normalize_rows(rnd(N, D, seed=2))
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    tgt[0], tgt[-1] = 0, N - 1
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), prec=PREC_BF16)
+    wn, wl, wd = emulate(rx, E, tgt)
+    torch.testing.assert_close(lse.cpu(), wl, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(nll.cpu(), wn, rtol=2e-5, atol=3e-5)
+    assert (dx.cpu() - wd).abs().max() < 4e-3 * wd.abs().max()
+    nll2, _, none = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), prec=PREC_BF16, want_dx=False)
+    assert none is None and torch.equal(nll2, nll)
+
+
+@pytest.mark.parametrize("R,N,D", [(70, 1000, 64), (300, 4099, 128)])
+def test_bf16_ce_masks(ops, R, N, D):
+    from pivotcvae_amd._hip import PREC_BF16
+    rx, E = rnd(R, D, seed=4, scale=2.0), orc.normalize_rows(rnd(N, D, seed=5))
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(6))
+    keep = (torch.rand(R, N, generator=torch.Generator().manual_seed(7)) < 0.2).to(torch.uint8)
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), keep_mask=keep.to(DEV), prec=PREC_BF16)
+    wn, wl, wd = emulate(rx, E, tgt, keep)
+    torch.testing.assert_close(nll.cpu(), wn, rtol=2e-5, atol=3e-5)
+    assert (dx.cpu() - wd).abs().max() < 4e-3 * wd.abs().max()
+    seed, off, p = 77, 500, 0.1
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), keep_prob=p, seed=seed, row_offset=off,
+                                      prec=PREC_BF16)
+    wn, wl, wd = emulate(rx, E, tgt, torch.from_numpy(philox_ref.keep_mask(R, N, p, seed, off)))
+    torch.testing.assert_close(nll.cpu(), wn, rtol=2e-5, atol=3e-5)
+    assert (dx.cpu() - wd).abs().max() < 4e-3 * wd.abs().max()
+
+
+def test_bf16_ce_lazy_max_branches(ops):
+    """rows whose maximum jumps late / early / stays very negative exercise the lazy running-max raise"""
+    from pivotcvae_amd._hip import PREC_BF16
+    R, N, D = 256, 8192, 128
+    E = orc.normalize_rows(rnd(N, D, seed=2))
+    rx = rnd(R, D, seed=1, scale=0.1)
+    rx[3] = E[N - 5] * 60.0
+    rx[4] = E[40] * 60.0
+    rx[5] = -E[77] * 50.0
+    rx[6] = E[5000] * 30.0 + E[100] * 20.0
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), prec=PREC_BF16)
+    wn, wl, wd = emulate(rx, E, tgt)
+    torch.testing.assert_close(lse.cpu(), wl, rtol=3e-5, atol=3e-5)
+    torch.testing.assert_close(nll.cpu(), wn, rtol=3e-5, atol=1e-4)
+    assert (dx.cpu() - wd).abs().max() < 4e-3 * wd.abs().max()
+
+
+def test_bf16_vs_fp32_reference_arithmetic(ops):
+    """what bf16 costs against the fp32 oracle: zero-mean per-row noise, batch mean within 1e-4 relative"""
+    from pivotcvae_amd._hip import PREC_BF16
+    R, N, D = 2048, 4099, 128
+    rx, E = rnd(R, D, seed=1, scale=2.0), orc.normalize_rows(rnd(N, D, seed=2))
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), prec=PREC_BF16)
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+    err = nll.cpu().numpy().astype(np.float64) - wn
+    assert np.abs(err).max() < 2.5e-2  # |rx| ~ 13 here: one bf16 product error is ~13 * 2^-9
+    assert abs(err.mean()) / wn.mean() < 1e-4
+    assert np.abs(dx.cpu().numpy() - wd).max() < 2e-2 * np.abs(wd).max()
+
+
+def test_model_level_bf16_elbo(ops):
+    """PivotCVAE.loss with catalog_precision=bf16 against the fp32 oracle at D=64: ELBO terms within 1e-3
+    (R = 640 rows only, so the per-row bf16 noise has not averaged out as it does at the bench sizes)."""
+    import pivotcvae_amd as pa
+    S, D, Z, N, NU, B, H, HP = 5, 64, 8, 3001, 40, 128, 64, 32
+    C = S + 1
+    torch.manual_seed(0)
+    e_raw, u_raw = orc.synthetic_tables(N, NU, D, seed=0)
+    st = dict(enc=[S * D + C + D, H, H], psm=[Z + C + D, H, H, D], scm=[Z + C + 2 * D, H, H, (S - 1) * D],
+              prior=[C + D, HP, HP])
+    m = pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"](torch.nn.Embedding.from_pretrained(e_raw),
+                                              torch.nn.Embedding.from_pretrained(u_raw), S, D, Z, C, st["enc"],
+                                              st["psm"], st["scm"], st["prior"], False, DEV)
+    m.set_catalog_precision("bf16")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    cfg = orc.Config("pivotcvae_gt_pi", S, D, Z, False, st)
+    g = torch.Generator().manual_seed(1)
+    s = torch.randint(0, N, (B, S), generator=g)
+    u = torch.randint(0, NU, (B, 1), generator=g)
+    r = (torch.rand(B, S, generator=g) < 0.5).float()
+    eps = torch.randn(B, Z, generator=g)
+    loss, rec, kld = m.loss(s.to(DEV), r.to(DEV), u.to(DEV), 0.001, eps=eps.to(DEV))
+    loss.backward()
+    (ol, orec, okld), grads = orc.loss_and_grads(sd, cfg, s, r, u, eps, 0.001)
+    np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], [ol, orec, okld], rtol=1e-3)
+    for k, prm in m.named_parameters():
+        if grads.get(k) is not None:
+            gs = grads[k].abs().max()
+            assert (prm.grad.cpu() - grads[k]).abs().max() < 3e-2 * gs + 1e-6, k
