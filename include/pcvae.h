@@ -129,10 +129,13 @@ int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t
  *     tiles, flash-style), so the backward pass is dx * (upstream / R).
  *     E_lo: second table for PCVAE_PREC_BF16X3 (residual), E is the bf16 table for BF16/BF16X3 and
  *     the fp32 table for F32.  `ws` is scratch of at least pcvae_catalog_ws_bytes().
+ *     e_max_norm: max_n ||E_n||_2 of the table (the model's table is row-normalised: 1.0).  The bf16
+ *     path uses it to prove, per 256-row block, that exp2(logit) cannot leave the fp32 range and then
+ *     skips the running-max machinery; pass <= 0 when unknown (always take the running-max kernel).
  * ------------------------------------------------------------------------------------------- */
 size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_dx);
 int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
-                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
+                     float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
                      const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, size_t ws_bytes,
                      pcvae_stream_t stream);
 

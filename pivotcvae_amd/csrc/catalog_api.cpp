@@ -14,13 +14,13 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
         const size_t rows = (size_t)pl.nsplit * (size_t)R;
         const size_t ce = rows * 2 * sizeof(float) + (want_dx ? rows * (size_t)D * sizeof(float) : 0);
         const size_t am = (rows + 1) * sizeof(float) + rows * sizeof(int64_t) + 16;
-        need = std::max(need, std::max(ce, am));
+        need = std::max(need, std::max(ce, am) + (size_t)pl.nrb + 64);
     }
     return need + 256;
 }
 
 extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
-                                int prec, const int64_t* target, float keep_prob, uint64_t seed,
+                                int prec, float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed,
                                 uint64_t row_offset, const uint8_t* keep_mask, float* nll, float* lse, float* dx,
                                 void* ws, size_t ws_bytes, pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && target && nll && ws, "catalog_ce: null pointer");
@@ -36,13 +36,14 @@ extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const
     }
     if (prec == PCVAE_PREC_F32) {
         (void)E_lo;
+        (void)e_max_norm;
         return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E), N, D, target, keep_prob, seed, row_offset,
                               keep_mask, nll, lse, dx, ws, as_stream(stream));
     }
     if (prec == PCVAE_PREC_BF16) {
         (void)E_lo;
-        return catalog_ce_bf16(rx, R, reinterpret_cast<const uint16_t*>(E), N, D, target, keep_prob, seed, row_offset,
-                               keep_mask, nll, lse, dx, ws, as_stream(stream));
+        return catalog_ce_bf16(rx, R, reinterpret_cast<const uint16_t*>(E), N, D, e_max_norm, target, keep_prob, seed,
+                               row_offset, keep_mask, nll, lse, dx, ws, as_stream(stream));
     }
     set_error("catalog_ce: precision mode %d not available in this build", prec);
     return PCVAE_EINVAL;

@@ -51,6 +51,8 @@ struct CatParamsB {
     float* pm;              // [nsplit][R] running max, log2 domain
     float* pl;              // [nsplit][R]
     float* pU;              // [nsplit][R][D]
+    const uint8_t* safe_flags;  // [nrb] or null: 1 = this row block needs the lazy-max kernel (large |rx|)
+    int run_if_flag;        // this launch handles the row blocks whose flag equals this value
 };
 
 template <int D>
@@ -108,6 +110,7 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_kernel(CatParamsB p) {
     const int li = lane & 31, h = lane >> 5;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / p.nrb, rb = logical % p.nrb;
+    if (p.safe_flags && p.safe_flags[rb] != p.run_if_flag) return;  // the other kernel owns this row block
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
     const int n_chunks = (t_end - t_beg + 3) / 4;
@@ -276,6 +279,204 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_kernel(CatParamsB p) {
     }
 }
 
+// =============================================================================================
+// Row bound prologue: a row whose |logit| bound  ||rx_r|| * max_n ||E_n|| * log2(e)  is <= 90 can use raw
+// exp2(logit) with NO running max at all: every term is in [2^-90, 2^90], a sum of 10^7 of them is
+// < 2^114, all normal fp32 numbers.  Row blocks with a larger bound are flagged for the lazy-max kernel.
+// =============================================================================================
+constexpr float kFastBound = 90.0f;
+
+template <int D>
+__global__ void __launch_bounds__(256) catalog_row_bound_kernel(const float* __restrict__ rx, int64_t R, float e_max_norm,
+                                                                uint8_t* __restrict__ flags) {
+    __shared__ int any_unsafe;
+    if (threadIdx.x == 0) any_unsafe = 0;
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * ROWS_WG + threadIdx.x;
+    bool unsafe = !(e_max_norm > 0.f);
+    if (r < R && !unsafe) {
+        float ss = 0.f;
+        for (int k = 0; k < D; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(rx + r * D + k);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        unsafe = !(sqrtf(ss) * e_max_norm * kLog2e <= kFastBound);  // NaN/inf rows count as unsafe
+    }
+    if (unsafe) atomicOr(&any_unsafe, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = (uint8_t)any_unsafe;
+}
+
+// =============================================================================================
+// Fast path, D = 128: no running max, LDS offsets of all reads are lane base ^ constant + immediate
+// (tools/lds_bank_check.py proves the decomposition), the (buffer, subtile) loops are unrolled so that
+// the hot loop carries no address arithmetic, no compare and no branch besides the chunk loop itself.
+// =============================================================================================
+template <int MASK, bool WANT_DX, bool CHECK_N>
+__device__ __forceinline__ void subtile_d128(const CatParamsB& p, const char* smem, const int off, const int64_t n0,
+                                             const bf16x8 (&xb)[8], f32x16 (&U)[4], float& lsum, const int a0,
+                                             const int t0, const int h, const int64_t tgt, const uint64_t grow,
+                                             const int64_t rl) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 5)) + off));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc, 0, 0, 0);
+    }
+    bool kp[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kp[i] = true;
+    if (MASK == MASK_PHILOX) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const uint64_t nbq = (uint64_t)(n0 + 8 * qq + 4 * h);
+            const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(nbq >> 2),
+                                             (uint32_t)(nbq >> 34) ^ 0x4D41534Bu, (uint32_t)p.seed,
+                                             (uint32_t)(p.seed >> 32));
+            const uint32_t u[4] = {ph.x, ph.y, ph.z, ph.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kp[4 * qq + j] = (u[j] < p.keep_thresh) || ((int64_t)(n0 + 8 * qq + 4 * h + j) == tgt);
+        }
+    } else if (MASK == MASK_BYTES) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t n = n0 + nloc(i, h);
+            kp[i] = (n == tgt) || (n < p.N && p.keep[rl * p.N + n] != 0);
+        }
+    }
+    if (MASK != MASK_NONE) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = kp[i] ? acc[i] : 0.f;  // masked-out logit is 0 -> exp2 = 1
+    }
+    if (CHECK_N) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (n0 + nloc(i, h) >= p.N) { acc[i] = -INFINITY; kp[i] = false; }
+    }
+    float pk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(acc[i]);
+        lsum += e;
+        pk[i] = (MASK == MASK_NONE || kp[i]) ? e : 0.f;
+    }
+    if (WANT_DX) {
+        bf16x8 pb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[ks][j] = (__bf16)pk[8 * ks + j];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(smem + ((t0 ^ (b << 6)) + (ks * 4096 + off))));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(smem + ((t0 ^ ((b << 6) | 32)) + (ks * 4096 + 2048 + off))));
+                const s16x8 a16 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                U[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[ks], U[b], 0, 0, 0);
+            }
+    }
+}
+
+template <int MASK, bool WANT_DX>
+__global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatParamsB p) {
+    constexpr int D = 128;
+    using G = GeoB<D>;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / p.nrb, rb = logical % p.nrb;
+    if (p.safe_flags[rb] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int n_chunks = (t_end - t_beg + 3) / 4;
+    // chunks whose 128 items all exist: no per-element bound checks in their bodies
+    int n_full = (int)min((int64_t)n_chunks, (p.N - (int64_t)t_beg * 32) / BN);
+    n_full = max(n_full, 0);
+
+    const int64_t r = (int64_t)rb * ROWS_WG + wave * 32 + li;
+    const bool row_ok = r < p.R;
+    const int64_t rl = row_ok ? r : p.R - 1;
+
+    stage_chunk<D>(p.E, p.N, (int64_t)t_beg * 32, smem);
+
+    bf16x8 xb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h);
+        const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h + 4);
+        xb[s][0] = (__bf16)(v0.x * kLog2e); xb[s][1] = (__bf16)(v0.y * kLog2e);
+        xb[s][2] = (__bf16)(v0.z * kLog2e); xb[s][3] = (__bf16)(v0.w * kLog2e);
+        xb[s][4] = (__bf16)(v1.x * kLog2e); xb[s][5] = (__bf16)(v1.y * kLog2e);
+        xb[s][6] = (__bf16)(v1.z * kLog2e); xb[s][7] = (__bf16)(v1.w * kLog2e);
+    }
+    const int64_t tgt = (MASK != MASK_NONE) ? p.target[rl] : -1;
+    const uint64_t grow = p.row_offset + (uint64_t)rl;
+
+    f32x16 U[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) U[b][i] = 0.f;
+    float lsum = 0.f;
+
+    // lane bases of the two LDS read patterns (see tools/lds_bank_check.py)
+    const int w = ((li & 3) << 2) | ((li >> 2) & 3);
+    const int a0 = li * 256 + ((w ^ h) << 4);
+    const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3, g1 = grp >> 1, g0 = grp & 1;
+    const int t0 = (4 * g1 + q) * 256 + ((((q << 2) | g1) ^ (2 * g0 + (pp >> 1))) << 4) + (pp & 1) * 8;
+
+    __syncthreads();
+    int c = 0;
+    for (; c + 2 <= n_full; c += 2) {  // two full chunks per iteration: buffer 0 then buffer 1, offsets immediate
+        const int64_t nA = (int64_t)(t_beg + 4 * c) * 32;
+        stage_chunk<D>(p.E, p.N, nA + BN, smem + G::CHUNK_BYTES);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            subtile_d128<MASK, WANT_DX, false>(p, smem, st * 8192, nA + 32 * st, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+        __syncthreads();
+        if (c + 2 < n_chunks) stage_chunk<D>(p.E, p.N, nA + 2 * BN, smem);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+            subtile_d128<MASK, WANT_DX, false>(p, smem, G::CHUNK_BYTES + st * 8192, nA + BN + 32 * st, xb, U, lsum, a0,
+                                               t0, h, tgt, grow, rl);
+        __syncthreads();
+    }
+    for (; c < n_chunks; ++c) {  // tail: at most two chunks, possibly short / ragged; runtime offsets
+        const int t0c = t_beg + 4 * c;
+        const int boff = (c & 1) ? G::CHUNK_BYTES : 0;
+        if (c + 1 < n_chunks) stage_chunk<D>(p.E, p.N, (int64_t)(t0c + 4) * 32, smem + (G::CHUNK_BYTES - boff));
+        const int nsub = min(4, t_end - t0c);
+        for (int st = 0; st < nsub; ++st)
+            subtile_d128<MASK, WANT_DX, true>(p, smem, boff + st * 8192, (int64_t)(t0c + st) * 32, xb, U, lsum, a0, t0, h,
+                                              tgt, grow, rl);
+        __syncthreads();
+    }
+
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (row_ok) {
+        const int64_t o = (int64_t)split * p.R + r;
+        if (h == 0) { p.pm[o] = 0.f; p.pl[o] = ltot; }
+        if (WANT_DX) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int d0 = b * 32 + 8 * qq + 4 * h;
+                    *reinterpret_cast<float4*>(p.pU + o * D + d0) =
+                        make_float4(U[b][4 * qq], U[b][4 * qq + 1], U[b][4 * qq + 2], U[b][4 * qq + 3]);
+                }
+        }
+    }
+}
+
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
 
 // one wave per row: merge split partials (log2 domain), target logit in the kernel's own arithmetic
@@ -312,10 +513,42 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_bf16_kernel(CatParamsB p
 }
 
 template <int D>
-int launch_ce_b(const CatParamsB& p, int mask_mode, bool want_dx, float* nll, float* lse, float* dx, hipStream_t st) {
+int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uint8_t* flags, float* nll, float* lse,
+                float* dx, hipStream_t st) {
     using G = GeoB<D>;
     const size_t lds = 2 * G::CHUNK_BYTES;
     const dim3 grid((unsigned)(p.nrb * p.nsplit)), block(512);
+    p.safe_flags = nullptr;
+    p.run_if_flag = 1;
+    if (D == 128) {
+        // row blocks with a small logit bound run the max-free kernel, the others the lazy-max kernel;
+        // both launches cover the whole grid and each workgroup exits at once if the other kernel owns it
+        hipLaunchKernelGGL((catalog_row_bound_kernel<D>), dim3((unsigned)p.nrb), dim3(256), 0, st, p.rx, p.R, e_max_norm,
+                           flags);
+        p.safe_flags = flags;
+#define PCVAE_CEF(MASKV, DXV)                                                                                    \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_d128_fast_kernel<MASKV, DXV>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((catalog_ce_bf16_d128_fast_kernel<MASKV, DXV>), grid, block, lds, st, p);             \
+    } while (0)
+        if (want_dx) {
+            if (mask_mode == MASK_NONE) PCVAE_CEF(MASK_NONE, true);
+            else if (mask_mode == MASK_PHILOX) PCVAE_CEF(MASK_PHILOX, true);
+            else PCVAE_CEF(MASK_BYTES, true);
+        } else {
+            if (mask_mode == MASK_NONE) PCVAE_CEF(MASK_NONE, false);
+            else if (mask_mode == MASK_PHILOX) PCVAE_CEF(MASK_PHILOX, false);
+            else PCVAE_CEF(MASK_BYTES, false);
+        }
+#undef PCVAE_CEF
+        int rc0 = check_launch("catalog_ce_bf16_fast");
+        if (rc0 != PCVAE_OK) return rc0;
+    }
 #define PCVAE_CEB(MASKV, DXV)                                                                                    \
     do {                                                                                                         \
         static bool attr_set = false;                                                                            \
@@ -347,9 +580,9 @@ int launch_ce_b(const CatParamsB& p, int mask_mode, bool want_dx, float* nll, fl
 
 namespace pcvae {
 
-int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, const int64_t* target,
-                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,
-                    float* lse, float* dx, void* ws, hipStream_t st) {
+int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
+                    const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
+                    const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, hipStream_t st) {
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16);
     CatParamsB p{};
     p.rx = rx; p.E = E; p.target = target; p.keep = keep_mask;
@@ -358,6 +591,8 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
     p.pm = reinterpret_cast<float*>(ws);
     p.pl = p.pm + (int64_t)pl.nsplit * R;
     p.pU = p.pl + (int64_t)pl.nsplit * R;
+    // row-block flags live behind the partials (pcvae_catalog_ws_bytes reserves them)
+    uint8_t* flags = reinterpret_cast<uint8_t*>(p.pU + (dx ? (int64_t)pl.nsplit * R * D : 0));
     int mask_mode = MASK_NONE;
     if (keep_mask) mask_mode = MASK_BYTES;
     else if (keep_prob < 1.0f) {
@@ -366,9 +601,9 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
         p.keep_thresh = th <= 0.0 ? 0u : (th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th);
     }
     switch (D) {
-        case 64: return launch_ce_b<64>(p, mask_mode, dx != nullptr, nll, lse, dx, st);
-        case 128: return launch_ce_b<128>(p, mask_mode, dx != nullptr, nll, lse, dx, st);
-        case 256: return launch_ce_b<256>(p, mask_mode, dx != nullptr, nll, lse, dx, st);
+        case 64: return launch_ce_b<64>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
+        case 128: return launch_ce_b<128>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
+        case 256: return launch_ce_b<256>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
     }
     set_error("catalog_ce(bf16): unsupported D=%d (64, 128, 256; smaller tables use the f32 kernel)", D);
     return PCVAE_EINVAL;

@@ -286,6 +286,7 @@ class CatalogTable:
         self.weight = weight
         self._ver = None
         self._hi = self._lo = None
+        self._emax = 0.0
 
     def operands(self, prec):
         w = self.weight
@@ -297,8 +298,14 @@ class CatalogTable:
             hi = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
             lo = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
             check(lib().pcvae_split_bf16(ptr(w32, F32), w32.numel(), ptr(hi), ptr(lo), stream()), "split_bf16")
+            # max row norm: lets the bf16 kernel skip the running max where |logit| provably stays small.
+            # One-off per table version (frozen table), like the bf16 copies themselves.
+            self._emax = float(w32.pow(2).sum(1).max().sqrt().item()) * (1.0 + 1e-6)
             self._hi, self._lo, self._ver = hi, lo, key
         return self._hi, (self._lo if prec == PREC_BF16X3 else None)
+
+    def e_max_norm(self, prec):
+        return 0.0 if prec == PREC_F32 else self._emax
 
 
 _ws_cache = {}
@@ -350,7 +357,8 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     ws = _workspace(rx.device, nbytes)
     timing = CATALOG_CE_TIMING
     tok = timing[0]() if timing else None
-    check(lib().pcvae_catalog_ce(ptr(rx, F32), R, ptr(E), ptr(E_lo), N, D, prec, ptr(target), float(keep_prob),
+    check(lib().pcvae_catalog_ce(ptr(rx, F32), R, ptr(E), ptr(E_lo), N, D, prec, table.e_max_norm(prec), ptr(target),
+                                 float(keep_prob),
                                  int(seed), int(row_offset), ptr(keep_mask), ptr(nll, F32), ptr(lse, F32), ptr(dx),
                                  ptr(ws), ws.numel(), stream()), "catalog_ce")
     if timing:
