@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpcvae_hip.so")
+# PCVAE_LIB: load an alternative build of the same ABI (kernel A/B experiments, tools/bench_catalog.py)
+LIB_PATH = os.environ.get("PCVAE_LIB") or os.path.join(_HERE, "lib", "libpcvae_hip.so")
 
 ACT_NONE, ACT_LEAKY = 0, 1
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2

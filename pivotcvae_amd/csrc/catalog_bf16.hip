@@ -3,20 +3,28 @@
 //
 // Same algorithm as catalog_f32.hip (flash-attention with K = V = E, split over catalog ranges, merged by a
 // deterministic log-sum-exp kernel) re-tiled for the 16x faster bf16 pipe, where the softmax VALU work and
-// the LDS/L2 feed - not the MFMA - are the things to budget:
+// the LDS / L2 feed - not the MFMA - are the things to budget:
 //
 //   * workgroup = 8 waves = 256 rows of rx; wave w owns rows 32w..32w+31 for the whole catalog range and
 //     keeps them in registers as bf16 B fragments, pre-multiplied by log2(e) so exp is a bare v_exp_f32;
 //     two waves share a SIMD, so one wave's softmax VALU runs under its partner's MFMAs;
-//   * the bf16 copy of E streams through LDS in 128-item chunks (32 KB, double buffered) filled by
-//     global_load_lds_dwordx4 (no staging VGPRs, asynchronous); the LDS image keeps 2*D-byte rows and
-//     XOR-swizzles the 16-byte chunks with ((row&3)<<2 | (row>>2)&3) on the SOURCE address, which makes both
-//     the row reads (ds_read_b128, logits A operand) and the transposed reads (ds_read_b64_tr_b16, E^T A
-//     operand of the gradient chain) bank-conflict free on one image;
-//   * logits are produced "swapped" (C[n][r]) with the running max folded into the accumulator's initial
-//     value (acc = -m), so per element the epilogue is max3 / exp2 / add / cvt; the max is raised lazily
-//     (only when a tile exceeds it by more than 2^8), keeping the O(D) rescale of the U accumulator rare;
-//   * exp2 values converted pairwise to bf16 are, in place, the B operand of U^T[d][r] += E^T[d][n] P[n][r].
+//   * the bf16 copy of E streams through LDS by global_load_lds_dwordx4 (no staging VGPRs, asynchronous); the
+//     LDS image keeps 2*D-byte rows and XOR-swizzles the 16-byte chunks with ((row&3)<<2 | (row>>2)&3) on the
+//     SOURCE address, which makes both the row reads (ds_read_b128, logits A operand) and the transposed reads
+//     (ds_read_b64_tr_b16, E^T A operand of the gradient chain) bank-conflict free on one image
+//     (tools/lds_bank_check.py; measured SQ_LDS_BANK_CONFLICT = 0);
+//   * logits are produced "swapped" (C[n][r]): a lane holds 16 logits of one row, exp / sum are lane-local, and
+//     the exp2 values converted pairwise to bf16 are, in place, the B operand of U^T[d][r] += E^T[d][n] P[n][r].
+//
+// Three kernels:
+//   catalog_row_bound_kernel          per 256-row block: is ||rx|| * max||E|| * log2(e) <= 90 for every row?
+//   catalog_ce_bf16_d128_fast_kernel  D = 128, blocks that pass: NO running max (every exp2(logit) is a normal fp32
+//                                     number, sums of 10^7 of them stay < 2^114); 4-deep ring of 64-item LDS
+//                                     buffers requested three chunks ahead, counted s_waitcnt vmcnt(4) + raw
+//                                     s_barrier at the seams, all LDS offsets immediates, transposed reads
+//                                     through inline asm (the builtin makes hipcc drain every in-flight LDS-DMA)
+//   catalog_ce_bf16_kernel<D>         D = 64 / 128 / 256, any norms, masks, loss-only: lazy running max (raised
+//                                     only when a tile exceeds it by 2^8), 128-item double-buffered chunks
 //
 // Numerics: bf16 inputs (round-to-nearest-even), fp32 accumulation, softmax statistics in fp32.  Against
 // the fp32 reference the per-logit error is ~2^-9 relative per product and zero-mean, so the ELBO terms of
@@ -312,7 +320,23 @@ __global__ void __launch_bounds__(256) catalog_row_bound_kernel(const float* __r
 // (tools/lds_bank_check.py proves the decomposition), the (buffer, subtile) loops are unrolled so that
 // the hot loop carries no address arithmetic, no compare and no branch besides the chunk loop itself.
 // =============================================================================================
-template <int MASK, bool WANT_DX, bool CHECK_N>
+
+// ds_read_b64_tr_b16 through inline asm: the builtin makes hipcc wait vmcnt(0) for every in-flight
+// global_load_lds before the read (it cannot prove the read does not alias the LDS-DMA write), which serialises
+// the whole staging stream behind the compute.  The asm reads are invisible to hipcc's counters, so their
+// completion is awaited explicitly (tr_wait) before the first consumer.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(const unsigned addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ void tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MASK, bool WANT_DX, bool CHECK_N, int OFF>
 __device__ __forceinline__ void subtile_d128(const CatParamsB& p, const char* smem, const int off, const int64_t n0,
                                              const bf16x8 (&xb)[8], f32x16 (&U)[4], float& lsum, const int a0,
                                              const int t0, const int h, const int64_t tgt, const uint64_t grow,
@@ -322,7 +346,7 @@ __device__ __forceinline__ void subtile_d128(const CatParamsB& p, const char* sm
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 5)) + off));
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 5)) + off + OFF));
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc, 0, 0, 0);
     }
     bool kp[16];
@@ -369,17 +393,53 @@ __device__ __forceinline__ void subtile_d128(const CatParamsB& p, const char* sm
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) pb[ks][j] = (__bf16)pk[8 * ks + j];
+        // gradient chain: E^T pieces by asm transposed reads, requested two MFMAs ahead (8 VGPRs in flight)
+        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)off;
+        s16x4 tl[8], th[8];
+#define PCVAE_TR(K)                                                                                             \
+        {                                                                                                       \
+            const unsigned alo = lbase + (unsigned)(t0 ^ (((K) >> 1) << 6)), ahi = lbase + (unsigned)(t0 ^ ((((K) >> 1) << 6) | 32)); \
+            tl[K] = tr_read<OFF + ((K) & 1) * 4096>(alo);                                                       \
+            th[K] = tr_read<OFF + ((K) & 1) * 4096 + 2048>(ahi);                                                \
+        }
+        PCVAE_TR(0) PCVAE_TR(1)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(smem + ((t0 ^ (b << 6)) + (ks * 4096 + off))));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4*)(smem + ((t0 ^ ((b << 6) | 32)) + (ks * 4096 + 2048 + off))));
-                const s16x8 a16 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                U[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[ks], U[b], 0, 0, 0);
+        for (int k = 0; k < 8; ++k) {
+            if (k + 2 < 8) {
+                if (k == 0) PCVAE_TR(2) else if (k == 1) PCVAE_TR(3) else if (k == 2) PCVAE_TR(4)
+                else if (k == 3) PCVAE_TR(5) else if (k == 4) PCVAE_TR(6) else PCVAE_TR(7)
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // reads of step k done, steps k+1, k+2 in flight
+            } else if (k == 6) {
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const s16x8 a16 = __builtin_shufflevector(tl[k], th[k], 0, 1, 2, 3, 4, 5, 6, 7);
+            U[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[k & 1], U[k >> 1], 0, 0, 0);
+        }
+#undef PCVAE_TR
+    }
+}
+
+// Ring of 4 x 64-item LDS buffers (16 KB each): chunk c lives in buffer c & 3 and is requested THREE chunks
+// before it is consumed, so the LDS-DMA stream has ~2.5 us to land (one chunk ahead was latency-bound:
+// every variant of the inner loop ran at the same 32.5 ms).  The seam between chunks is a counted
+// s_waitcnt vmcnt(4) (the two younger chunks stay in flight) + a raw s_barrier; all offsets stay immediates.
+constexpr int BNF = 64;                 // items per chunk of the fast kernel
+constexpr int CBF = BNF * 256;          // bytes per chunk (D = 128, bf16)
+constexpr int NRING = 4;
+
+// global -> LDS copy of one full 64-item chunk by 8 waves (2 one-KiB pieces each): wave-uniform base + one of two
+// per-lane 32-bit offsets (the swizzle depends on the piece only through piece & 3 = 2*(wave & 1) + i)
+__device__ __forceinline__ void stage_chunk_f(const uint16_t* __restrict__ E, int64_t n0, char* buf, const int wave_u,
+                                              const int (&lane_off)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pc = wave_u * 2 + i;
+        const char* base = reinterpret_cast<const char*>(E) + (n0 + pc * 4) * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane_off[i]),
+                                         (__attribute__((address_space(3))) void*)(buf + pc * 1024), 16, 0, 0);
     }
 }
 
@@ -396,16 +456,27 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
     if (p.safe_flags[rb] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
-    const int n_chunks = (t_end - t_beg + 3) / 4;
-    // chunks whose 128 items all exist: no per-element bound checks in their bodies
-    int n_full = (int)min((int64_t)n_chunks, (p.N - (int64_t)t_beg * 32) / BN);
+    const int64_t nbase = (int64_t)t_beg * 32;
+    // 64-item chunks of this range that exist in full (no per-element bound checks in their bodies)
+    const int n_half = (t_end - t_beg + 1) / 2;
+    int n_full = (int)min((int64_t)n_half, (p.N - nbase) / BNF);
     n_full = max(n_full, 0);
 
     const int64_t r = (int64_t)rb * ROWS_WG + wave * 32 + li;
     const bool row_ok = r < p.R;
     const int64_t rl = row_ok ? r : p.R - 1;
 
-    stage_chunk<D>(p.E, p.N, (int64_t)t_beg * 32, smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int lane_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // row = 4*piece + (lane>>4), piece & 3 = 2*(wave&1) + i
+        const int rr = (lane >> 4) | (((2 * (wave & 1) + i) & 3) << 2);
+        lane_off[i] = (lane >> 4) * 256 + (swz_chunk<128>(rr, lane & 15) << 4);
+    }
+    // prologue: chunks 0..2 in flight
+#pragma unroll
+    for (int c0 = 0; c0 < 3; ++c0)
+        if (c0 < n_full) stage_chunk_f(p.E, nbase + (int64_t)c0 * BNF, smem + c0 * CBF, wave_u, lane_off);
 
     bf16x8 xb[8];
 #pragma unroll
@@ -427,37 +498,51 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
         for (int i = 0; i < 16; ++i) U[b][i] = 0.f;
     float lsum = 0.f;
 
-    // lane bases of the two LDS read patterns (see tools/lds_bank_check.py)
     const int w = ((li & 3) << 2) | ((li >> 2) & 3);
     const int a0 = li * 256 + ((w ^ h) << 4);
     const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3, g1 = grp >> 1, g0 = grp & 1;
     const int t0 = (4 * g1 + q) * 256 + ((((q << 2) | g1) ^ (2 * g0 + (pp >> 1))) << 4) + (pp & 1) * 8;
 
-    __syncthreads();
+    // ---- pipelined part: while chunk c is consumed, chunks c+1..c+3 are landed or in flight
+    // seam before consuming chunk c: this wave's pieces of chunk c have landed once at most 4 younger
+    // LDS-DMA instructions (chunks c+1, c+2) are outstanding; then everybody's have (barrier)
+#define PCVAE_SEAM(VMCNT) asm volatile("s_waitcnt vmcnt(" #VMCNT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
     int c = 0;
-    for (; c + 2 <= n_full; c += 2) {  // two full chunks per iteration: buffer 0 then buffer 1, offsets immediate
-        const int64_t nA = (int64_t)(t_beg + 4 * c) * 32;
-        stage_chunk<D>(p.E, p.N, nA + BN, smem + G::CHUNK_BYTES);
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-            subtile_d128<MASK, WANT_DX, false>(p, smem, st * 8192, nA + 32 * st, xb, U, lsum, a0, t0, h, tgt, grow, rl);
-        __syncthreads();
-        if (c + 2 < n_chunks) stage_chunk<D>(p.E, p.N, nA + 2 * BN, smem);
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-            subtile_d128<MASK, WANT_DX, false>(p, smem, G::CHUNK_BYTES + st * 8192, nA + BN + 32 * st, xb, U, lsum, a0,
-                                               t0, h, tgt, grow, rl);
-        __syncthreads();
+    const int n_pipe = n_full >= 3 ? n_full - 2 : 0;   // chunks consumed with two younger chunks in flight
+    for (; c + 4 <= n_pipe; c += 4) {
+#define PCVAE_RING_STEP(UU)                                                                                          \
+        {                                                                                                            \
+            const int64_t nA = nbase + (int64_t)(c + UU) * BNF;                                                      \
+            PCVAE_SEAM(4);                                                                                           \
+            /* buffer (UU+3)&3 held chunk c+UU-1, which every wave has finished: refill it */                        \
+            if (c + UU + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((UU + 3) & 3) * CBF, wave_u, lane_off); \
+            subtile_d128<MASK, WANT_DX, false, UU * CBF>(p, smem, 0, nA, xb, U, lsum, a0, t0, h, tgt, grow, rl);     \
+            subtile_d128<MASK, WANT_DX, false, UU * CBF + 8192>(p, smem, 0, nA + 32, xb, U, lsum, a0, t0, h, tgt, grow, rl); \
+        }
+        PCVAE_RING_STEP(0)
+        PCVAE_RING_STEP(1)
+        PCVAE_RING_STEP(2)
+        PCVAE_RING_STEP(3)
+#undef PCVAE_RING_STEP
     }
-    for (; c < n_chunks; ++c) {  // tail: at most two chunks, possibly short / ragged; runtime offsets
-        const int t0c = t_beg + 4 * c;
-        const int boff = (c & 1) ? G::CHUNK_BYTES : 0;
-        if (c + 1 < n_chunks) stage_chunk<D>(p.E, p.N, (int64_t)(t0c + 4) * 32, smem + (G::CHUNK_BYTES - boff));
-        const int nsub = min(4, t_end - t0c);
-        for (int st = 0; st < nsub; ++st)
-            subtile_d128<MASK, WANT_DX, true>(p, smem, boff + st * 8192, (int64_t)(t0c + st) * 32, xb, U, lsum, a0, t0, h,
-                                              tgt, grow, rl);
+    // ---- remaining full chunks: drain the ring (vmcnt(0)), runtime offsets
+    for (; c < n_full; ++c) {
+        const int64_t nA = nbase + (int64_t)c * BNF;
+        PCVAE_SEAM(0);
+        if (c + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((c + 3) & 3) * CBF, wave_u, lane_off);
+        const int boff = (c & 3) * CBF;
+        subtile_d128<MASK, WANT_DX, false, 0>(p, smem, boff, nA, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+        subtile_d128<MASK, WANT_DX, false, 8192>(p, smem, boff, nA + 32, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+    }
+#undef PCVAE_SEAM
+    // ---- tail: short / ragged chunks (at most a few subtiles), staged synchronously with clamped addresses
+    for (int t = t_beg + 2 * n_full; t < t_end; t += 4) {
         __syncthreads();
+        stage_chunk<D>(p.E, p.N, (int64_t)t * 32, smem);
+        __syncthreads();
+        const int nsub = min(4, t_end - t);
+        for (int st = 0; st < nsub; ++st)
+            subtile_d128<MASK, WANT_DX, true, 0>(p, smem, st * 8192, (int64_t)(t + st) * 32, xb, U, lsum, a0, t0, h, tgt, grow, rl);
     }
 
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
