@@ -126,6 +126,9 @@ def main():
                          "parity with the fp32 oracle is measured live in the 'parity' block) or exact f32 MFMA")
     ap.add_argument("--n_neg", type=int, default=None, help="default: N (full-catalog softmax)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="override the config's global batch (e.g. 1024 on one GPU = the per-rank load of the 8-GPU run)")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -143,12 +146,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.global_batch:
+        cfg["B"] = args.global_batch
     N, S, D, B = cfg["N"], cfg["S"], cfg["D"], cfg["B"]
     if B % world:
         raise SystemExit("global batch not divisible by the number of GPUs")
     model, st = build_model(cfg, device, args.dtype)
-    trainer = Trainer(model, lr=LR, beta=BETA, n_neg=args.n_neg)
+    trainer = Trainer(model, lr=LR, beta=BETA, n_neg=args.n_neg, capture_graph=not args.no_graph)
     s, r, u = synthetic_batch(cfg, B, device)
     (s, r, u), lo = trainer.shard(s, r, u)
     s, r, u = s.contiguous(), r.contiguous(), u.contiguous()
@@ -173,7 +178,9 @@ def main():
 
     for _ in range(args.warmup):
         trainer.step(s, r, u, global_batch=B, row_offset=lo)
-    ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
+    graphed = trainer.capture_graph and trainer._graph is not None
+    if not graphed:
+        ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -185,6 +192,17 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    if graphed:
+        # HIP events cannot be recorded inside a hipGraph (ROCm 7.2: hipErrorInvalidHandle, tools/evt_graph_probe.py),
+        # so the dominant kernel is timed over the same number of EAGER steps right after the timed region:
+        # same kernel, same inputs, same launch stream.
+        trainer.capture_graph = False
+        ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
+        for _ in range(args.steps):
+            trainer.step(s, r, u, global_batch=B, row_offset=lo)
+        torch.cuda.synchronize()
+        ops.CATALOG_CE_TIMING = None
+        trainer.capture_graph = True
 
     kern_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
     R_local = s.shape[0] * S
@@ -205,13 +223,16 @@ def main():
         "config": {"workload": f"PivotCVAE gt_pi train step (fwd+bwd+Adam), catalog N={N} slate K={S} emb D={D} "
                                f"global batch B={B}, full-catalog softmax" + ("" if args.n_neg is None else f" n_neg={args.n_neg}"),
                    "global_batch": B, "per_gpu_batch": B // world, "parallelism": f"dp{world}",
-                   "catalog_arithmetic": args.dtype, "mlp_arithmetic": "f32"},
+                   "catalog_arithmetic": args.dtype, "mlp_arithmetic": "f32",
+                   "launch": "hipGraph replay (zero-grad+fwd+bwd) + eager all-reduce + Adam" if graphed else "eager"},
         "elbo": {"loss": loss.item(), "recLoss": rec.item(), "KLD": kld.item()},
         "roofline": {"kernel": (f"catalog_ce_bf16_d128_fast_kernel<0,true>" if (args.dtype == "bf16" and D == 128) else
                                 f"catalog_ce_{args.dtype}_kernel<{D}>") + " (events also span its row-bound prologue and "
                                "merge kernels, <1% together)", "bound": "mfma",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "ms_per_launch": kern_ms, "algorithmic_flops_per_launch": flops},
+                     "traffic": traffic, "ms_per_launch": kern_ms, "algorithmic_flops_per_launch": flops,
+                     "timed_over": (f"{args.steps} eager steps right after the timed graph-replayed steps (HIP events cannot be "
+                                    "recorded inside a hipGraph)") if graphed else "the timed steps"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, parity = cpu_baseline_and_parity(model, st, cfg, args.dtype)

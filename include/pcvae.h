@@ -96,6 +96,9 @@ int pcvae_leaky_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t 
  * ------------------------------------------------------------------------------------------- */
 int pcvae_reparam_fwd(const float* mu, const float* logvar, const float* eps_in, uint64_t seed, uint64_t offset,
                       float* z, int64_t ldz, float* eps_out, int64_t B, int Z, pcvae_stream_t stream);
+/* out[i] = N(0,1) sample i of the same Philox stream pcvae_reparam_fwd uses (counter = offset + i): lets a caller
+ * draw eps outside a captured hipGraph and feed it in through eps_in (kernel arguments are frozen at capture) */
+int pcvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, pcvae_stream_t stream);
 int pcvae_reparam_bwd(const float* dz, int64_t lddz, const float* eps, const float* logvar, float* dmu,
                       float* dlogvar, int64_t B, int Z, pcvae_stream_t stream);
 

@@ -33,6 +33,7 @@ SIGNATURES = {
     "pcvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _P],
     "pcvae_leaky_bwd": [_P, _L, _P, _L, _L, _I, _P],
     "pcvae_reparam_fwd": [_P, _P, _P, _U64, _U64, _P, _L, _P, _L, _I, _P],
+    "pcvae_philox_normal": [_P, _L, _U64, _U64, _P],
     "pcvae_reparam_bwd": [_P, _L, _P, _P, _P, _P, _L, _I, _P],
     "pcvae_kld_fwd": [_P, _P, _P, _P, _L, _P, _P],
     "pcvae_kld_bwd": [_P, _P, _P, _P, _L, _P, _F, _P, _P, _P, _P, _P],

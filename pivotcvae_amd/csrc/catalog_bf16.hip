@@ -564,23 +564,33 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
 
-// one wave per row: merge split partials (log2 domain), target logit in the kernel's own arithmetic
+// one wave per row: merge the split partials (log2 domain), target logit in the kernel's own arithmetic.
+// Lane j owns split j's (m, l) (nsplit <= 64), so max / rescale / sum are wave reductions; the U rows of the
+// splits are then streamed with 8 independent loads in flight per lane.
 template <int D>
 __global__ void __launch_bounds__(256) catalog_ce_merge_bf16_kernel(CatParamsB p, float* __restrict__ nll,
                                                                     float* __restrict__ lse, float* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= p.R) return;
-    float M = -INFINITY;
-    for (int j = 0; j < p.nsplit; ++j) M = fmaxf(M, p.pm[(int64_t)j * p.R + r]);
-    float L = 0.f;
-    for (int j = 0; j < p.nsplit; ++j) L += p.pl[(int64_t)j * p.R + r] * exp2f(p.pm[(int64_t)j * p.R + r] - M);
+    const float mj = lane < p.nsplit ? p.pm[(int64_t)lane * p.R + r] : -INFINITY;
+    const float lj = lane < p.nsplit ? p.pl[(int64_t)lane * p.R + r] : 0.f;
+    float M = mj;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+    const float sj = lane < p.nsplit ? exp2f(mj - M) : 0.f;
+    float L = lj * sj;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o, 64);
     const int64_t t = p.target[r];
     const bool t_ok = t >= 0 && t < p.N;
+    // target logit: each lane takes D/64 of the products, same bf16 operands as the MFMA chain
     float zt = 0.f;
     if (t_ok)
-        for (int k = 0; k < D; ++k)
+        for (int k = lane; k < D; k += 64)
             zt = fmaf(bf16_to_f32(p.E[t * D + k]), (float)(__bf16)(p.rx[r * D + k] * kLog2e), zt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zt += __shfl_xor(zt, o, 64);
     const float lse_r = (M + log2f(L)) * kLn2;
     if (lane == 0) {
         nll[r] = t_ok ? lse_r - zt * kLn2 : NAN;
@@ -590,8 +600,15 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_bf16_kernel(CatParamsB p
         const float invL = 1.f / L;
         for (int d = lane; d < D; d += 64) {
             float u = 0.f;
-            for (int j = 0; j < p.nsplit; ++j)
-                u += p.pU[((int64_t)j * p.R + r) * D + d] * exp2f(p.pm[(int64_t)j * p.R + r] - M);
+            int j = 0;
+            for (; j + 8 <= p.nsplit; j += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = p.pU[((int64_t)(j + q) * p.R + r) * D + d];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u = fmaf(v[q], __shfl(sj, j + q, 64), u);
+            }
+            for (; j < p.nsplit; ++j) u = fmaf(p.pU[((int64_t)j * p.R + r) * D + d], __shfl(sj, j, 64), u);
             dx[r * D + d] = t_ok ? u * invL - bf16_to_f32(p.E[t * D + d]) : NAN;
         }
     }

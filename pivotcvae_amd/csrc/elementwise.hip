@@ -214,6 +214,19 @@ extern "C" int pcvae_reparam_fwd(const float* mu, const float* logvar, const flo
     return check_launch("reparam_fwd");
 }
 
+__global__ void philox_normal_kernel(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = philox_normal(seed, offset + (uint64_t)i);
+}
+
+extern "C" int pcvae_philox_normal(float* out, int64_t n, uint64_t seed, uint64_t offset, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(n >= 0 && (out || n == 0), "philox_normal: bad arguments");
+    if (n == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 2048);
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, n, seed, offset);
+    return check_launch("philox_normal");
+}
+
 __global__ void reparam_bwd_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ eps,
                                    const float* __restrict__ logvar, float* __restrict__ dmu,
                                    float* __restrict__ dlogvar, int64_t B, int Z) {

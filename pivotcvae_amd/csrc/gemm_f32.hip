@@ -30,6 +30,7 @@ struct GemmParams {
     float* C; int64_t ldc;         // C(m, n)
     int64_t M, N, K;
     const float* bias;             // EPI_FWD: [N] or null
+    float* bias_grad;              // EPI_DW: [M of this GEMM = layer outputs] or null: += sum over the reduction index
     const float* aux; int64_t ldaux;  // EPI_DX: activated input [M,N] or null
     int act;
     int64_t k_per_split;           // EPI_DW: reduction range per blockIdx.z
@@ -83,6 +84,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    // EPI_DW: A(m, k) = dY[k][m]; the column sums of dY (bias gradient) are the k-sums of the A tiles this block
+    // streams anyway.  Only the blocks of the first output column (blockIdx.x == 0) do it, 64 threads each.
+    const bool do_bias = (EPI == EPI_DW) && p.bias_grad != nullptr && blockIdx.x == 0 && threadIdx.x < BM;
+    float bsum = 0.f;
+
     float va[4], vb[4];
     load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, va);
     load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, vb);
@@ -92,6 +98,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
         store_tile<A_KC>(As, va);
         store_tile<B_KC>(Bs, vb);
         __syncthreads();
+        if (do_bias) {
+#pragma unroll
+            for (int k = 0; k < BK; ++k) bsum += As[k * LDT + threadIdx.x];
+        }
         if (k0 + BK < kend) {  // prefetch the next tile while this one is multiplied
             load_tile<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, kend, va);
             load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, vb);
@@ -103,6 +113,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     }
+
+    if (do_bias && m0 + threadIdx.x < p.M) atomicAdd(&p.bias_grad[m0 + threadIdx.x], bsum);
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t n = n0 + wn * 32 + li;
@@ -126,22 +138,6 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
     }
 }
 
-// db[n] += sum_m dY[m, n]
-__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ dY, int64_t ld, int64_t M, int64_t N,
-                                                     int64_t m_per_split, float* __restrict__ db) {
-    __shared__ float part[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int64_t n = (int64_t)blockIdx.x * 64 + tx;
-    const int64_t mbeg = (int64_t)blockIdx.y * m_per_split;
-    const int64_t mend = mbeg + m_per_split < M ? mbeg + m_per_split : M;
-    float acc = 0.f;
-    if (n < N)
-        for (int64_t m = mbeg + ty; m < mend; m += 4) acc += dY[m * ld + n];
-    part[ty][tx] = acc;
-    __syncthreads();
-    if (ty == 0 && n < N) atomicAdd(&db[n], part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
-}
-
 }  // namespace
 
 extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
@@ -152,7 +148,7 @@ extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int
     PCVAE_REQUIRE(act == PCVAE_ACT_NONE || act == PCVAE_ACT_LEAKY, "linear_fwd: unknown activation %d", act);
     if (M == 0) return PCVAE_OK;
     PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_fwd: M too large");
-    GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, 0, act, 0};
+    GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, nullptr, 0, act, 0};
     hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM)),
                        dim3(256), 0, as_stream(stream), p);
     return check_launch("linear_fwd");
@@ -167,7 +163,7 @@ extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float
     if (M == 0) return PCVAE_OK;
     PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_bwd_input: M too large");
     // C(m, kk) = sum_n dY[m, n] * W[n, kk]:  A = dY (reduction index contiguous), B(kk, n) = W[n * ldw + kk]
-    GemmParams p{dY, lddy, W, ldw, dX, lddx, M, K, N, nullptr, Xact, ldxa, 0, 0};
+    GemmParams p{dY, lddy, W, ldw, dX, lddx, M, K, N, nullptr, nullptr, Xact, ldxa, 0, 0};
     hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(M, BM)),
                        dim3(256), 0, as_stream(stream), p);
     return check_launch("linear_bwd_input");
@@ -187,19 +183,10 @@ extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const floa
     splits = std::min<int64_t>(splits, 64);
     int64_t kps = cdiv(cdiv(M, splits), BK) * BK;
     splits = cdiv(M, kps);
-    GemmParams p{dY, lddy, X, ldx, dW, lddw, N, K, M, nullptr, nullptr, 0, 0, kps};
+    GemmParams p{dY, lddy, X, ldx, dW, lddw, N, K, M, nullptr, db, nullptr, 0, 0, kps};
     hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_DW>),
                        dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(N, BM), (unsigned)splits), dim3(256), 0,
                        as_stream(stream), p);
     int rc = check_launch("linear_bwd_weight");
-    if (rc != PCVAE_OK) return rc;
-    if (db) {
-        int64_t ms = std::max<int64_t>(1, std::min<int64_t>(64, cdiv(M, 256)));
-        int64_t mps = cdiv(M, ms);
-        ms = cdiv(M, mps);
-        hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)ms), dim3(256), 0, as_stream(stream), dY,
-                           lddy, M, N, mps, db);
-        rc = check_launch("linear_bwd_weight(colsum)");
-    }
     return rc;
 }

@@ -145,7 +145,10 @@ class _MLP(torch.autograd.Function):
     """A stack of Linear(+LeakyReLU) layers as one autograd node.
 
     forward keeps the activated outputs; backward walks the stack once: LeakyReLU' of an inner layer is
-    fused into the epilogue of the input-gradient GEMM of the layer above it.
+    fused into the epilogue of the input-gradient GEMM of the layer above it.  When a parameter already owns a
+    gradient buffer (FlatAdam attaches views of its flat gradient buffer), the weight-gradient GEMM accumulates
+    straight into it - the kernel is an accumulating one anyway - instead of materialising a temporary that
+    autograd would then have to add (saves a fill + an add launch per parameter tensor).
     """
 
     @staticmethod
@@ -161,6 +164,9 @@ class _MLP(torch.autograd.Function):
             acts.append(h)
         ctx.last_linear = last_linear
         ctx.n = n
+        # gradient buffers to accumulate into directly (leaf parameters with a pre-attached, same-shape .grad)
+        ctx.direct = [p.grad if (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_cuda
+                                 and p.grad.shape == p.shape and p.grad.is_contiguous()) else None for p in params]
         ctx.save_for_backward(*acts, *params)
         return h
 
@@ -176,10 +182,14 @@ class _MLP(torch.autograd.Function):
         for i in range(n - 1, -1, -1):
             W, b = params[2 * i], params[2 * i + 1]
             if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
-                dW = torch.zeros_like(W)
-                db = torch.zeros_like(b)
-                linear_bwd_weight_raw(g, acts[i], dW, db)
-                grads[2 * i], grads[2 * i + 1] = dW, db
+                dW, db = ctx.direct[2 * i], ctx.direct[2 * i + 1]
+                if dW is not None and db is not None:
+                    linear_bwd_weight_raw(g, acts[i], dW, db)  # accumulated in place: nothing to hand to autograd
+                else:
+                    dW = torch.zeros_like(W)
+                    db = torch.zeros_like(b)
+                    linear_bwd_weight_raw(g, acts[i], dW, db)
+                    grads[2 * i], grads[2 * i + 1] = dW, db
             if i > 0:
                 g = linear_bwd_input_raw(g, W, xact=acts[i])  # acts[i] is layer i-1's activated output
             elif ctx.needs_input_grad[0]:
@@ -249,6 +259,13 @@ class _Reparam(torch.autograd.Function):
 def reparam(mu, logvar, eps=None, seed=0, offset=0):
     """-> (z, eps_used).  eps=None draws N(0,1) with the in-kernel Philox stream (seed, offset)."""
     return _Reparam.apply(mu, logvar, eps, int(seed), int(offset))
+
+
+def philox_normal_(out, seed=0, offset=0):
+    """Fill ``out`` with the N(0,1) stream reparam() would draw at (seed, offset)."""
+    require_device(out)
+    check(lib().pcvae_philox_normal(ptr(out, F32), out.numel(), int(seed), int(offset), stream()), "philox_normal")
+    return out
 
 
 # ------------------------------------------------------------------------------------------- K7

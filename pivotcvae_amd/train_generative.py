@@ -59,7 +59,8 @@ class Trainer:
     injectable so the collective logic can be exercised on CPU with gloo in tests.
     """
 
-    def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None):
+    def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None,
+                 capture_graph=False):
         import torch.distributed as dist
         self.model, self.beta, self.n_neg = model, float(beta), n_neg
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
@@ -69,6 +70,13 @@ class Trainer:
         self.opt = optimizer if optimizer is not None else FlatAdam(model, lr)
         self.loss_fn = loss_fn or (lambda m, s, r, u, **kw: m.loss(s, r, u, **kw))
         self.global_step = 0
+        # hipGraph capture of zero-grad + forward + backward (the ~90 small launches of a step become one graph
+        # launch; matters when a rank only holds B/8 slates).  eps is drawn OUTSIDE the graph into a static buffer
+        # because kernel arguments (Philox offsets) are frozen at capture; the in-kernel Bernoulli mask (n_neg < N)
+        # has the same problem, so that mode stays eager.  The all-reduce and Adam stay outside the graph.
+        self.capture_graph = bool(capture_graph) and n_neg is None and loss_fn is None
+        self._graph = None
+        self._static = None
 
     def shard(self, *tensors):
         """Contiguous shard of a global batch for this rank (+ its offset in the global batch)."""
@@ -79,6 +87,34 @@ class Trainer:
         lo = self.rank * per
         return [t[lo:lo + per] for t in tensors], lo
 
+    def _local(self, s, r, u, eps, row_offset, eps_offset):
+        """zero-grad + local loss + backward (this rank's shard)."""
+        B, S = s.shape
+        self.opt.zero_grad()
+        loss, rec, kld = self.loss_fn(self.model, s, r, u, beta=self.beta, n_neg=self.n_neg, eps=eps,
+                                      row_offset=row_offset, inv_count=1.0 / (B * S * self.world),
+                                      eps_offset=eps_offset, mask_seed=self.global_step)
+        loss.backward()
+        return loss.detach(), rec.detach(), kld.detach()
+
+    def _capture(self, s, r, u, row_offset):
+        B = s.shape[0]
+        Z = self.model.latent_size
+        st = dict(s=s.clone(), r=r.clone(), u=u.clone(), eps=torch.zeros(B, Z, dtype=torch.float32, device=s.device),
+                  row_offset=row_offset)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up: scratch buffers, bf16 table copies, kernel attributes
+            for _ in range(2):
+                self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
+        self._graph, self._static = graph, st
+
     def step(self, s, r, u, eps=None, global_batch=None, row_offset=0):
         """s, r, u: THIS rank's shard.  Returns (loss, recLoss, KLD) as device scalars of the GLOBAL batch
         (after a 3-float all-reduce when world_size > 1); nothing is synchronised with the host."""
@@ -86,17 +122,35 @@ class Trainer:
         W = self.world
         gb = global_batch if global_batch is not None else B * W
         Z = self.model.latent_size
-        self.opt.zero_grad()
-        loss, rec, kld = self.loss_fn(self.model, s, r, u, beta=self.beta, n_neg=self.n_neg, eps=eps,
-                                      row_offset=row_offset, inv_count=1.0 / (B * S * W),
-                                      eps_offset=(self.global_step * gb + row_offset) * Z,
-                                      mask_seed=self.global_step)
-        loss.backward()
+        eps_offset = (self.global_step * gb + row_offset) * Z
+        if self.capture_graph:
+            if self._graph is None:
+                try:
+                    self._capture(s, r, u, row_offset)
+                except Exception as e:  # capture is an optimisation: fall back to eager launches
+                    import warnings
+                    warnings.warn(f"hipGraph capture failed ({e}); running eagerly")
+                    torch.cuda.synchronize()
+                    self.capture_graph, self._graph = False, None
+        if self.capture_graph and self._graph is not None and tuple(s.shape) == tuple(self._static["s"].shape) \
+                and row_offset == self._static["row_offset"]:
+            st = self._static
+            st["s"].copy_(s)
+            st["r"].copy_(r)
+            st["u"].copy_(u)
+            if eps is None:
+                ops.philox_normal_(st["eps"], seed=self.model.rng_seed, offset=eps_offset)
+            else:
+                st["eps"].copy_(eps)
+            self._graph.replay()
+            loss, rec, kld = st["out"]
+        else:
+            loss, rec, kld = self._local(s, r, u, eps, row_offset, eps_offset)
         if W > 1:
             self.dist.all_reduce(self.opt.grad, group=self.pg)  # SUM: one collective per step
-            stats = torch.stack([loss.detach(), rec.detach(), kld.detach()])
+            stats = torch.stack([loss, rec, kld])
             self.dist.all_reduce(stats, group=self.pg)
             loss, rec, kld = stats[0], stats[1], stats[2]
         self.opt.step()
         self.global_step += 1
-        return loss.detach(), rec.detach(), kld.detach()
+        return loss, rec, kld

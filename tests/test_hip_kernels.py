@@ -324,3 +324,47 @@ def test_bad_arguments_are_rejected_before_launch(ops):
         ops.catalog_ce_raw(rx, E, torch.zeros(8, dtype=torch.long, device=DEV))
     with pytest.raises(RuntimeError):
         ops.linear_fwd_raw(rnd(4, 8).to(DEV), rnd(3, 9).to(DEV), None, 0)
+
+
+# ----------------------------------------------------------------- BASELINE.json full catalog size
+@pytest.mark.parametrize("prec_name", ["f32", "bf16"])
+def test_full_size_catalog_properties(ops, prec_name):
+    """N = 1M, D = 128 (the north-star table) with a small row count: size-independent properties.
+      * lse / nll / gradient direction agree with a chunked dense computation done by torch ON THE DEVICE
+        (fp64 accumulation of fp32 logits) - an independent path through the same data;
+      * sum_n softmax_n = 1  <=>  dx + E[target] = sum_n p_n E_n has norm <= max ||E_n|| = 1;
+      * greedy decode is idempotent on table rows: argmax_n <E_i, E_n> = i (unit-norm, distinct rows).
+    """
+    from pivotcvae_amd._hip import PREC_NAMES
+    N, D, R = 1_000_000, 128, 96
+    g = torch.Generator(device=DEV).manual_seed(5)
+    E = torch.rand(N, D, device=DEV, generator=g) * 2 - 1
+    E = E / E.norm(dim=1, keepdim=True)
+    rx = (torch.rand(R, D, device=DEV, generator=g) * 2 - 1) * 1.5
+    tgt = torch.randint(0, N, (R,), device=DEV, generator=g)
+    table = ops.CatalogTable(E)
+    nll, lse, dx = ops.catalog_ce_raw(rx, table, tgt, prec=PREC_NAMES[prec_name])
+    # chunked dense reference on the device
+    m = torch.full((R,), -float("inf"), device=DEV, dtype=torch.float64)
+    ssum = torch.zeros(R, device=DEV, dtype=torch.float64)
+    num = torch.zeros(R, D, device=DEV, dtype=torch.float64)
+    for c0 in range(0, N, 125_000):
+        lg = (rx @ E[c0:c0 + 125_000].t()).double()
+        mn = torch.maximum(m, lg.max(1)[0])
+        sc = torch.exp(m - mn)
+        pe = torch.exp(lg - mn[:, None])
+        ssum = ssum * sc + pe.sum(1)
+        num = num * sc[:, None] + pe @ E[c0:c0 + 125_000].double()
+        m = mn
+    want_lse = m + torch.log(ssum)
+    zt = (rx.double() * E[tgt].double()).sum(1)
+    want_dx = num / ssum[:, None] - E[tgt].double()
+    tol = dict(f32=(2e-6, 2e-5), bf16=(2e-3, 2e-2))[prec_name]
+    torch.testing.assert_close(lse.double(), want_lse, rtol=tol[0], atol=tol[0] * 10)
+    torch.testing.assert_close(nll.double(), want_lse - zt, rtol=tol[0], atol=max(tol[0] * 10, 2e-5) if prec_name == "f32" else 3e-2)
+    assert (dx.double() - want_dx).abs().max() < tol[1] * want_dx.abs().max()
+    assert float((dx + E[tgt] if prec_name == "f32" else dx + E[tgt].to(torch.bfloat16).float()).norm(dim=1).max()) <= 1.0 + 1e-3
+    if prec_name == "f32":
+        pick = torch.randint(0, N, (64,), device=DEV, generator=g)
+        idx = ops.catalog_argmax(E[pick].contiguous(), table)
+        assert torch.equal(idx, pick)
