@@ -35,6 +35,7 @@ extern "C" {
 
 #define PCVAE_ACT_NONE 0
 #define PCVAE_ACT_LEAKY 1   /* LeakyReLU(0.01): models/cvae.py:43 */
+#define PCVAE_ACT_RELU 2    /* F.relu of the response model: env/response_model.py:85 (forward only) */
 
 /* catalog precision modes (arithmetic the [R,D]x[D,N] contraction is computed in) */
 #define PCVAE_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact k-ordered fmaf chain (bit-exact ids) */
@@ -66,6 +67,14 @@ int pcvae_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, i
 /* out[r, c] = x[r, c] * scale_host * (scale_dev ? *scale_dev : 1)   (chain rule through 'mean') */
 int pcvae_scale_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int cols,
                      const float* scale_dev, float scale_host, pcvae_stream_t stream);
+
+/* ---- in-loop evaluation against the response model (train_generative.py:169-195, env/response_model.py:76-87) ----
+ * normalize_rows : x[r, :] /= max(||x[r, :]||_2, 1e-12) in place (F.normalize of the WHOLE concatenated slate vector)
+ * click_stats    : nc[b] = sum_s sigmoid(logits[b, s]);  out[0..2] = (min_b nc, mean_b nc, max_b nc)
+ * philox_randint : out[i] = Philox(seed, offset + i) mod hi  (sample_users: uniform user ids, env/response_model.py:10-13) */
+int pcvae_normalize_rows(float* x, int64_t ldx, int64_t rows, int cols, pcvae_stream_t stream);
+int pcvae_click_stats(const float* logits, int64_t B, int S, float* nc, float* out3, pcvae_stream_t stream);
+int pcvae_philox_randint(int64_t* out, int64_t n, int64_t hi, uint64_t seed, uint64_t offset, pcvae_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K3  MLP layers (addmm + leaky_relu)       models/pivotcvae.py:167-173, 205-210, 215-220, 232-239
@@ -165,6 +174,12 @@ int pcvae_candidate_scores(const float* rx, int64_t R, const float* E, int64_t N
                            int Cn, float* p, pcvae_stream_t stream);
 int pcvae_candidate_scores_bwd(const float* dp, int64_t R, const float* E, int64_t N, int D, const int64_t* cand,
                                int Cn, float* drx, pcvae_stream_t stream);
+
+/* dense softmax cross-entropy over a small class axis (candidate sets, Cn <= a few thousand)
+ *                                                       train_generative.py:56 (lossFun(pred, sampleTargets))
+ *     nll[r] = logsumexp_c p[r, c] - p[r, target[r]] ;  dp[r, c] = softmax(p[r, :])_c - [c == target[r]]  (optional) */
+int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, const int64_t* target, float* nll, float* dp,
+                   int64_t lddp, pcvae_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8  Adam over one flat fp32 buffer                    train_generative.py:103,134

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PCVAE_LIB: load an alternative build of the same ABI (kernel A/B experiments, tools/bench_catalog.py)
 LIB_PATH = os.environ.get("PCVAE_LIB") or os.path.join(_HERE, "lib", "libpcvae_hip.so")
 
-ACT_NONE, ACT_LEAKY = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
@@ -28,6 +28,9 @@ SIGNATURES = {
     "pcvae_condition": [_P, _L, _I, _P, _L, _P],
     "pcvae_copy2d": [_P, _L, _P, _L, _L, _I, _P],
     "pcvae_scale_rows": [_P, _L, _P, _L, _L, _I, _P, _F, _P],
+    "pcvae_normalize_rows": [_P, _L, _L, _I, _P],
+    "pcvae_click_stats": [_P, _L, _I, _P, _P, _P],
+    "pcvae_philox_randint": [_P, _L, _L, _U64, _U64, _P],
     "pcvae_linear_fwd": [_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _P],
     "pcvae_linear_bwd_input": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P],
     "pcvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _P],
@@ -45,6 +48,7 @@ SIGNATURES = {
     "pcvae_split_bf16": [_P, _L, _P, _P, _P],
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_candidate_scores_bwd": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
+    "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],
     "pcvae_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
 }
 _RESTYPES = {"pcvae_last_error": _c.c_char_p, "pcvae_catalog_ws_bytes": _SZ}

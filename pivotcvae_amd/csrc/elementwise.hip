@@ -331,6 +331,74 @@ extern "C" int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcv
 }
 
 // =============================================================================================
+// in-loop evaluation helpers (response model)
+// =============================================================================================
+__global__ void __launch_bounds__(256) normalize_rows_kernel(float* __restrict__ x, int64_t ldx, int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per row
+    if (r >= rows) return;
+    float ss = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = x[r * ldx + c]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = lane; c < cols; c += 64) x[r * ldx + c] *= inv;
+}
+
+extern "C" int pcvae_normalize_rows(float* x, int64_t ldx, int64_t rows, int cols, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(cols > 0 && ldx >= cols && rows >= 0 && (x || rows == 0), "normalize_rows: bad arguments");
+    if (rows == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, ldx, rows, cols);
+    return check_launch("normalize_rows");
+}
+
+__global__ void __launch_bounds__(1024) click_stats_kernel(const float* __restrict__ logits, int64_t B, int S,
+                                                           float* __restrict__ nc, float* __restrict__ out3) {
+    __shared__ float smin[16], smax[16];
+    float mn = INFINITY, mx = -INFINITY, sum = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc += 1.f / (1.f + expf(-logits[b * S + s]));
+        if (nc) nc[b] = acc;
+        mn = fminf(mn, acc); mx = fmaxf(mx, acc); sum += acc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    const float tot = block_sum_1024(sum);  // contains a __syncthreads()
+    if (threadIdx.x == 0) {
+        float a = INFINITY, b = -INFINITY;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a = fminf(a, smin[w]); b = fmaxf(b, smax[w]); }
+        out3[0] = a; out3[1] = tot / (float)B; out3[2] = b;
+    }
+}
+
+extern "C" int pcvae_click_stats(const float* logits, int64_t B, int S, float* nc, float* out3, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(logits && out3 && B > 0 && S > 0, "click_stats: bad arguments");
+    hipLaunchKernelGGL(click_stats_kernel, dim3(1), dim3(1024), 0, as_stream(stream), logits, B, S, nc, out3);
+    return check_launch("click_stats");
+}
+
+__global__ void philox_randint_kernel(int64_t* __restrict__ out, int64_t n, uint64_t hi, uint64_t seed, uint64_t offset) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t e = offset + (uint64_t)i, ctr = e >> 1;
+        const Philox4 p = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0x55534552u /*"USER"*/, 0u, (uint32_t)seed,
+                                        (uint32_t)(seed >> 32));
+        const uint64_t u = (e & 1) ? (((uint64_t)p.z << 32) | p.w) : (((uint64_t)p.x << 32) | p.y);
+        out[i] = (int64_t)(u % hi);  // 64 random bits: modulo bias < hi / 2^64
+    }
+}
+
+extern "C" int pcvae_philox_randint(int64_t* out, int64_t n, int64_t hi, uint64_t seed, uint64_t offset,
+                                    pcvae_stream_t stream) {
+    PCVAE_REQUIRE(n >= 0 && hi > 0 && (out || n == 0), "philox_randint: bad arguments");
+    if (n == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 1024);
+    hipLaunchKernelGGL(philox_randint_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, n, (uint64_t)hi,
+                       seed, offset);
+    return check_launch("philox_randint");
+}
+
+// =============================================================================================
 // fp32 -> bf16 hi/lo split (round-to-nearest-even, NaN preserved)
 // =============================================================================================
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
@@ -414,6 +482,42 @@ extern "C" int pcvae_candidate_scores_bwd(const float* dp, int64_t R, const floa
     hipLaunchKernelGGL(candidate_scores_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dp, R, E,
                        D, cand, Cn, drx);
     return check_launch("candidate_scores_bwd");
+}
+
+// =============================================================================================
+// dense softmax-CE over a small class axis: one wave per row, two passes over the row (max, then sum + gradient)
+// =============================================================================================
+__global__ void __launch_bounds__(256) dense_ce_kernel(const float* __restrict__ p, int64_t ldp, int64_t R, int C,
+                                                       const int64_t* __restrict__ target, float* __restrict__ nll,
+                                                       float* __restrict__ dp, int64_t lddp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float* row = p + r * ldp;
+    float m = -INFINITY;
+    for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(row[c] - m);
+    sum = wave_sum(sum);
+    const int64_t t = target[r];
+    const bool ok = t >= 0 && t < C;
+    const float lse = m + logf(sum);
+    if (lane == 0) nll[r] = ok ? lse - row[t] : NAN;
+    if (dp) {
+        const float inv = 1.f / sum;
+        for (int c = lane; c < C; c += 64) dp[r * lddp + c] = expf(row[c] - m) * inv - (c == t ? 1.f : 0.f);
+    }
+}
+
+extern "C" int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, const int64_t* target, float* nll, float* dp,
+                              int64_t lddp, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(p && target && nll && C > 0 && ldp >= C && (!dp || lddp >= C) && R >= 0, "dense_ce: bad arguments");
+    if (R == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(dense_ce_kernel, dim3((unsigned)cdiv(R, 4)), dim3(256), 0, as_stream(stream), p, ldp, R, C, target,
+                       nll, dp, lddp);
+    return check_launch("dense_ce");
 }
 
 // =============================================================================================

@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
         if (EPI == EPI_FWD) {
             v += bias;
             if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
+            else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
             p.C[m * p.ldc + n] = v;
         } else if (EPI == EPI_DX) {
             if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
@@ -145,7 +146,7 @@ extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int
     PCVAE_REQUIRE(X && W && Y, "linear_fwd: null pointer");
     PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, "linear_fwd: bad shape M=%lld N=%lld K=%lld",
                   (long long)M, (long long)N, (long long)K);
-    PCVAE_REQUIRE(act == PCVAE_ACT_NONE || act == PCVAE_ACT_LEAKY, "linear_fwd: unknown activation %d", act);
+    PCVAE_REQUIRE(act == PCVAE_ACT_NONE || act == PCVAE_ACT_LEAKY || act == PCVAE_ACT_RELU, "linear_fwd: unknown activation %d", act);
     if (M == 0) return PCVAE_OK;
     PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_fwd: M too large");
     GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, nullptr, 0, act, 0};

@@ -7,7 +7,8 @@ hand-written (they call the backward kernels); nothing here falls back to eager 
 import torch
 
 from . import _hip
-from ._hip import ACT_LEAKY, ACT_NONE, PREC_BF16, PREC_BF16X3, PREC_F32, check, lib, ptr, require_device, stream
+from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, PREC_BF16, PREC_BF16X3, PREC_F32, check, lib, ptr, require_device,
+                   stream)
 
 F32 = torch.float32
 
@@ -479,6 +480,67 @@ class _CandidateScores(torch.autograd.Function):
 def candidate_scores(rx, E, cand):
     """p[r, c] = <E[cand[r, c]], rx_r> (models/pivotcvae.py:265-271)."""
     return _CandidateScores.apply(rx, E, cand)
+
+
+# ------------------------------------------------------- in-loop evaluation (response model)
+def normalize_rows_(x):
+    """x[r, :] /= max(||x[r, :]||, 1e-12) in place (F.normalize(p=2, dim=1))."""
+    require_device(x)
+    check(lib().pcvae_normalize_rows(ptr(x, F32), _ld(x), x.shape[0], x.shape[1], stream()), "normalize_rows")
+    return x
+
+
+def click_stats(logits):
+    """-> (nc [B] = sum_s sigmoid(logits), stats [3] = (min, mean, max) of nc)   (train_generative.py:185-190)."""
+    require_device(logits)
+    logits = _c2d(logits).contiguous()
+    B, S = logits.shape
+    nc = torch.empty(B, dtype=F32, device=logits.device)
+    out = torch.empty(3, dtype=F32, device=logits.device)
+    check(lib().pcvae_click_stats(ptr(logits, F32), B, S, ptr(nc, F32), ptr(out, F32), stream()), "click_stats")
+    return nc, out
+
+
+def philox_randint(n, hi, device, seed=0, offset=0):
+    """n uniform integers in [0, hi) from the Philox stream (seed, offset) -> int64 [n]."""
+    out = torch.empty(int(n), dtype=torch.int64, device=device)
+    require_device(out)
+    check(lib().pcvae_philox_randint(ptr(out), out.numel(), int(hi), int(seed), int(offset), stream()), "philox_randint")
+    return out
+
+
+class _DenseCE(torch.autograd.Function):
+    """mean softmax cross-entropy over a small dense class axis (the candidate path), fused loss + gradient."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        require_device(p, target)
+        p = _c2d(p)
+        R, C = p.shape
+        target = target.reshape(-1).to(torch.int64).contiguous()
+        nll = torch.empty(R, dtype=F32, device=p.device)
+        dp = torch.empty(R, C, dtype=F32, device=p.device) if p.requires_grad else None
+        check(lib().pcvae_dense_ce(ptr(p, F32), _ld(p), R, C, ptr(target), ptr(nll, F32), ptr(dp), C, stream()), "dense_ce")
+        out = torch.empty((), dtype=F32, device=p.device)
+        check(lib().pcvae_sum(ptr(nll, F32), R, 1.0 / R, ptr(out, F32), stream()), "sum")
+        ctx.inv = 1.0 / R
+        if dp is not None:
+            ctx.save_for_backward(dp)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        g = g.contiguous()
+        out = torch.empty_like(dp)
+        check(lib().pcvae_scale_rows(ptr(dp, F32), _ld(dp), ptr(out, F32), _ld(out), dp.shape[0], dp.shape[1], ptr(g, F32),
+                                     ctx.inv, stream()), "scale_rows")
+        return out, None
+
+
+def dense_ce(p, target):
+    """nn.CrossEntropyLoss()(p, target) for a small dense [R, C] logits tensor."""
+    return _DenseCE.apply(p, target)
 
 
 # ------------------------------------------------------------------------------------------- K8

@@ -43,11 +43,38 @@ def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None):
         cand = torch.as_tensor(np.asarray(batch_data["sample_candidates"]), dtype=torch.long).to(model.device)
         tgt = torch.as_tensor(np.asarray(batch_data["sample_targets"]), dtype=torch.long).to(model.device)
         pred, _rx, _z, _emb, mu, logvar = model.forward(slates, targets, candidates=cand, u=users, eps=eps)
-        recLoss = lossFun(pred, tgt.reshape(-1))
+        # the reference passes nn.CrossEntropyLoss(); that case runs our dense-CE kernel, anything else is called as given
+        plain_ce = isinstance(lossFun, torch.nn.CrossEntropyLoss) and lossFun.weight is None and \
+            lossFun.reduction == "mean" and lossFun.ignore_index == -100 and getattr(lossFun, "label_smoothing", 0.0) == 0.0
+        recLoss = ops.dense_ce(pred, tgt.reshape(-1)) if plain_ce else lossFun(pred, tgt.reshape(-1))
         KLD = ops.kld(mu, logvar, pMu, pLogvar)
         return recLoss + beta * KLD, recLoss, KLD
     N = model.docEmbed.weight.shape[0]
     return model.loss(slates, targets, users, beta, n_neg=None if n_neg == N else n_neg, eps=eps)
+
+
+@torch.no_grad()
+def recommendation_test(model, resp_model, bs, n_test_trial=100, seed=0):
+    """The in-loop evaluation of reference train_generative.py:169-195, entirely on the device.
+
+    For each of ``n_test_trial`` trials: sample ``bs`` users, and for the five contexts "i+1 desired clicks"
+    (i = 0..4) generate greedy slates with ``model.recommend`` and score them with the response model; the expected
+    number of clicks of a slate is sum_s sigmoid(logit).  Returns a [5, 3] tensor of (min, mean, max) expected clicks
+    averaged over the trials - the three numbers the reference logs per context - without any host synchronisation
+    inside the loop (the reference does 15 ``.cpu()`` copies per trial)."""
+    from .env.response_model import sample_users
+    device = model.docEmbed.weight.device
+    acc = torch.zeros(5, 3, dtype=torch.float32, device=device)
+    for k in range(n_test_trial):
+        users = sample_users(resp_model, bs, seed=seed, offset=k * bs)
+        context = torch.zeros(bs, 5, dtype=torch.float32, device=device)
+        for i in range(5):
+            context[:, i] = 1
+            slates, _mu = model.recommend(context, users, return_item=True)
+            logits = resp_model(slates.view(bs, -1), users)
+            _nc, stats = ops.click_stats(logits)
+            acc[i] += stats
+    return acc / n_test_trial
 
 
 class Trainer:

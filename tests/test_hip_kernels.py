@@ -368,3 +368,17 @@ def test_full_size_catalog_properties(ops, prec_name):
         pick = torch.randint(0, N, (64,), device=DEV, generator=g)
         idx = ops.catalog_argmax(E[pick].contiguous(), table)
         assert torch.equal(idx, pick)
+
+
+@pytest.mark.parametrize("R,C", [(35, 13), (300, 1000), (5, 64), (129, 65)])
+def test_dense_ce(ops, R, C):
+    p = rnd(R, C, seed=1, scale=4.0)
+    tgt = torch.randint(0, C, (R,), generator=torch.Generator().manual_seed(2))
+    pr = p.clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(pr, tgt)
+    (want * 0.7).backward()
+    pd = p.to(DEV).requires_grad_(True)
+    got = ops.dense_ce(pd, tgt.to(DEV))
+    (got * 0.7).backward()
+    np.testing.assert_allclose(got.item(), want.item(), rtol=2e-6)
+    torch.testing.assert_close(pd.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-8)

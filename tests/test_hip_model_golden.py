@@ -171,3 +171,58 @@ def test_graph_captured_step_equals_eager_step():
     assert outs[0][0][0] != outs[0][0][1]  # eps (and the parameters) really changed from step to step
     for k in outs[0][1]:
         close(outs[1][1][k], outs[0][1][k], rtol=1e-4, atol=2e-6)
+
+
+def test_g7_response_model_and_click_stats():
+    """UserResponseModel_MLP.forward against the golden logits of the reference; sigmoid-sum statistics."""
+    from pivotcvae_amd import ops
+    from pivotcvae_amd.env.response_model import UserResponseModel_MLP, sample_users
+    g = load("response_mlp")
+    m = g.meta
+    rm = UserResponseModel_MLP(m["N"] - 1, m["NU"] - 1, m["D"], m["S"], [(m["S"] + 1) * m["D"], m["H"], m["H"], m["S"]],
+                               DEV, False)
+    rm.load_state_dict(g.sd)
+    rm.to(DEV)
+    logits = rm(dev(g.t("s")), dev(g.t("u")))
+    close(logits, g.t("logits"), rtol=1e-5, atol=1e-5)
+    nc, stats = ops.click_stats(logits)
+    want = torch.sigmoid(g.t("logits")).sum(1)
+    close(nc, want, rtol=1e-5, atol=1e-6)
+    close(stats, torch.stack([want.min(), want.mean(), want.max()]), rtol=1e-5, atol=1e-6)
+    users = sample_users(rm, 20000, seed=3).cpu()
+    assert users.min() >= 0 and users.max() <= m["NU"] - 1
+    freq = torch.bincount(users, minlength=m["NU"]).float() / 20000
+    assert (freq - 1.0 / m["NU"]).abs().max() < 0.01
+    assert torch.equal(users, sample_users(rm, 20000, seed=3).cpu())
+
+
+def test_recommendation_test_matches_oracle_composition():
+    """The device-side in-loop evaluation == oracle recommend + oracle response model on the same users and eps."""
+    from oracle import pivotcvae_oracle as orc
+    from pivotcvae_amd.env.response_model import UserResponseModel_MLP, sample_users
+    from pivotcvae_amd import ops
+    g = load("pivotcvae_gt_pi_user")
+    gm = load("response_mlp")
+    model = build_from_golden(g)
+    m = gm.meta
+    rm = UserResponseModel_MLP(m["N"] - 1, m["NU"] - 1, m["D"], m["S"], [(m["S"] + 1) * m["D"], m["H"], m["H"], m["S"]],
+                               DEV, False)
+    rm.load_state_dict(gm.sd)
+    rm.to(DEV)
+    bs = 16
+    users = sample_users(rm, bs, seed=1)
+    ctx = torch.zeros(bs, 5, device=DEV)
+    ctx[:, :2] = 1
+    eps = torch.randn(bs, g.meta["Z"], generator=torch.Generator().manual_seed(0))
+    items, _ = model.recommend(ctx, users, return_item=True, eps=dev(eps))
+    _nc, stats = ops.click_stats(rm(items.view(bs, -1), users))
+    o = orc.recommend(g.sd, g.cfg(), ctx.cpu(), users.cpu().reshape(-1, 1), eps)
+    want = torch.sigmoid(orc.response_mlp(gm.sd, o["items"].reshape(bs, -1), users.cpu())).sum(1)
+    assert torch.equal(items.cpu(), o["items"])
+    close(stats, torch.stack([want.min(), want.mean(), want.max()]), rtol=1e-5, atol=1e-6)
+    # and the full loop runs (Philox users / eps inside): shapes and ranges only
+    from pivotcvae_amd.train_generative import recommendation_test
+    out = recommendation_test(model, rm, bs=32, n_test_trial=3, seed=5)
+    assert tuple(out.shape) == (5, 3)
+    o3 = out.cpu()
+    assert torch.all(o3[:, 0] <= o3[:, 1]) and torch.all(o3[:, 1] <= o3[:, 2]) and torch.all(o3 >= 0) and torch.all(o3 <= 5)
