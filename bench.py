@@ -71,6 +71,31 @@ def synthetic_batch(cfg, B, device, seed=1):
     return s, r, u
 
 
+def gather_roofline(model, cfg, device):
+    """K1 on its own: the (S+2)*B embedding rows of one step, cold caches, against the 8 TB/s HBM peak."""
+    from pivotcvae_amd import ops
+    N, S, D, B = cfg["N"], cfg["S"], cfg["D"], cfg["B"]
+    g = torch.Generator(device=device).manual_seed(3)
+    idx = torch.randint(0, N, (B * (S + 2),), device=device, generator=g)
+    out = torch.empty(idx.numel(), D, device=device)
+    flush = torch.empty(128 * 1024 * 1024, device=device)  # 512 MB > the 256 MB Infinity Cache
+    ts = []
+    for it in range(13):
+        flush.fill_(float(it))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.gather_rows(model.docEmbed.weight, idx, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        if it >= 3:
+            ts.append(e0.elapsed_time(e1))
+    nbytes = idx.numel() * (2 * D * 4 + 8)  # rows read + rows written + int64 indices (SURVEY.md 8d)
+    ms = sum(ts) / len(ts)
+    return {"kernel": "gather_rows_vec4_kernel", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 8e12, "bytes_per_launch": nbytes, "us_per_launch": ms * 1e3,
+            "rows": idx.numel(), "cache": "cold (512 MB written between launches)"}
+
+
 def cpu_baseline_and_parity(model, st, cfg, dtype):
     """Oracle train step on the host cores on a bounded sample + HIP-vs-oracle ELBO on that same sample."""
     from oracle import pivotcvae_oracle as orc
@@ -238,6 +263,7 @@ def main():
         base, parity = cpu_baseline_and_parity(model, st, cfg, args.dtype)
         out["cpu_baseline"] = base
         out["parity"] = parity
+        out["gather_roofline"] = gather_roofline(model, cfg, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

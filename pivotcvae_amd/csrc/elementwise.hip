@@ -10,38 +10,45 @@ using namespace pcvae;
 // K1: row gather.  One 16-byte chunk per lane; LPR lanes cover one row, 64/LPR rows per
 // wave-instruction, UNROLL row groups in flight per wave so the dependent idx->row loads overlap.
 // =============================================================================================
-template <int UNROLL>
-__global__ void __launch_bounds__(256) gather_rows_vec4_kernel(const float4* __restrict__ table, int chunks, int lpr,
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: what the nontemporal builtins accept
+#ifndef GATHER_UNROLL
+#define GATHER_UNROLL 16  // rows in flight per lane group: 16 measured best of {2,4,8,16} (tools/bench_gather.py)
+#endif
+#ifndef GATHER_MAXBLOCKS
+#define GATHER_MAXBLOCKS (256 * 8)
+#endif
+
+template <int UNROLL, bool CONTIG>
+__global__ void __launch_bounds__(256) gather_rows_vec4_kernel(const f32x4* __restrict__ table, int chunks, int lpr,
                                                                const int64_t* __restrict__ idx, int64_t n_idx,
                                                                int group, float* __restrict__ out, int64_t out_ld,
                                                                int D) {
     const int lane = threadIdx.x & 63;
     const int rows_per_wave = 64 / lpr;
-    const int sub = lane / lpr;    // which row of the wave's row group
+    const int sub = lane / lpr;     // which row of the wave's row group
     const int chunk0 = lane % lpr;  // first 16 B chunk of the row handled by this lane
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t n_groups = (n_idx + rows_per_wave - 1) / rows_per_wave;
     for (int64_t g0 = wave * UNROLL; g0 < n_groups; g0 += n_waves * UNROLL) {
         int64_t src[UNROLL];
-        int64_t i_[UNROLL];
+        int64_t dst[UNROLL];  // float offset of the destination row
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             const int64_t i = (g0 + u) * rows_per_wave + sub;
-            i_[u] = i;
-            src[u] = (g0 + u < n_groups && i < n_idx) ? idx[i] : -1;
+            const bool ok = g0 + u < n_groups && i < n_idx;
+            src[u] = ok ? idx[i] : -1;
+            // CONTIG: out_ld == group * D, i.e. output row i starts at i * D (no 64-bit division on the hot path)
+            dst[u] = CONTIG ? i * (int64_t)D : (i / group) * out_ld + (i % group) * (int64_t)D;
         }
         for (int c = chunk0; c < chunks; c += lpr) {
-            float4 v[UNROLL];
+            f32x4 v[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                if (src[u] >= 0) v[u] = table[src[u] * chunks + c];
+                if (src[u] >= 0) v[u] = __builtin_nontemporal_load(&table[src[u] * chunks + c]);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                if (src[u] >= 0) {
-                    float* o = out + (i_[u] / group) * out_ld + (i_[u] % group) * (int64_t)D + c * 4;
-                    *reinterpret_cast<float4*>(o) = v[u];
-                }
+                if (src[u] >= 0) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(out + dst[u] + c * 4));
         }
     }
 }
@@ -75,10 +82,13 @@ extern "C" int pcvae_gather_rows(const float* table, int64_t n_rows, int D, cons
         while (lpr < chunks && lpr < 64) lpr <<= 1;
         const int rows_per_wave = 64 / lpr;
         const int64_t n_groups = cdiv(n_idx, rows_per_wave);
-        const int64_t blocks = std::min<int64_t>(cdiv(cdiv(n_groups, 4), 4), 256 * 8);
-        hipLaunchKernelGGL(gather_rows_vec4_kernel<4>, dim3((unsigned)std::max<int64_t>(blocks, 1)), dim3(256), 0,
-                           as_stream(stream), reinterpret_cast<const float4*>(table), chunks, lpr, idx, n_idx, group,
-                           out, out_ld, D);
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(cdiv(cdiv(n_groups, GATHER_UNROLL), 4), GATHER_MAXBLOCKS));
+        if (out_ld == (int64_t)group * D)
+            hipLaunchKernelGGL((gather_rows_vec4_kernel<GATHER_UNROLL, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                               reinterpret_cast<const f32x4*>(table), chunks, lpr, idx, n_idx, group, out, out_ld, D);
+        else
+            hipLaunchKernelGGL((gather_rows_vec4_kernel<GATHER_UNROLL, false>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                               reinterpret_cast<const f32x4*>(table), chunks, lpr, idx, n_idx, group, out, out_ld, D);
     } else {
         const int64_t blocks = std::min<int64_t>(cdiv(n_idx, 4), 256 * 8);
         hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), table,
