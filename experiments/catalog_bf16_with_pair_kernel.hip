@@ -1,0 +1,966 @@
+// K5 on the bf16 matrix cores: fused full-catalog softmax cross-entropy (loss + gradient direction in ONE
+// streaming pass) with v_mfma_f32_32x32x16_bf16, fp32 accumulate (gfx950).
+//
+// Same algorithm as catalog_f32.hip (flash-attention with K = V = E, split over catalog ranges, merged by a
+// deterministic log-sum-exp kernel) re-tiled for the 16x faster bf16 pipe, where the softmax VALU work and
+// the LDS / L2 feed - not the MFMA - are the things to budget:
+//
+//   * workgroup = 8 waves = 256 rows of rx; wave w owns rows 32w..32w+31 for the whole catalog range and
+//     keeps them in registers as bf16 B fragments, pre-multiplied by log2(e) so exp is a bare v_exp_f32;
+//     two waves share a SIMD, so one wave's softmax VALU runs under its partner's MFMAs;
+//   * the bf16 copy of E streams through LDS by global_load_lds_dwordx4 (no staging VGPRs, asynchronous); the
+//     LDS image keeps 2*D-byte rows and XOR-swizzles the 16-byte chunks with ((row&3)<<2 | (row>>2)&3) on the
+//     SOURCE address, which makes both the row reads (ds_read_b128, logits A operand) and the transposed reads
+//     (ds_read_b64_tr_b16, E^T A operand of the gradient chain) bank-conflict free on one image
+//     (tools/lds_bank_check.py; measured SQ_LDS_BANK_CONFLICT = 0);
+//   * logits are produced "swapped" (C[n][r]): a lane holds 16 logits of one row, exp / sum are lane-local, and
+//     the exp2 values converted pairwise to bf16 are, in place, the B operand of U^T[d][r] += E^T[d][n] P[n][r].
+//
+// Three kernels:
+//   catalog_row_bound_kernel          per 256-row block: is ||rx|| * max||E|| * log2(e) <= 90 for every row?
+//   catalog_ce_bf16_d128_fast_kernel  D = 128, blocks that pass: NO running max (every exp2(logit) is a normal fp32
+//                                     number, sums of 10^7 of them stay < 2^114); 4-deep ring of 64-item LDS
+//                                     buffers requested three chunks ahead, counted s_waitcnt vmcnt(4) + raw
+//                                     s_barrier at the seams, all LDS offsets immediates, transposed reads
+//                                     through inline asm (the builtin makes hipcc drain every in-flight LDS-DMA)
+//   catalog_ce_bf16_kernel<D>         D = 64 / 128 / 256, any norms, masks, loss-only: lazy running max (raised
+//                                     only when a tile exceeds it by 2^8), 128-item double-buffered chunks
+//
+// Numerics: bf16 inputs (round-to-nearest-even), fp32 accumulation, softmax statistics in fp32.  Against
+// the fp32 reference the per-logit error is ~2^-9 relative per product and zero-mean, so the ELBO terms of
+// a batch agree to ~1e-6 while individual gradients agree to ~1e-3 (tests/test_hip_bf16.py).
+#include "catalog_plan.h"
+
+using namespace pcvae;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+enum { MASK_NONE = 0, MASK_PHILOX = 1, MASK_BYTES = 2 };
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kRaiseThr = 8.0f;  // raise the running max when a tile exceeds it by more than 2^8
+constexpr int BN = 128;            // catalog items per LDS chunk
+constexpr int ROWS_WG = 256;
+
+struct CatParamsB {
+    const float* rx;        // [R, D] fp32
+    const uint16_t* E;      // [N, D] bf16 bits
+    const int64_t* target;  // [R]
+    const uint8_t* keep;    // [R, N] or null
+    uint32_t keep_thresh;
+    uint64_t seed, row_offset;
+    int64_t R, N;
+    int nrb, nsplit, tiles_per_split, ntiles;  // tiles = 32-item subtiles; tiles_per_split % 4 == 0
+    float* pm;              // [nsplit][R] running max, log2 domain
+    float* pl;              // [nsplit][R]
+    float* pU;              // [nsplit][R][D]
+    const uint8_t* safe_flags;  // [nrb] or null: 1 = this row block needs the lazy-max kernel (large |rx|)
+    int run_if_flag;        // this launch handles the row blocks whose flag equals this value
+};
+
+template <int D>
+struct GeoB {
+    static constexpr int RB = 2 * D;          // bytes per table row
+    static constexpr int CPR = D / 8;         // 16-byte chunks per row
+    static constexpr int KS = D / 16;         // k-steps of the logits chain
+    static constexpr int NDB = D / 32;        // 32-wide d blocks of the U accumulator
+    static constexpr int CHUNK_BYTES = BN * RB;
+    static constexpr int PIECES = CHUNK_BYTES / 1024;  // 1 KiB global_load_lds pieces per chunk
+    static constexpr int ROWS_PER_PIECE = 1024 / RB;
+};
+
+// 16-byte-chunk swizzle of the LDS image (an involution on the chunk index of one row)
+template <int D>
+__device__ __forceinline__ int swz_chunk(int row, int c) {
+    if (D >= 128) return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    return c ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));  // D == 64: two rows per 256-B bank row
+}
+
+template <int D>
+__device__ __forceinline__ int lds_off(int row, int col) {  // byte offset of element (row, col) in a chunk image
+    return row * GeoB<D>::RB + (swz_chunk<D>(row, col >> 3) << 4) + ((col & 7) << 1);
+}
+
+// issue the global->LDS copy of one 128-item chunk (asynchronous; completed by the next __syncthreads)
+template <int D>
+__device__ __forceinline__ void stage_chunk(const uint16_t* __restrict__ E, int64_t N, int64_t n0, char* buf) {
+    using G = GeoB<D>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < G::PIECES / 8; ++i) {
+        const int pc = wave * (G::PIECES / 8) + i;
+        const int row = pc * G::ROWS_PER_PIECE + (lane * 16) / G::RB;   // LDS destination is lane-linear
+        const int cdst = ((lane * 16) % G::RB) >> 4;
+        const int csrc = swz_chunk<D>(row, cdst);                        // swizzle on the SOURCE address
+        int64_t n = n0 + row;
+        n = n < N ? n : N - 1;                                           // ragged tail: clamp, masked later
+        const char* src = reinterpret_cast<const char*>(E) + n * G::RB + (csrc << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + pc * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ int nloc(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+template <int D, int MASK, bool WANT_DX>
+__global__ void __launch_bounds__(512, 1) catalog_ce_bf16_kernel(CatParamsB p) {
+    using G = GeoB<D>;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* buf0 = smem;
+    char* buf1 = smem + G::CHUNK_BYTES;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / p.nrb, rb = logical % p.nrb;
+    if (p.safe_flags && p.safe_flags[rb] != p.run_if_flag) return;  // the other kernel owns this row block
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int n_chunks = (t_end - t_beg + 3) / 4;
+
+    const int64_t r = (int64_t)rb * ROWS_WG + wave * 32 + li;
+    const bool row_ok = r < p.R;
+    const int64_t rl = row_ok ? r : p.R - 1;
+
+    stage_chunk<D>(p.E, p.N, (int64_t)t_beg * 32, buf0);
+
+    // B operand of the logits chain: lane (row li, half h) holds bf16(rx[row][16s + 8h + j] * log2e), j = 0..7
+    bf16x8 xb[G::KS];
+#pragma unroll
+    for (int s = 0; s < G::KS; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h);
+        const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h + 4);
+        xb[s][0] = (__bf16)(v0.x * kLog2e); xb[s][1] = (__bf16)(v0.y * kLog2e);
+        xb[s][2] = (__bf16)(v0.z * kLog2e); xb[s][3] = (__bf16)(v0.w * kLog2e);
+        xb[s][4] = (__bf16)(v1.x * kLog2e); xb[s][5] = (__bf16)(v1.y * kLog2e);
+        xb[s][6] = (__bf16)(v1.z * kLog2e); xb[s][7] = (__bf16)(v1.w * kLog2e);
+    }
+
+    const int64_t tgt = (MASK != MASK_NONE) ? p.target[rl] : -1;
+    const uint64_t grow = p.row_offset + (uint64_t)rl;
+
+    f32x16 U[G::NDB];
+#pragma unroll
+    for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) U[b][i] = 0.f;
+    float m_run = 0.f, lsum = 0.f;
+    bool first = true;
+
+    // per-lane pieces of the LDS addresses
+    const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3;
+
+    __syncthreads();  // chunk 0 landed (the barrier drains the LDS-DMA)
+
+    for (int c = 0; c < n_chunks; ++c) {
+        const char* cur = (c & 1) ? buf1 : buf0;
+        char* nxt = (c & 1) ? buf0 : buf1;
+        const int t0 = t_beg + 4 * c;
+        if (c + 1 < n_chunks) stage_chunk<D>(p.E, p.N, (int64_t)(t0 + 4) * 32, nxt);
+        const int nsub = min(4, t_end - t0);
+
+        for (int st = 0; st < nsub; ++st) {
+            const int nb = st * 32;                      // first LDS row of this 32-item subtile
+            const int64_t n0 = (int64_t)(t0 + st) * 32;  // first catalog item of this subtile
+
+            // ---- logits (log2 domain) minus the running max: acc starts at -m
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = -m_run;
+#pragma unroll
+            for (int s = 0; s < G::KS; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + lds_off<D>(nb + li, 16 * s + 8 * h));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc, 0, 0, 0);
+            }
+
+            bool kp[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) kp[i] = true;
+            if (MASK == MASK_PHILOX) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const uint64_t nbq = (uint64_t)(n0 + 8 * qq + 4 * h);
+                    const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(nbq >> 2),
+                                                     (uint32_t)(nbq >> 34) ^ 0x4D41534Bu, (uint32_t)p.seed,
+                                                     (uint32_t)(p.seed >> 32));
+                    const uint32_t u[4] = {ph.x, ph.y, ph.z, ph.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        kp[4 * qq + j] = (u[j] < p.keep_thresh) || ((int64_t)(n0 + 8 * qq + 4 * h + j) == tgt);
+                }
+            } else if (MASK == MASK_BYTES) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t n = n0 + nloc(i, h);
+                    kp[i] = (n == tgt) || (n < p.N && p.keep[rl * p.N + n] != 0);
+                }
+            }
+            if (MASK != MASK_NONE) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] = kp[i] ? acc[i] : -m_run;  // masked-out logit is 0
+            }
+            if (n0 + 32 > p.N) {  // ragged last subtile (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (n0 + nloc(i, h) >= p.N) { acc[i] = -INFINITY; kp[i] = false; }
+            }
+
+            // ---- lazy running max, shared by the two lane halves of a row
+            float zmax = fmaxf(fmaxf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) zmax = fmaxf(fmaxf(zmax, acc[i]), acc[i + 1]);
+            zmax = fmaxf(zmax, acc[15]);
+            zmax = fmaxf(zmax, __shfl_xor(zmax, 32, 64));
+            if (first) {
+                m_run = zmax;  // m_run was 0: acc holds the raw logits
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] -= zmax;
+                first = false;
+            } else if (__any(zmax > kRaiseThr)) {
+                const float shift = zmax > kRaiseThr ? zmax : 0.f;
+                const float alpha = exp2f(-shift);
+                lsum *= alpha;
+                if (WANT_DX) {
+#pragma unroll
+                    for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) U[b][i] *= alpha;
+                }
+                m_run += shift;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] -= shift;
+            }
+
+            // ---- numerators; bf16 pairs of them are the B operand of the gradient chain
+            float pk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = __builtin_amdgcn_exp2f(acc[i]);
+                lsum += e;
+                pk[i] = (MASK == MASK_NONE || kp[i]) ? e : 0.f;
+            }
+            if (WANT_DX) {
+                bf16x8 pb[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pb[ks][j] = (__bf16)pk[8 * ks + j];
+                // U^T[d][r] += sum_n E[n][d] P[n][r]; A operand = E^T fragments by transposed LDS reads:
+                // element j of lane (d, h) is E[16ks + 8(j>>2) + 4h + (j&3)][d]
+#pragma unroll
+                for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int col = 32 * b + 16 * (grp & 1) + 4 * pp;
+                        const int rowa = nb + 16 * ks + 4 * (grp >> 1) + q;
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(cur + lds_off<D>(rowa, col)));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(cur + lds_off<D>(rowa + 8, col)));
+                        const s16x8 a16 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        U[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[ks], U[b], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();  // next chunk landed; everyone is done with `cur`
+    }
+
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (row_ok) {
+        const int64_t o = (int64_t)split * p.R + r;
+        if (h == 0) { p.pm[o] = m_run; p.pl[o] = ltot; }
+        if (WANT_DX) {
+#pragma unroll
+            for (int b = 0; b < G::NDB; ++b)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int d0 = b * 32 + 8 * qq + 4 * h;
+                    *reinterpret_cast<float4*>(p.pU + o * D + d0) =
+                        make_float4(U[b][4 * qq], U[b][4 * qq + 1], U[b][4 * qq + 2], U[b][4 * qq + 3]);
+                }
+        }
+    }
+}
+
+// =============================================================================================
+// Row bound prologue: a row whose |logit| bound  ||rx_r|| * max_n ||E_n|| * log2(e)  is <= 90 can use raw
+// exp2(logit) with NO running max at all: every term is in [2^-90, 2^90], a sum of 10^7 of them is
+// < 2^114, all normal fp32 numbers.  Row blocks with a larger bound are flagged for the lazy-max kernel.
+// =============================================================================================
+constexpr float kFastBound = 90.0f;
+
+template <int D>
+__global__ void __launch_bounds__(256) catalog_row_bound_kernel(const float* __restrict__ rx, int64_t R, float e_max_norm,
+                                                                uint8_t* __restrict__ flags) {
+    __shared__ int any_unsafe;
+    if (threadIdx.x == 0) any_unsafe = 0;
+    __syncthreads();
+    const int64_t r = (int64_t)blockIdx.x * ROWS_WG + threadIdx.x;
+    bool unsafe = !(e_max_norm > 0.f);
+    if (r < R && !unsafe) {
+        float ss = 0.f;
+        for (int k = 0; k < D; k += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(rx + r * D + k);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        unsafe = !(sqrtf(ss) * e_max_norm * kLog2e <= kFastBound);  // NaN/inf rows count as unsafe
+    }
+    if (unsafe) atomicOr(&any_unsafe, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = (uint8_t)any_unsafe;
+}
+
+// =============================================================================================
+// Fast path, D = 128: no running max, LDS offsets of all reads are lane base ^ constant + immediate
+// (tools/lds_bank_check.py proves the decomposition), the (buffer, subtile) loops are unrolled so that
+// the hot loop carries no address arithmetic, no compare and no branch besides the chunk loop itself.
+// =============================================================================================
+
+// ds_read_b64_tr_b16 through inline asm: the builtin makes hipcc wait vmcnt(0) for every in-flight
+// global_load_lds before the read (it cannot prove the read does not alias the LDS-DMA write), which serialises
+// the whole staging stream behind the compute.  The asm reads are invisible to hipcc's counters, so their
+// completion is awaited explicitly (tr_wait) before the first consumer.
+template <int OFF>
+__device__ __forceinline__ s16x4 tr_read(const unsigned addr) {
+    s16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ void tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MASK, bool WANT_DX, bool CHECK_N, int OFF>
+__device__ __forceinline__ void subtile_d128(const CatParamsB& p, const char* smem, const int off, const int64_t n0,
+                                             const bf16x8 (&xb)[8], f32x16 (&U)[4], float& lsum, const int a0,
+                                             const int t0, const int h, const int64_t tgt, const uint64_t grow,
+                                             const int64_t rl) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 5)) + off + OFF));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc, 0, 0, 0);
+    }
+    bool kp[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kp[i] = true;
+    if (MASK == MASK_PHILOX) {
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const uint64_t nbq = (uint64_t)(n0 + 8 * qq + 4 * h);
+            const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(nbq >> 2),
+                                             (uint32_t)(nbq >> 34) ^ 0x4D41534Bu, (uint32_t)p.seed,
+                                             (uint32_t)(p.seed >> 32));
+            const uint32_t u[4] = {ph.x, ph.y, ph.z, ph.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                kp[4 * qq + j] = (u[j] < p.keep_thresh) || ((int64_t)(n0 + 8 * qq + 4 * h + j) == tgt);
+        }
+    } else if (MASK == MASK_BYTES) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t n = n0 + nloc(i, h);
+            kp[i] = (n == tgt) || (n < p.N && p.keep[rl * p.N + n] != 0);
+        }
+    }
+    if (MASK != MASK_NONE) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = kp[i] ? acc[i] : 0.f;  // masked-out logit is 0 -> exp2 = 1
+    }
+    if (CHECK_N) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (n0 + nloc(i, h) >= p.N) { acc[i] = -INFINITY; kp[i] = false; }
+    }
+    float pk[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float e = __builtin_amdgcn_exp2f(acc[i]);
+        lsum += e;
+        pk[i] = (MASK == MASK_NONE || kp[i]) ? e : 0.f;
+    }
+    if (WANT_DX) {
+        bf16x8 pb[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pb[ks][j] = (__bf16)pk[8 * ks + j];
+        // gradient chain: E^T pieces by asm transposed reads, requested two MFMAs ahead (8 VGPRs in flight)
+        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)off;
+        s16x4 tl[8], th[8];
+#define PCVAE_TR(K)                                                                                             \
+        {                                                                                                       \
+            const unsigned alo = lbase + (unsigned)(t0 ^ (((K) >> 1) << 6)), ahi = lbase + (unsigned)(t0 ^ ((((K) >> 1) << 6) | 32)); \
+            tl[K] = tr_read<OFF + ((K) & 1) * 4096>(alo);                                                       \
+            th[K] = tr_read<OFF + ((K) & 1) * 4096 + 2048>(ahi);                                                \
+        }
+        PCVAE_TR(0) PCVAE_TR(1)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k + 2 < 8) {
+                if (k == 0) PCVAE_TR(2) else if (k == 1) PCVAE_TR(3) else if (k == 2) PCVAE_TR(4)
+                else if (k == 3) PCVAE_TR(5) else if (k == 4) PCVAE_TR(6) else PCVAE_TR(7)
+                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // reads of step k done, steps k+1, k+2 in flight
+            } else if (k == 6) {
+                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const s16x8 a16 = __builtin_shufflevector(tl[k], th[k], 0, 1, 2, 3, 4, 5, 6, 7);
+            U[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[k & 1], U[k >> 1], 0, 0, 0);
+        }
+#undef PCVAE_TR
+    }
+}
+
+// Ring of 4 x 64-item LDS buffers (16 KB each): chunk c lives in buffer c & 3 and is requested THREE chunks
+// before it is consumed, so the LDS-DMA stream has ~2.5 us to land (one chunk ahead was latency-bound:
+// every variant of the inner loop ran at the same 32.5 ms).  The seam between chunks is a counted
+// s_waitcnt vmcnt(4) (the two younger chunks stay in flight) + a raw s_barrier; all offsets stay immediates.
+constexpr int BNF = 64;                 // items per chunk of the fast kernel
+constexpr int CBF = BNF * 256;          // bytes per chunk (D = 128, bf16)
+constexpr int NRING = 4;
+
+// global -> LDS copy of one full 64-item chunk by 8 waves (2 one-KiB pieces each): wave-uniform base + one of two
+// per-lane 32-bit offsets (the swizzle depends on the piece only through piece & 3 = 2*(wave & 1) + i)
+__device__ __forceinline__ void stage_chunk_f(const uint16_t* __restrict__ E, int64_t n0, char* buf, const int wave_u,
+                                              const int (&lane_off)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pc = wave_u * 2 + i;
+        const char* base = reinterpret_cast<const char*>(E) + (n0 + pc * 4) * 256;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane_off[i]),
+                                         (__attribute__((address_space(3))) void*)(buf + pc * 1024), 16, 0, 0);
+    }
+}
+
+template <int MASK, bool WANT_DX>
+__global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatParamsB p) {
+    constexpr int D = 128;
+    using G = GeoB<D>;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / p.nrb, rb = logical % p.nrb;
+    if (p.safe_flags[rb] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int64_t nbase = (int64_t)t_beg * 32;
+    // 64-item chunks of this range that exist in full (no per-element bound checks in their bodies)
+    const int n_half = (t_end - t_beg + 1) / 2;
+    int n_full = (int)min((int64_t)n_half, (p.N - nbase) / BNF);
+    n_full = max(n_full, 0);
+
+    const int64_t r = (int64_t)rb * ROWS_WG + wave * 32 + li;
+    const bool row_ok = r < p.R;
+    const int64_t rl = row_ok ? r : p.R - 1;
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int lane_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // row = 4*piece + (lane>>4), piece & 3 = 2*(wave&1) + i
+        const int rr = (lane >> 4) | (((2 * (wave & 1) + i) & 3) << 2);
+        lane_off[i] = (lane >> 4) * 256 + (swz_chunk<128>(rr, lane & 15) << 4);
+    }
+    // prologue: chunks 0..2 in flight
+#pragma unroll
+    for (int c0 = 0; c0 < 3; ++c0)
+        if (c0 < n_full) stage_chunk_f(p.E, nbase + (int64_t)c0 * BNF, smem + c0 * CBF, wave_u, lane_off);
+
+    bf16x8 xb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h);
+        const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h + 4);
+        xb[s][0] = (__bf16)(v0.x * kLog2e); xb[s][1] = (__bf16)(v0.y * kLog2e);
+        xb[s][2] = (__bf16)(v0.z * kLog2e); xb[s][3] = (__bf16)(v0.w * kLog2e);
+        xb[s][4] = (__bf16)(v1.x * kLog2e); xb[s][5] = (__bf16)(v1.y * kLog2e);
+        xb[s][6] = (__bf16)(v1.z * kLog2e); xb[s][7] = (__bf16)(v1.w * kLog2e);
+    }
+    const int64_t tgt = (MASK != MASK_NONE) ? p.target[rl] : -1;
+    const uint64_t grow = p.row_offset + (uint64_t)rl;
+
+    f32x16 U[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) U[b][i] = 0.f;
+    float lsum = 0.f;
+
+    const int w = ((li & 3) << 2) | ((li >> 2) & 3);
+    const int a0 = li * 256 + ((w ^ h) << 4);
+    const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3, g1 = grp >> 1, g0 = grp & 1;
+    const int t0 = (4 * g1 + q) * 256 + ((((q << 2) | g1) ^ (2 * g0 + (pp >> 1))) << 4) + (pp & 1) * 8;
+
+    // ---- pipelined part: while chunk c is consumed, chunks c+1..c+3 are landed or in flight
+    // seam before consuming chunk c: this wave's pieces of chunk c have landed once at most 4 younger
+    // LDS-DMA instructions (chunks c+1, c+2) are outstanding; then everybody's have (barrier)
+#define PCVAE_SEAM(VMCNT) asm volatile("s_waitcnt vmcnt(" #VMCNT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    int c = 0;
+    const int n_pipe = n_full >= 3 ? n_full - 2 : 0;   // chunks consumed with two younger chunks in flight
+    for (; c + 4 <= n_pipe; c += 4) {
+#define PCVAE_RING_STEP(UU)                                                                                          \
+        {                                                                                                            \
+            const int64_t nA = nbase + (int64_t)(c + UU) * BNF;                                                      \
+            PCVAE_SEAM(4);                                                                                           \
+            /* buffer (UU+3)&3 held chunk c+UU-1, which every wave has finished: refill it */                        \
+            if (c + UU + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((UU + 3) & 3) * CBF, wave_u, lane_off); \
+            subtile_d128<MASK, WANT_DX, false, UU * CBF>(p, smem, 0, nA, xb, U, lsum, a0, t0, h, tgt, grow, rl);     \
+            subtile_d128<MASK, WANT_DX, false, UU * CBF + 8192>(p, smem, 0, nA + 32, xb, U, lsum, a0, t0, h, tgt, grow, rl); \
+        }
+        PCVAE_RING_STEP(0)
+        PCVAE_RING_STEP(1)
+        PCVAE_RING_STEP(2)
+        PCVAE_RING_STEP(3)
+#undef PCVAE_RING_STEP
+    }
+    // ---- remaining full chunks: drain the ring (vmcnt(0)), runtime offsets
+    for (; c < n_full; ++c) {
+        const int64_t nA = nbase + (int64_t)c * BNF;
+        PCVAE_SEAM(0);
+        if (c + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((c + 3) & 3) * CBF, wave_u, lane_off);
+        const int boff = (c & 3) * CBF;
+        subtile_d128<MASK, WANT_DX, false, 0>(p, smem, boff, nA, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+        subtile_d128<MASK, WANT_DX, false, 8192>(p, smem, boff, nA + 32, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+    }
+#undef PCVAE_SEAM
+    // ---- tail: short / ragged chunks (at most a few subtiles), staged synchronously with clamped addresses
+    for (int t = t_beg + 2 * n_full; t < t_end; t += 4) {
+        __syncthreads();
+        stage_chunk<D>(p.E, p.N, (int64_t)t * 32, smem);
+        __syncthreads();
+        const int nsub = min(4, t_end - t);
+        for (int st = 0; st < nsub; ++st)
+            subtile_d128<MASK, WANT_DX, true, 0>(p, smem, st * 8192, (int64_t)(t + st) * 32, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+    }
+
+    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+    if (row_ok) {
+        const int64_t o = (int64_t)split * p.R + r;
+        if (h == 0) { p.pm[o] = 0.f; p.pl[o] = ltot; }
+        if (WANT_DX) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int d0 = b * 32 + 8 * qq + 4 * h;
+                    *reinterpret_cast<float4*>(p.pU + o * D + d0) =
+                        make_float4(U[b][4 * qq], U[b][4 * qq + 1], U[b][4 * qq + 2], U[b][4 * qq + 3]);
+                }
+        }
+    }
+}
+
+__device__ __forceinline__ void load_rows_bf16(const float* __restrict__ rx, int64_t row, int h, bf16x8 (&xb)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(rx + row * 128 + 16 * s + 8 * h);
+        const float4 v1 = *reinterpret_cast<const float4*>(rx + row * 128 + 16 * s + 8 * h + 4);
+        xb[s][0] = (__bf16)(v0.x * kLog2e); xb[s][1] = (__bf16)(v0.y * kLog2e);
+        xb[s][2] = (__bf16)(v0.z * kLog2e); xb[s][3] = (__bf16)(v0.w * kLog2e);
+        xb[s][4] = (__bf16)(v1.x * kLog2e); xb[s][5] = (__bf16)(v1.y * kLog2e);
+        xb[s][6] = (__bf16)(v1.z * kLog2e); xb[s][7] = (__bf16)(v1.w * kLog2e);
+    }
+}
+
+// =============================================================================================
+// Fast path, D = 128, ROLE-SPLIT pairs.  The two waves that share a SIMD (w and w + 4) own the SAME 64 rows:
+//   wave w     ("logits wave")   : both 32-row logits chains of a subtile (the E row fragments are read from LDS
+//                                  once and used twice), exp2 / row sums, bf16 numerators -> LDS
+//   wave w + 4 ("gradient wave") : both 32-row gradient chains (the E^T pieces are read once and used twice), with
+//                                  the numerators its partner produced ONE CHUNK EARLIER
+// Why: with both partners running the same S -> softmax -> U program, the older wave wins the MFMA arbitration,
+// finishes early and idles at every seam while the younger one runs alone (stamps: 455/320/280 vs 650/325/365
+// cycles per tile).  Here one partner is MFMA + VALU, the other MFMA only, they are decoupled by a whole chunk
+// (the gradient wave never waits for data: what it needs was finished before the previous seam), the per-chunk
+// barrier is also the hand-off of the numerators, and the LDS reads per MFMA are halved.
+// LDS: [0, 64K) E ring of 4 x 16 KB chunks; [64K, 128K) numerators: [chunk parity][pair][subtile][row block][k step][lane]
+// Seam k: chunk k landed (vmcnt(2): chunk k+1 stays in flight), numerators of chunk k-1 complete, buffer of chunk
+// k-2 free -> refill it with chunk k+2; then the logits waves run chunk k and the gradient waves chunk k-1.
+// =============================================================================================
+constexpr int PBASE = 65536;  // byte offset of the numerator buffers
+
+template <bool CHECK_N>
+__device__ __forceinline__ void softmax_pack(const f32x16& acc, bf16x8 (&pb)[2], float& lsum, const int64_t n0, const int h,
+                                             const int64_t N) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        float a0 = acc[i], a1 = acc[i + 1];
+        if (CHECK_N) {
+            if (n0 + nloc(i, h) >= N) a0 = -INFINITY;
+            if (n0 + nloc(i + 1, h) >= N) a1 = -INFINITY;
+        }
+        const float e0 = __builtin_amdgcn_exp2f(a0);
+        const float e1 = __builtin_amdgcn_exp2f(a1);
+        lsum += e0;
+        lsum += e1;
+        pb[i >> 3][i & 7] = (__bf16)e0;
+        pb[i >> 3][(i & 7) + 1] = (__bf16)e1;
+    }
+}
+
+// logits wave, one subtile: E rows at (a0 ^ ..) + off + OFF; numerators to pdst + POFF (+ rbk*2048 + ks*1024)
+template <int OFF, int POFF, bool CHECK_N>
+__device__ __forceinline__ void logits_subtile(char* smem, const int off, const int a0, const int pdst, const bf16x8 (&xb0)[8],
+                                               const bf16x8 (&xb1)[8], float& lsum0, float& lsum1, const int64_t n0,
+                                               const int h, const int64_t N) {
+    bf16x8 af[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) af[s] = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 5)) + off + OFF));
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], xb0[s], acc0, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], xb1[s], acc1, 0, 0, 0);
+    bf16x8 pb0[2], pb1[2];
+    softmax_pack<CHECK_N>(acc0, pb0, lsum0, n0, h, N);
+    softmax_pack<CHECK_N>(acc1, pb1, lsum1, n0, h, N);
+    *reinterpret_cast<bf16x8*>(smem + (pdst + POFF)) = pb0[0];
+    *reinterpret_cast<bf16x8*>(smem + (pdst + POFF + 1024)) = pb0[1];
+    *reinterpret_cast<bf16x8*>(smem + (pdst + POFF + 2048)) = pb1[0];
+    *reinterpret_cast<bf16x8*>(smem + (pdst + POFF + 3072)) = pb1[1];
+}
+
+// gradient wave, one subtile: E^T pieces at (t0 ^ ..) + off + OFF; numerators from psrc + POFF
+template <int OFF, int POFF>
+__device__ __forceinline__ void grad_subtile(const char* smem, const int off, const int t0, const int psrc, f32x16 (&U0)[4],
+                                             f32x16 (&U1)[4]) {
+    s16x4 tl[8], th[8];
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)off;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned alo = lbase + (unsigned)(t0 ^ ((k >> 1) << 6)), ahi = lbase + (unsigned)(t0 ^ (((k >> 1) << 6) | 32));
+        if (k & 1) { tl[k] = tr_read<OFF + 4096>(alo); th[k] = tr_read<OFF + 4096 + 2048>(ahi); }
+        else       { tl[k] = tr_read<OFF>(alo);        th[k] = tr_read<OFF + 2048>(ahi); }
+    }
+    const bf16x8 p00 = *reinterpret_cast<const bf16x8*>(smem + (psrc + POFF));
+    const bf16x8 p01 = *reinterpret_cast<const bf16x8*>(smem + (psrc + POFF + 1024));
+    const bf16x8 p10 = *reinterpret_cast<const bf16x8*>(smem + (psrc + POFF + 2048));
+    const bf16x8 p11 = *reinterpret_cast<const bf16x8*>(smem + (psrc + POFF + 3072));
+    tr_wait();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const s16x8 a16 = __builtin_shufflevector(tl[k], th[k], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+        U0[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, (k & 1) ? p01 : p00, U0[k >> 1], 0, 0, 0);
+        U1[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, (k & 1) ? p11 : p10, U1[k >> 1], 0, 0, 0);
+    }
+}
+
+__global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_pair_kernel(CatParamsB p) {
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / p.nrb, rb = logical % p.nrb;
+    if (p.safe_flags[rb] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int64_t nbase = (int64_t)t_beg * 32;
+    const int n_half = (t_end - t_beg + 1) / 2;
+    int n_full = (int)min((int64_t)n_half, (p.N - nbase) / BNF);  // 64-item chunks that exist in full
+    n_full = max(n_full, 0);
+    const int n_pipe = (n_full / 4) * 4;  // the ring handles whole groups of 4 chunks
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int role = wave_u >> 2;   // 0: logits wave, 1: gradient wave
+    const int pair = wave_u & 3;
+    const int64_t r0 = (int64_t)rb * ROWS_WG + pair * 64 + li, r1 = r0 + 32;
+    const int64_t rl0 = r0 < p.R ? r0 : p.R - 1, rl1 = r1 < p.R ? r1 : p.R - 1;
+
+    int lane_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {  // row = 4*piece + (lane>>4), piece & 3 = 2*(wave&1) + i
+        const int rr = (lane >> 4) | (((2 * (wave & 1) + i) & 3) << 2);
+        lane_off[i] = (lane >> 4) * 256 + (swz_chunk<128>(rr, lane & 15) << 4);
+    }
+    if (n_pipe > 0) {
+        stage_chunk_f(p.E, nbase, smem, wave_u, lane_off);
+        stage_chunk_f(p.E, nbase + BNF, smem + CBF, wave_u, lane_off);
+    }
+
+    const int w = ((li & 3) << 2) | ((li >> 2) & 3);
+    const int a0 = li * 256 + ((w ^ h) << 4);
+    const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3, g1 = grp >> 1, g0 = grp & 1;
+    const int t0 = (4 * g1 + q) * 256 + ((((q << 2) | g1) ^ (2 * g0 + (pp >> 1))) << 4) + (pp & 1) * 8;
+    const int pl = PBASE + pair * 8192 + lane * 16;  // this lane's slot in the numerator buffers
+
+#define PCVAE_PSEAM(VMCNT) asm volatile("s_waitcnt vmcnt(" #VMCNT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PCVAE_PAIR_SEAM_AND_STAGE(UU)                                                                                \
+            const int kk = k + UU;                                                                                   \
+            if (kk + 1 < n_pipe) { PCVAE_PSEAM(2); } else { PCVAE_PSEAM(0); }                                        \
+            if (kk + 2 < n_pipe)                                                                                     \
+                stage_chunk_f(p.E, nbase + (int64_t)(kk + 2) * BNF, smem + ((UU + 2) & 3) * CBF, wave_u, lane_off);
+
+    // The two roles are two separate code paths (so that each only carries its own registers); both execute exactly
+    // the same sequence of barriers: n_pipe + 1 seams, then the synchronous tail.
+    if (role == 0) {
+        // ================= logits wave: iteration k runs chunk k =================
+        bf16x8 xb0[8], xb1[8];
+        float lsum0 = 0.f, lsum1 = 0.f;
+        load_rows_bf16(p.rx, rl0, h, xb0);
+        load_rows_bf16(p.rx, rl1, h, xb1);
+        for (int k = 0; k <= n_pipe; k += 4) {
+#define PCVAE_LOGITS_STEP(UU)                                                                                        \
+            if (k + UU <= n_pipe) {                                                                                  \
+                PCVAE_PAIR_SEAM_AND_STAGE(UU)                                                                        \
+                if (kk < n_pipe) {                                                                                   \
+                    const int64_t nA = nbase + (int64_t)kk * BNF;                                                    \
+                    logits_subtile<(UU & 3) * CBF, (UU & 1) * 32768, false>(smem, 0, a0, pl, xb0, xb1, lsum0, lsum1, nA, h, p.N); \
+                    logits_subtile<(UU & 3) * CBF + 8192, (UU & 1) * 32768 + 4096, false>(smem, 0, a0, pl, xb0, xb1, lsum0, lsum1, \
+                                                                                         nA + 32, h, p.N);           \
+                }                                                                                                    \
+            }
+            PCVAE_LOGITS_STEP(0)
+            PCVAE_LOGITS_STEP(1)
+            PCVAE_LOGITS_STEP(2)
+            PCVAE_LOGITS_STEP(3)
+#undef PCVAE_LOGITS_STEP
+        }
+        for (int t = t_beg + 2 * n_pipe; t < t_end; t += 4) {  // synchronous tail (short / ragged chunks)
+            __syncthreads();
+            stage_chunk<D>(p.E, p.N, (int64_t)t * 32, smem);
+            __syncthreads();
+            const int nsub = min(4, t_end - t);
+            for (int st = 0; st < nsub; ++st) {
+                logits_subtile<0, 0, true>(smem, st * 8192, a0, pl, xb0, xb1, lsum0, lsum1, (int64_t)(t + st) * 32, h, p.N);
+                __syncthreads();
+                __syncthreads();
+            }
+        }
+        const float l0 = lsum0 + __shfl_xor(lsum0, 32, 64), l1 = lsum1 + __shfl_xor(lsum1, 32, 64);
+        if (h == 0) {
+            if (r0 < p.R) { p.pm[(int64_t)split * p.R + r0] = 0.f; p.pl[(int64_t)split * p.R + r0] = l0; }
+            if (r1 < p.R) { p.pm[(int64_t)split * p.R + r1] = 0.f; p.pl[(int64_t)split * p.R + r1] = l1; }
+        }
+    } else {
+        // ================= gradient wave: iteration k runs chunk k-1 =================
+        f32x16 U0[4], U1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { U0[b][i] = 0.f; U1[b][i] = 0.f; }
+        for (int k = 0; k <= n_pipe; k += 4) {
+#define PCVAE_GRAD_STEP(UU)                                                                                          \
+            if (k + UU <= n_pipe) {                                                                                  \
+                PCVAE_PAIR_SEAM_AND_STAGE(UU)                                                                        \
+                if (kk >= 1) {                                                                                       \
+                    grad_subtile<((UU + 3) & 3) * CBF, ((UU + 1) & 1) * 32768>(smem, 0, t0, pl, U0, U1);            \
+                    grad_subtile<((UU + 3) & 3) * CBF + 8192, ((UU + 1) & 1) * 32768 + 4096>(smem, 0, t0, pl, U0, U1); \
+                }                                                                                                    \
+            }
+            PCVAE_GRAD_STEP(0)
+            PCVAE_GRAD_STEP(1)
+            PCVAE_GRAD_STEP(2)
+            PCVAE_GRAD_STEP(3)
+#undef PCVAE_GRAD_STEP
+        }
+        for (int t = t_beg + 2 * n_pipe; t < t_end; t += 4) {
+            __syncthreads();
+            stage_chunk<D>(p.E, p.N, (int64_t)t * 32, smem);
+            __syncthreads();
+            const int nsub = min(4, t_end - t);
+            for (int st = 0; st < nsub; ++st) {
+                __syncthreads();
+                grad_subtile<0, 0>(smem, st * 8192, t0, pl, U0, U1);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+            const int64_t r = blk ? r1 : r0;
+            if (r < p.R) {
+                const int64_t o = (int64_t)split * p.R + r;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int d0 = b * 32 + 8 * qq + 4 * h;
+                        const f32x16& Ub = blk ? U1[b] : U0[b];
+                        *reinterpret_cast<float4*>(p.pU + o * D + d0) =
+                            make_float4(Ub[4 * qq], Ub[4 * qq + 1], Ub[4 * qq + 2], Ub[4 * qq + 3]);
+                    }
+            }
+        }
+    }
+#undef PCVAE_PAIR_SEAM_AND_STAGE
+#undef PCVAE_PSEAM
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+
+// one wave per row: merge the split partials (log2 domain), target logit in the kernel's own arithmetic.
+// Lane j owns split j's (m, l) (nsplit <= 64), so max / rescale / sum are wave reductions; the U rows of the
+// splits are then streamed with 8 independent loads in flight per lane.
+template <int D>
+__global__ void __launch_bounds__(256) catalog_ce_merge_bf16_kernel(CatParamsB p, float* __restrict__ nll,
+                                                                    float* __restrict__ lse, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    const float mj = lane < p.nsplit ? p.pm[(int64_t)lane * p.R + r] : -INFINITY;
+    const float lj = lane < p.nsplit ? p.pl[(int64_t)lane * p.R + r] : 0.f;
+    float M = mj;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+    const float sj = lane < p.nsplit ? exp2f(mj - M) : 0.f;
+    float L = lj * sj;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o, 64);
+    const int64_t t = p.target[r];
+    const bool t_ok = t >= 0 && t < p.N;
+    // target logit: each lane takes D/64 of the products, same bf16 operands as the MFMA chain
+    float zt = 0.f;
+    if (t_ok)
+        for (int k = lane; k < D; k += 64)
+            zt = fmaf(bf16_to_f32(p.E[t * D + k]), (float)(__bf16)(p.rx[r * D + k] * kLog2e), zt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) zt += __shfl_xor(zt, o, 64);
+    const float lse_r = (M + log2f(L)) * kLn2;
+    if (lane == 0) {
+        nll[r] = t_ok ? lse_r - zt * kLn2 : NAN;
+        if (lse) lse[r] = lse_r;
+    }
+    if (dx) {
+        const float invL = 1.f / L;
+        for (int d = lane; d < D; d += 64) {
+            float u = 0.f;
+            int j = 0;
+            for (; j + 8 <= p.nsplit; j += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = p.pU[((int64_t)(j + q) * p.R + r) * D + d];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) u = fmaf(v[q], __shfl(sj, j + q, 64), u);
+            }
+            for (; j < p.nsplit; ++j) u = fmaf(p.pU[((int64_t)j * p.R + r) * D + d], __shfl(sj, j, 64), u);
+            dx[r * D + d] = t_ok ? u * invL - bf16_to_f32(p.E[t * D + d]) : NAN;
+        }
+    }
+}
+
+template <int D>
+int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uint8_t* flags, float* nll, float* lse,
+                float* dx, hipStream_t st) {
+    using G = GeoB<D>;
+    const size_t lds = 2 * G::CHUNK_BYTES;
+    const dim3 grid((unsigned)(p.nrb * p.nsplit)), block(512);
+    p.safe_flags = nullptr;
+    p.run_if_flag = 1;
+    if (D == 128) {
+        // row blocks with a small logit bound run the max-free kernel, the others the lazy-max kernel;
+        // both launches cover the whole grid and each workgroup exits at once if the other kernel owns it
+        hipLaunchKernelGGL((catalog_row_bound_kernel<D>), dim3((unsigned)p.nrb), dim3(256), 0, st, p.rx, p.R, e_max_norm,
+                           flags);
+        p.safe_flags = flags;
+#define PCVAE_CEF(MASKV, DXV)                                                                                    \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_d128_fast_kernel<MASKV, DXV>),   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((catalog_ce_bf16_d128_fast_kernel<MASKV, DXV>), grid, block, lds, st, p);             \
+    } while (0)
+#ifndef PCVAE_PAIR_KERNEL
+#define PCVAE_PAIR_KERNEL 1
+#endif
+        if (PCVAE_PAIR_KERNEL && want_dx && mask_mode == MASK_NONE) {
+            // the training call: role-split pair kernel (E ring + numerator buffers = 128 KB of LDS)
+            static bool attr_set_pair = false;
+            if (!attr_set_pair) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_d128_pair_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                attr_set_pair = true;
+            }
+            hipLaunchKernelGGL(catalog_ce_bf16_d128_pair_kernel, grid, block, 131072, st, p);
+        } else if (want_dx) {
+            if (mask_mode == MASK_NONE) PCVAE_CEF(MASK_NONE, true);
+            else if (mask_mode == MASK_PHILOX) PCVAE_CEF(MASK_PHILOX, true);
+            else PCVAE_CEF(MASK_BYTES, true);
+        } else {
+            if (mask_mode == MASK_NONE) PCVAE_CEF(MASK_NONE, false);
+            else if (mask_mode == MASK_PHILOX) PCVAE_CEF(MASK_PHILOX, false);
+            else PCVAE_CEF(MASK_BYTES, false);
+        }
+#undef PCVAE_CEF
+        int rc0 = check_launch("catalog_ce_bf16_fast");
+        if (rc0 != PCVAE_OK) return rc0;
+    }
+#define PCVAE_CEB(MASKV, DXV)                                                                                    \
+    do {                                                                                                         \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_kernel<D, MASKV, DXV>),          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((catalog_ce_bf16_kernel<D, MASKV, DXV>), grid, block, lds, st, p);                    \
+    } while (0)
+    if (want_dx) {
+        if (mask_mode == MASK_NONE) PCVAE_CEB(MASK_NONE, true);
+        else if (mask_mode == MASK_PHILOX) PCVAE_CEB(MASK_PHILOX, true);
+        else PCVAE_CEB(MASK_BYTES, true);
+    } else {
+        if (mask_mode == MASK_NONE) PCVAE_CEB(MASK_NONE, false);
+        else if (mask_mode == MASK_PHILOX) PCVAE_CEB(MASK_PHILOX, false);
+        else PCVAE_CEB(MASK_BYTES, false);
+    }
+#undef PCVAE_CEB
+    int rc = check_launch("catalog_ce_bf16");
+    if (rc != PCVAE_OK) return rc;
+    hipLaunchKernelGGL((catalog_ce_merge_bf16_kernel<D>), dim3((unsigned)cdiv(p.R, 4)), dim3(256), 0, st, p, nll, lse,
+                       want_dx ? dx : nullptr);
+    return check_launch("catalog_ce_merge_bf16");
+}
+
+}  // namespace
+
+namespace pcvae {
+
+int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
+                    const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
+                    const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, hipStream_t st) {
+    const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16);
+    CatParamsB p{};
+    p.rx = rx; p.E = E; p.target = target; p.keep = keep_mask;
+    p.seed = seed; p.row_offset = row_offset; p.R = R; p.N = N;
+    p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
+    p.pm = reinterpret_cast<float*>(ws);
+    p.pl = p.pm + (int64_t)pl.nsplit * R;
+    p.pU = p.pl + (int64_t)pl.nsplit * R;
+    // row-block flags live behind the partials (pcvae_catalog_ws_bytes reserves them)
+    uint8_t* flags = reinterpret_cast<uint8_t*>(p.pU + (dx ? (int64_t)pl.nsplit * R * D : 0));
+    int mask_mode = MASK_NONE;
+    if (keep_mask) mask_mode = MASK_BYTES;
+    else if (keep_prob < 1.0f) {
+        mask_mode = MASK_PHILOX;
+        const double th = (double)keep_prob * 4294967296.0;
+        p.keep_thresh = th <= 0.0 ? 0u : (th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th);
+    }
+    switch (D) {
+        case 64: return launch_ce_b<64>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
+        case 128: return launch_ce_b<128>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
+        case 256: return launch_ce_b<256>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
+    }
+    set_error("catalog_ce(bf16): unsupported D=%d (64, 128, 256; smaller tables use the f32 kernel)", D);
+    return PCVAE_EINVAL;
+}
+
+}  // namespace pcvae
