@@ -96,6 +96,29 @@ def gather_roofline(model, cfg, device):
             "rows": idx.numel(), "cache": "cold (512 MB written between launches)"}
 
 
+def generate_throughput(model, cfg, device, iters=3):
+    """Greedy slate generation (recommend(return_item=True)): prior MLP -> z -> PSM -> catalog argmax (pivot) -> SCM ->
+    catalog argmax (S slots).  Always in exact f32 so that the item ids are bit-exact against the reference arithmetic."""
+    B, S = cfg["B"], cfg["S"]
+    g = torch.Generator(device=device).manual_seed(7)
+    u = torch.randint(0, N_USER, (B, 1), device=device, generator=g)
+    ctx = (torch.rand(B, S, device=device, generator=g) < 0.5).float()
+    prec = model.catalog_precision
+    model.set_catalog_precision("f32")
+    with torch.no_grad():
+        model.recommend(ctx, u, return_item=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            items, _ = model.recommend(ctx, u, return_item=True)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+    model.catalog_precision = prec
+    flops = 2.0 * (S + 1) * cfg["N"] * cfg["D"] * B  # pivot argmax + S slot argmaxes (SURVEY.md 8d, F_generate)
+    return {"value": B / dt, "unit": "slates/s", "ms_per_batch": dt * 1e3, "arithmetic": "f32 MFMA (bit-exact greedy ids)",
+            "achieved_TFLOPs": flops / dt / 1e12, "peak_TFLOPs": PEAK_TFLOPS["f32"], "frac": flops / dt / 1e12 / PEAK_TFLOPS["f32"]}
+
+
 def cpu_baseline_and_parity(model, st, cfg, dtype):
     """Oracle train step on the host cores on a bounded sample + HIP-vs-oracle ELBO on that same sample."""
     from oracle import pivotcvae_oracle as orc
@@ -251,7 +274,7 @@ def main():
                    "catalog_arithmetic": args.dtype, "mlp_arithmetic": "f32",
                    "launch": "hipGraph replay (zero-grad+fwd+bwd) + eager all-reduce + Adam" if graphed else "eager"},
         "elbo": {"loss": loss.item(), "recLoss": rec.item(), "KLD": kld.item()},
-        "roofline": {"kernel": (f"catalog_ce_bf16_d128_fast_kernel<0,true>" if (args.dtype == "bf16" and D == 128) else
+        "roofline": {"kernel": (f"catalog_ce_bf16_d128_fast_kernel" if (args.dtype == "bf16" and D == 128) else
                                 f"catalog_ce_{args.dtype}_kernel<{D}>") + " (events also span its row-bound prologue and "
                                "merge kernels, <1% together)", "bound": "mfma",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -264,6 +287,7 @@ def main():
         out["cpu_baseline"] = base
         out["parity"] = parity
         out["gather_roofline"] = gather_roofline(model, cfg, device)
+        out["generate"] = generate_throughput(model, cfg, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -77,7 +77,9 @@ struct GeoB {
 // 16-byte-chunk swizzle of the LDS image (an involution on the chunk index of one row)
 template <int D>
 __device__ __forceinline__ int swz_chunk(int row, int c) {
-    if (D >= 128) return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    // low field = 2-bit reversal of (row >> 2) & 3: keeps the 32x32x16 read patterns conflict-free and makes the
+    // 16x16x32 ones (fast kernel) conflict-free too - tools/lds_bank_check.py models both
+    if (D >= 128) return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1)));
     return c ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3));  // D == 64: two rows per 256-B bank row
 }
 
@@ -336,99 +338,100 @@ __device__ __forceinline__ void tr_wait() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MASK, bool WANT_DX, bool CHECK_N, int OFF>
-__device__ __forceinline__ void subtile_d128(const CatParamsB& p, const char* smem, const int off, const int64_t n0,
-                                             const bf16x8 (&xb)[8], f32x16 (&U)[4], float& lsum, const int a0,
-                                             const int t0, const int h, const int64_t tgt, const uint64_t grow,
-                                             const int64_t rl) {
-    f32x16 acc;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// The fast kernel computes with v_mfma_f32_16x16x32_bf16: at equal FLOPs per cycle the chip holds a ~12 % higher
+// clock on this shape than on 32x32x16 under MFMA-dense load (bare loops on random operands: 1.95 vs 1.74 PFLOP/s,
+// tools/mfma_shape_probe.hip), and the kernel runs at the power-limited ceiling.
+// Lane l: c = l & 15, g = l >> 4.  A wave owns 32 rows = two 16-row column tiles ct; a subtile = 32 items = two
+// 16-item row tiles rt.
+//   logits   acc[rt][ct] (f32x4) = sum over 4 k-steps; lane holds logit(n = 16 rt + 4 g + reg, r = 16 ct + c).
+//            Lane group g takes the 16-byte chunks 4g..4g+3 of a row over the 4 k-steps (any bijection of chunks to
+//            (k-step, lane group) is a valid k order as long as both operands use it) - this one keeps the row reads
+//            bank-conflict free.
+//   softmax  16 exp2 per lane; the 8 values of column tile ct, [acc[0][ct][0..3], acc[1][ct][0..3]], are IN PLACE
+//            the B operand of the gradient MFMA (k slot (g, j) <-> item 16 (j >> 2) + 4 g + (j & 3)).
+//   gradient U[dt][ct] (f32x4) += E^T tile dt (16 d x 32 items, two transposed reads per lane) . P tile ct: one MFMA
+//            per (d tile, column tile) covers the whole subtile (K = 32 items).
+// ---------------------------------------------------------------------------------------------------------------
+template <bool CHECK_N, int OFF>
+__device__ __forceinline__ void subtile16_d128(const char* smem, const int off, const int64_t n0, const int64_t N,
+                                               const bf16x8 (&xb)[2][4], f32x4 (&U)[8][2], float (&lsum)[2], const int a0,
+                                               const int t0, const int g) {
+    // ---- logits
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 5)) + off + OFF));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[s], acc, 0, 0, 0);
-    }
-    bool kp[16];
+        for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) kp[i] = true;
-    if (MASK == MASK_PHILOX) {
+            for (int i = 0; i < 4; ++i) acc[rt][ct][i] = 0.f;
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const uint64_t nbq = (uint64_t)(n0 + 8 * qq + 4 * h);
-            const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(nbq >> 2),
-                                             (uint32_t)(nbq >> 34) ^ 0x4D41534Bu, (uint32_t)p.seed,
-                                             (uint32_t)(p.seed >> 32));
-            const uint32_t u[4] = {ph.x, ph.y, ph.z, ph.w};
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                kp[4 * qq + j] = (u[j] < p.keep_thresh) || ((int64_t)(n0 + 8 * qq + 4 * h + j) == tgt);
+        for (int rt = 0; rt < 2; ++rt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 4)) + off + (OFF + rt * 4096)));
+            acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[0][s], acc[rt][0], 0, 0, 0);
+            acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[1][s], acc[rt][1], 0, 0, 0);
         }
-    } else if (MASK == MASK_BYTES) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int64_t n = n0 + nloc(i, h);
-            kp[i] = (n == tgt) || (n < p.N && p.keep[rl * p.N + n] != 0);
-        }
-    }
-    if (MASK != MASK_NONE) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = kp[i] ? acc[i] : 0.f;  // masked-out logit is 0 -> exp2 = 1
-    }
     if (CHECK_N) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (n0 + nloc(i, h) >= p.N) { acc[i] = -INFINITY; kp[i] = false; }
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + 16 * rt + 4 * g + i >= N) { acc[rt][0][i] = -INFINITY; acc[rt][1][i] = -INFINITY; }
     }
-    float pk[16];
+    // ---- numerators
+    bf16x8 pb[2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float e = __builtin_amdgcn_exp2f(acc[i]);
-        lsum += e;
-        pk[i] = (MASK == MASK_NONE || kp[i]) ? e : 0.f;
-    }
-    if (WANT_DX) {
-        bf16x8 pb[2];
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pb[ks][j] = (__bf16)pk[8 * ks + j];
-        // gradient chain: E^T pieces by asm transposed reads, requested two MFMAs ahead (8 VGPRs in flight)
-        const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)off;
-        s16x4 tl[8], th[8];
-#define PCVAE_TR(K)                                                                                             \
-        {                                                                                                       \
-            const unsigned alo = lbase + (unsigned)(t0 ^ (((K) >> 1) << 6)), ahi = lbase + (unsigned)(t0 ^ ((((K) >> 1) << 6) | 32)); \
-            tl[K] = tr_read<OFF + ((K) & 1) * 4096>(alo);                                                       \
-            th[K] = tr_read<OFF + ((K) & 1) * 4096 + 2048>(ahi);                                                \
-        }
-        PCVAE_TR(0) PCVAE_TR(1)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k + 2 < 8) {
-                if (k == 0) PCVAE_TR(2) else if (k == 1) PCVAE_TR(3) else if (k == 2) PCVAE_TR(4)
-                else if (k == 3) PCVAE_TR(5) else if (k == 4) PCVAE_TR(6) else PCVAE_TR(7)
-                asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // reads of step k done, steps k+1, k+2 in flight
-            } else if (k == 6) {
-                asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int i = 0; i < 4; i += 2) {
+                const float e0 = __builtin_amdgcn_exp2f(acc[rt][ct][i]);
+                const float e1 = __builtin_amdgcn_exp2f(acc[rt][ct][i + 1]);
+                lsum[ct] += e0;
+                lsum[ct] += e1;
+                pb[ct][4 * rt + i] = (__bf16)e0;
+                pb[ct][4 * rt + i + 1] = (__bf16)e1;
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const s16x8 a16 = __builtin_shufflevector(tl[k], th[k], 0, 1, 2, 3, 4, 5, 6, 7);
-            U[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[k & 1], U[k >> 1], 0, 0, 0);
-        }
-#undef PCVAE_TR
+    // ---- gradient chain: E^T pieces by asm transposed reads, requested two d tiles ahead
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)off;
+    s16x4 tl[8], th[8];
+#define PCVAE_TR16(DT)                                                        \
+    {                                                                         \
+        const unsigned ad = lbase + (unsigned)(t0 ^ ((DT) << 5));             \
+        tl[DT] = tr_read<OFF>(ad);                                            \
+        th[DT] = tr_read<OFF + 4096>(ad);                                     \
     }
+    PCVAE_TR16(0) PCVAE_TR16(1)
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+        if (dt + 2 < 8) {
+            if (dt == 0) PCVAE_TR16(2) else if (dt == 1) PCVAE_TR16(3) else if (dt == 2) PCVAE_TR16(4)
+            else if (dt == 3) PCVAE_TR16(5) else if (dt == 4) PCVAE_TR16(6) else PCVAE_TR16(7)
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // pieces of d tile dt landed, two d tiles in flight
+        } else if (dt == 6) {
+            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const s16x8 a16 = __builtin_shufflevector(tl[dt], th[dt], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+        U[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[0], U[dt][0], 0, 0, 0);
+        U[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[1], U[dt][1], 0, 0, 0);
+    }
+#undef PCVAE_TR16
 }
 
-// Ring of 4 x 64-item LDS buffers (16 KB each): chunk c lives in buffer c & 3 and is requested THREE chunks
-// before it is consumed, so the LDS-DMA stream has ~2.5 us to land (one chunk ahead was latency-bound:
-// every variant of the inner loop ran at the same 32.5 ms).  The seam between chunks is a counted
-// s_waitcnt vmcnt(4) (the two younger chunks stay in flight) + a raw s_barrier; all offsets stay immediates.
+// Ring of 4 x 64-item LDS buffers (16 KB each): chunk c lives in buffer c & 3 and is requested three chunks before
+// it is consumed.  The seam between chunks is a counted s_waitcnt vmcnt(4) (the two younger chunks stay in flight)
+// + a raw s_barrier; all LDS offsets of the reads are immediates.
 constexpr int BNF = 64;                 // items per chunk of the fast kernel
 constexpr int CBF = BNF * 256;          // bytes per chunk (D = 128, bf16)
-constexpr int NRING = 4;
 
 // global -> LDS copy of one full 64-item chunk by 8 waves (2 one-KiB pieces each): wave-uniform base + one of two
 // per-lane 32-bit offsets (the swizzle depends on the piece only through piece & 3 = 2*(wave & 1) + i)
@@ -443,14 +446,12 @@ __device__ __forceinline__ void stage_chunk_f(const uint16_t* __restrict__ E, in
     }
 }
 
-template <int MASK, bool WANT_DX>
 __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatParamsB p) {
     constexpr int D = 128;
-    using G = GeoB<D>;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int li = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / p.nrb, rb = logical % p.nrb;
     if (p.safe_flags[rb] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
@@ -462,9 +463,7 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
     int n_full = (int)min((int64_t)n_half, (p.N - nbase) / BNF);
     n_full = max(n_full, 0);
 
-    const int64_t r = (int64_t)rb * ROWS_WG + wave * 32 + li;
-    const bool row_ok = r < p.R;
-    const int64_t rl = row_ok ? r : p.R - 1;
+    const int64_t rw = (int64_t)rb * ROWS_WG + wave * 32;  // first row of this wave
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int lane_off[2];
@@ -473,51 +472,55 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
         const int rr = (lane >> 4) | (((2 * (wave & 1) + i) & 3) << 2);
         lane_off[i] = (lane >> 4) * 256 + (swz_chunk<128>(rr, lane & 15) << 4);
     }
-    // prologue: chunks 0..2 in flight
 #pragma unroll
-    for (int c0 = 0; c0 < 3; ++c0)
+    for (int c0 = 0; c0 < 3; ++c0)  // prologue: chunks 0..2 in flight
         if (c0 < n_full) stage_chunk_f(p.E, nbase + (int64_t)c0 * BNF, smem + c0 * CBF, wave_u, lane_off);
 
-    bf16x8 xb[8];
+    // B operand of the logits chain: column tile ct, k-step s: rx[row 16 ct + c][8 (4 g + s) .. + 7] * log2 e
+    bf16x8 xb[2][4];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h);
-        const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 16 * s + 8 * h + 4);
-        xb[s][0] = (__bf16)(v0.x * kLog2e); xb[s][1] = (__bf16)(v0.y * kLog2e);
-        xb[s][2] = (__bf16)(v0.z * kLog2e); xb[s][3] = (__bf16)(v0.w * kLog2e);
-        xb[s][4] = (__bf16)(v1.x * kLog2e); xb[s][5] = (__bf16)(v1.y * kLog2e);
-        xb[s][6] = (__bf16)(v1.z * kLog2e); xb[s][7] = (__bf16)(v1.w * kLog2e);
+    for (int ct = 0; ct < 2; ++ct) {
+        const int64_t r = rw + 16 * ct + c;
+        const int64_t rl = r < p.R ? r : p.R - 1;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * (4 * g + s));
+            const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * (4 * g + s) + 4);
+            xb[ct][s][0] = (__bf16)(v0.x * kLog2e); xb[ct][s][1] = (__bf16)(v0.y * kLog2e);
+            xb[ct][s][2] = (__bf16)(v0.z * kLog2e); xb[ct][s][3] = (__bf16)(v0.w * kLog2e);
+            xb[ct][s][4] = (__bf16)(v1.x * kLog2e); xb[ct][s][5] = (__bf16)(v1.y * kLog2e);
+            xb[ct][s][6] = (__bf16)(v1.z * kLog2e); xb[ct][s][7] = (__bf16)(v1.w * kLog2e);
+        }
     }
-    const int64_t tgt = (MASK != MASK_NONE) ? p.target[rl] : -1;
-    const uint64_t grow = p.row_offset + (uint64_t)rl;
 
-    f32x16 U[4];
+    f32x4 U[8][2];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int dt = 0; dt < 8; ++dt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) U[b][i] = 0.f;
-    float lsum = 0.f;
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) U[dt][ct][i] = 0.f;
+    float lsum[2] = {0.f, 0.f};
 
-    const int w = ((li & 3) << 2) | ((li >> 2) & 3);
-    const int a0 = li * 256 + ((w ^ h) << 4);
-    const int grp = lane >> 4, gi = lane & 15, q = gi >> 2, pp = gi & 3, g1 = grp >> 1, g0 = grp & 1;
-    const int t0 = (4 * g1 + q) * 256 + ((((q << 2) | g1) ^ (2 * g0 + (pp >> 1))) << 4) + (pp & 1) * 8;
+    // lane bases of the two LDS read patterns (address = base ^ constant + immediate; tools/lds_bank_check.py)
+    const int q = c >> 2, pp = c & 3;
+    const int wr = ((c & 3) << 2) | (((c >> 2) & 1) << 1) | ((c >> 3) & 1);   // swizzle of row c (mod 16)
+    const int a0 = c * 256 + (((4 * g) ^ wr) << 4);
+    const int brg = ((g & 1) << 1) | (g >> 1);                                  // 2-bit reversal of g
+    const int t0 = (4 * g + q) * 256 + (((pp >> 1) ^ ((q << 2) | brg)) << 4) + (pp & 1) * 8;
 
-    // ---- pipelined part: while chunk c is consumed, chunks c+1..c+3 are landed or in flight
-    // seam before consuming chunk c: this wave's pieces of chunk c have landed once at most 4 younger
-    // LDS-DMA instructions (chunks c+1, c+2) are outstanding; then everybody's have (barrier)
 #define PCVAE_SEAM(VMCNT) asm volatile("s_waitcnt vmcnt(" #VMCNT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
-    int c = 0;
+    int cc = 0;
     const int n_pipe = n_full >= 3 ? n_full - 2 : 0;   // chunks consumed with two younger chunks in flight
-    for (; c + 4 <= n_pipe; c += 4) {
+    for (; cc + 4 <= n_pipe; cc += 4) {
 #define PCVAE_RING_STEP(UU)                                                                                          \
         {                                                                                                            \
-            const int64_t nA = nbase + (int64_t)(c + UU) * BNF;                                                      \
+            const int64_t nA = nbase + (int64_t)(cc + UU) * BNF;                                                     \
             PCVAE_SEAM(4);                                                                                           \
-            /* buffer (UU+3)&3 held chunk c+UU-1, which every wave has finished: refill it */                        \
-            if (c + UU + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((UU + 3) & 3) * CBF, wave_u, lane_off); \
-            subtile_d128<MASK, WANT_DX, false, UU * CBF>(p, smem, 0, nA, xb, U, lsum, a0, t0, h, tgt, grow, rl);     \
-            subtile_d128<MASK, WANT_DX, false, UU * CBF + 8192>(p, smem, 0, nA + 32, xb, U, lsum, a0, t0, h, tgt, grow, rl); \
+            /* buffer (UU+3)&3 held chunk cc+UU-1, which every wave has finished: refill it */                       \
+            if (cc + UU + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((UU + 3) & 3) * CBF, wave_u, lane_off); \
+            subtile16_d128<false, UU * CBF>(smem, 0, nA, p.N, xb, U, lsum, a0, t0, g);                               \
+            subtile16_d128<false, UU * CBF + 8192>(smem, 0, nA + 32, p.N, xb, U, lsum, a0, t0, g);                   \
         }
         PCVAE_RING_STEP(0)
         PCVAE_RING_STEP(1)
@@ -526,13 +529,13 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
 #undef PCVAE_RING_STEP
     }
     // ---- remaining full chunks: drain the ring (vmcnt(0)), runtime offsets
-    for (; c < n_full; ++c) {
-        const int64_t nA = nbase + (int64_t)c * BNF;
+    for (; cc < n_full; ++cc) {
+        const int64_t nA = nbase + (int64_t)cc * BNF;
         PCVAE_SEAM(0);
-        if (c + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((c + 3) & 3) * CBF, wave_u, lane_off);
-        const int boff = (c & 3) * CBF;
-        subtile_d128<MASK, WANT_DX, false, 0>(p, smem, boff, nA, xb, U, lsum, a0, t0, h, tgt, grow, rl);
-        subtile_d128<MASK, WANT_DX, false, 8192>(p, smem, boff, nA + 32, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+        if (cc + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((cc + 3) & 3) * CBF, wave_u, lane_off);
+        const int boff = (cc & 3) * CBF;
+        subtile16_d128<false, 0>(smem, boff, nA, p.N, xb, U, lsum, a0, t0, g);
+        subtile16_d128<false, 8192>(smem, boff, nA + 32, p.N, xb, U, lsum, a0, t0, g);
     }
 #undef PCVAE_SEAM
     // ---- tail: short / ragged chunks (at most a few subtiles), staged synchronously with clamped addresses
@@ -542,22 +545,23 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
         __syncthreads();
         const int nsub = min(4, t_end - t);
         for (int st = 0; st < nsub; ++st)
-            subtile_d128<MASK, WANT_DX, true, 0>(p, smem, st * 8192, (int64_t)(t + st) * 32, xb, U, lsum, a0, t0, h, tgt, grow, rl);
+            subtile16_d128<true, 0>(smem, st * 8192, (int64_t)(t + st) * 32, p.N, xb, U, lsum, a0, t0, g);
     }
 
-    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-    if (row_ok) {
-        const int64_t o = (int64_t)split * p.R + r;
-        if (h == 0) { p.pm[o] = 0.f; p.pl[o] = ltot; }
-        if (WANT_DX) {
+    // row 16 ct + c: its sum is spread over the four lane groups g
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+    for (int ct = 0; ct < 2; ++ct) {
+        float l = lsum[ct];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int64_t r = rw + 16 * ct + c;
+        if (r < p.R) {
+            const int64_t o = (int64_t)split * p.R + r;
+            if (g == 0) { p.pm[o] = 0.f; p.pl[o] = l; }
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int d0 = b * 32 + 8 * qq + 4 * h;
-                    *reinterpret_cast<float4*>(p.pU + o * D + d0) =
-                        make_float4(U[b][4 * qq], U[b][4 * qq + 1], U[b][4 * qq + 2], U[b][4 * qq + 3]);
-                }
+            for (int dt = 0; dt < 8; ++dt)  // U[dt][ct][reg] = U^T[d = 16 dt + 4 g + reg][r]
+                *reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g) =
+                    make_float4(U[dt][ct][0], U[dt][ct][1], U[dt][ct][2], U[dt][ct][3]);
         }
     }
 }
@@ -625,29 +629,20 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
     if (D == 128) {
         // row blocks with a small logit bound run the max-free kernel, the others the lazy-max kernel;
         // both launches cover the whole grid and each workgroup exits at once if the other kernel owns it
-        hipLaunchKernelGGL((catalog_row_bound_kernel<D>), dim3((unsigned)p.nrb), dim3(256), 0, st, p.rx, p.R, e_max_norm,
-                           flags);
+        // masked / loss-only calls (validation, n_neg < N) all take the lazy-max kernel
+        const bool fast_ok = (mask_mode == MASK_NONE) && want_dx;
+        hipLaunchKernelGGL((catalog_row_bound_kernel<D>), dim3((unsigned)p.nrb), dim3(256), 0, st, p.rx, p.R,
+                           fast_ok ? e_max_norm : 0.f, flags);
         p.safe_flags = flags;
-#define PCVAE_CEF(MASKV, DXV)                                                                                    \
-    do {                                                                                                         \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_d128_fast_kernel<MASKV, DXV>),   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
-        hipLaunchKernelGGL((catalog_ce_bf16_d128_fast_kernel<MASKV, DXV>), grid, block, lds, st, p);             \
-    } while (0)
-        if (want_dx) {
-            if (mask_mode == MASK_NONE) PCVAE_CEF(MASK_NONE, true);
-            else if (mask_mode == MASK_PHILOX) PCVAE_CEF(MASK_PHILOX, true);
-            else PCVAE_CEF(MASK_BYTES, true);
-        } else {
-            if (mask_mode == MASK_NONE) PCVAE_CEF(MASK_NONE, false);
-            else if (mask_mode == MASK_PHILOX) PCVAE_CEF(MASK_PHILOX, false);
-            else PCVAE_CEF(MASK_BYTES, false);
+        if (fast_ok) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_d128_fast_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(catalog_ce_bf16_d128_fast_kernel, grid, block, lds, st, p);
         }
-#undef PCVAE_CEF
         int rc0 = check_launch("catalog_ce_bf16_fast");
         if (rc0 != PCVAE_OK) return rc0;
     }

@@ -70,7 +70,10 @@ def test_bf16_ce_matches_its_own_arithmetic(ops, R, N, D):
     torch.testing.assert_close(nll.cpu(), wn, rtol=2e-5, atol=3e-5)
     assert (dx.cpu() - wd).abs().max() < 4e-3 * wd.abs().max()
     nll2, _, none = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), prec=PREC_BF16, want_dx=False)
-    assert none is None and torch.equal(nll2, nll)
+    # the loss-only call runs the lazy-max kernel (32x32x16 MFMA), the training call the max-free 16x16x32 kernel:
+    # same bf16 operands, different fp32 summation order
+    assert none is None
+    torch.testing.assert_close(nll2, nll, rtol=2e-5, atol=3e-5)
 
 
 @pytest.mark.parametrize("R,N,D", [(70, 1000, 64), (300, 4099, 128)])

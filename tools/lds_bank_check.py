@@ -67,6 +67,34 @@ def check(D):
     return worst_row == 1 and worst_tr == 1
 
 
+
+
+# ---- 16x16x32 MFMA variant of the fast kernel (catalog_ce_bf16_d128_fast16_kernel) --------------------------------
+def check16(D=128, chunk_of=lambda s, g: 4 * g + s):
+    """lane l: c = l & 15, g = l >> 4.  Row reads: row nb + 16*rt + c, 16-B chunk chunk_of(s, g).  Transposed reads:
+    rows nb + 16*lohi + 4*g + q, cols 16*dt + 4*pp (q = c >> 2, pp = c & 3)."""
+    worst_row, worst_tr = 1, 1
+    for nb in (0, 32):
+        for rt in range(2):
+            for s in range(4):
+                addr = {l: lds_off(D, nb + 16 * rt + (l & 15), 8 * chunk_of(s, l >> 4)) for l in range(64)}
+                for grp in B128_GROUPS:
+                    worst_row = max(worst_row, conflicts([addr[l] for l in grp], 16))
+        for dt in range(D // 16):
+            for lohi in range(2):
+                addr = {}
+                for l in range(64):
+                    c, g = l & 15, l >> 4
+                    q, pp = c >> 2, c & 3
+                    addr[l] = lds_off(D, nb + 16 * lohi + 4 * g + q, 16 * dt + 4 * pp)
+                for half in (range(32), range(32, 64)):
+                    worst_tr = max(worst_tr, conflicts([addr[l] for l in half], 8))
+    print(f"16x16x32 variant, D={D}: b128 row read worst {worst_row}-way, tr_b16 read worst {worst_tr}-way")
+    return worst_row == 1 and worst_tr == 1
+
+
 if __name__ == "__main__":
     ok = all([check(D) for D in (64, 128, 256)])
+    check16(128, lambda s, g: 4 * s + g)            # natural chunk order: 2-way conflicts on the row reads
+    ok = check16(128, lambda s, g: 4 * g + s) and ok  # lane group g walks chunks 4g..4g+3: conflict-free
     sys.exit(0 if ok else 1)
