@@ -148,3 +148,11 @@ def test_flat_adam_views_keep_names_and_storage():
     assert opt.flat.numel() == n == opt.grad.numel()
     p0 = next(p for p in m.parameters() if p.requires_grad)
     assert p0.data_ptr() == opt.flat.data_ptr() and p0.grad.data_ptr() == opt.grad.data_ptr()
+
+
+def test_lds_bank_model_of_the_catalog_kernels():
+    """tools/lds_bank_check.py: the swizzled LDS image is conflict-free for the row reads and the transposed reads of both
+    MFMA shapes, the swizzle is an involution and the global_load_lds lane map covers the image exactly once."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lds_bank_check.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr

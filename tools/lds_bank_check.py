@@ -12,8 +12,8 @@ B128_GROUPS += [[l + 32 for l in g] for g in B128_GROUPS]
 
 
 def swz_chunk(D, row, c):
-    if D >= 128:
-        return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+    if D >= 128:  # low field = 2-bit reversal of (row >> 2) & 3 (same as swz_chunk<D> in catalog_bf16.hip)
+        return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1)))
     return c ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))
 
 
