@@ -40,7 +40,9 @@ extern "C" {
 /* catalog precision modes (arithmetic the [R,D]x[D,N] contraction is computed in) */
 #define PCVAE_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact k-ordered fmaf chain (bit-exact ids) */
 #define PCVAE_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16 on a bf16 copy of the table, fp32 accumulate */
-#define PCVAE_PREC_BF16X3 2 /* split-bf16 (hi+lo) 3-product emulation of fp32 on the bf16 MFMA pipe */
+#define PCVAE_PREC_BF16X3 2 /* split-bf16 (hi+lo) 3-product emulation of fp32 on the bf16 MFMA pipe (reserved) */
+#define PCVAE_PREC_SCREENED 3 /* argmax only: bf16 MFMA screening + exact fp32 rescoring of the few candidates;
+                                results identical to PCVAE_PREC_F32 (E = bf16 table, E_lo = fp32 table, D = 128) */
 
 typedef void* pcvae_stream_t;
 
@@ -154,7 +156,7 @@ int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo
 /* K6  fused catalog argmax (greedy decode)              models/cvae.py:97-101 ; models/pivotcvae.py:191
  *     idx[r] = first n maximising <x_r, E_n>  (torch.max tie rule: lowest index)                 */
 int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
-                         int64_t* idx, float* best, void* ws, size_t ws_bytes, pcvae_stream_t stream);
+                         float e_max_norm, int64_t* idx, float* best, void* ws, size_t ws_bytes, pcvae_stream_t stream);
 
 /* K10 sampled pivot                                     models/pivotcvae.py:349-351, 371-373
  *     idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) over the whole catalog, drawn with the Gumbel-max trick

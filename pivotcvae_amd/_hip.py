@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCVAE_LIB") or os.path.join(_HERE, "lib", "libpcvae_hip.so")
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
-PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_SCREENED = 0, 1, 2, 3
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
 _c = ctypes
@@ -43,7 +43,7 @@ SIGNATURES = {
     "pcvae_sum": [_P, _L, _F, _P, _P],
     "pcvae_catalog_ws_bytes": [_L, _L, _I, _I],
     "pcvae_catalog_ce": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _F, _U64, _U64, _P, _P, _P, _P, _P, _SZ, _P],
-    "pcvae_catalog_argmax": [_P, _L, _P, _P, _L, _I, _I, _P, _P, _P, _SZ, _P],
+    "pcvae_catalog_argmax": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_sample": [_P, _L, _P, _P, _L, _I, _I, _U64, _U64, _P, _P, _SZ, _P],
     "pcvae_split_bf16": [_P, _L, _P, _P, _P],
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],

@@ -16,6 +16,7 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
         const size_t am = (rows + 1) * sizeof(float) + rows * sizeof(int64_t) + 16;
         need = std::max(need, std::max(ce, am) + (size_t)pl.nrb + 64);
     }
+    need = std::max(need, (size_t)R * (8 + 4 + 4 + 64 * 4) + 64);  // screened argmax: keys, thresholds, <= 64 partial maxima
     return need + 256;
 }
 
@@ -50,7 +51,7 @@ extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const
 }
 
 static int argmax_common(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
-                         bool sample, uint64_t seed, uint64_t row_offset, int64_t* idx, float* best, void* ws,
+                         float e_max_norm, bool sample, uint64_t seed, uint64_t row_offset, int64_t* idx, float* best, void* ws,
                          size_t ws_bytes, pcvae_stream_t stream) {
     PCVAE_REQUIRE(x && E && idx && ws, "catalog_argmax: null pointer");
     PCVAE_REQUIRE(R > 0 && N > 0, "catalog_argmax: empty problem R=%lld N=%lld", (long long)R, (long long)N);
@@ -66,18 +67,24 @@ static int argmax_common(const float* x, int64_t R, const void* E, const void* E
         return catalog_argmax_f32(x, R, reinterpret_cast<const float*>(E), N, D, sample, seed, row_offset, idx, best,
                                   ws, as_stream(stream));
     }
+    if (prec == PCVAE_PREC_SCREENED) {
+        PCVAE_REQUIRE(D == 128 && !sample && E_lo && e_max_norm > 0.f && N < 0xffffffffLL && R < 0xffffffffLL && ((uintptr_t)E_lo % 16 == 0),
+                      "catalog_argmax(screened): needs D=128, the fp32 table in E_lo, e_max_norm > 0 and N < 2^32");
+        return catalog_argmax_screened_d128(x, R, reinterpret_cast<const uint16_t*>(E), reinterpret_cast<const float*>(E_lo),
+                                            N, e_max_norm, idx, best, ws, as_stream(stream));
+    }
     set_error("catalog_argmax: precision mode %d not available in this build", prec);
     return PCVAE_EINVAL;
 }
 
 extern "C" int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
-                                    int prec, int64_t* idx, float* best, void* ws, size_t ws_bytes,
+                                    int prec, float e_max_norm, int64_t* idx, float* best, void* ws, size_t ws_bytes,
                                     pcvae_stream_t stream) {
-    return argmax_common(x, R, E, E_lo, N, D, prec, false, 0, 0, idx, best, ws, ws_bytes, stream);
+    return argmax_common(x, R, E, E_lo, N, D, prec, e_max_norm, false, 0, 0, idx, best, ws, ws_bytes, stream);
 }
 
 extern "C" int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
                                     int prec, uint64_t seed, uint64_t row_offset, int64_t* idx, void* ws,
                                     size_t ws_bytes, pcvae_stream_t stream) {
-    return argmax_common(x, R, E, E_lo, N, D, prec, true, seed, row_offset, idx, nullptr, ws, ws_bytes, stream);
+    return argmax_common(x, R, E, E_lo, N, D, prec, 0.f, true, seed, row_offset, idx, nullptr, ws, ws_bytes, stream);
 }

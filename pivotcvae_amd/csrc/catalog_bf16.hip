@@ -673,6 +673,258 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
     return check_launch("catalog_ce_merge_bf16");
 }
 
+// =============================================================================================
+// K6 at bf16 speed with EXACT fp32 results ("screened" argmax), D = 128.
+//
+// The greedy item id must be bit-exact against the fp32 arithmetic (k-ordered fmaf chain, lowest index on ties), but
+// the exact f32-MFMA kernel runs at 1/16 of the bf16 rate.  Two bf16 passes over the catalog give the same answer:
+//   bound   approximate scores s~_n = <bf16(x), bf16(E_n)> (fp32 accumulate) satisfy |s~_n - s_n| <= eps_r :=
+//           (2^-8 * 1.02 + 2e-5) * ||x_r|| * max_n ||E_n||  (two RNE roundings of 2^-9 each per product, Cauchy-Schwarz
+//           over k, fp32 accumulation slack).  With m~ = max_n s~_n every exact maximiser n* has
+//           s~_{n*} >= s_{n*} - eps >= s_{n~} - eps >= m~ - 2 eps, and the same holds for any LOWER bound of m~.
+//   pass A  m0_r = max of s~ over a PREFIX of the catalog (N/16 items; the whole catalog when it is small): a lower
+//           bound of m~ that is already within a handful of items of it.
+//   pass B  one full bf16 pass; every item with s~_n >= max(m0_r, lane-local running max) - 2 eps is a candidate
+//           (~10-20 per row of 10^6): its EXACT score is computed on the spot as the k-ordered fmaf chain over the
+//           fp32 table - the same chain v_mfma_f32_32x32x2_f32 and oracle/catalog_oracle.c evaluate - and folded into
+//           best[r] with a 64-bit atomicMax on (ordered score bits << 32 | ~n): largest score, then lowest index.
+// Result: ids and winning scores identical to catalog_argmax_f32_kernel at several times its speed
+// (an adversarially ordered catalog only costs time - more candidates - never correctness).
+// =============================================================================================
+struct ScreenParams {
+    const float* x;        // [R, 128] fp32
+    const uint16_t* Eb;    // [N, 128] bf16 bits
+    const float* Ef;       // [N, 128] fp32 (exact rescoring)
+    int64_t R, N;
+    int nrb, nsplit, tiles_per_split, ntiles;
+    float* pm;                       // [nsplit][R] approximate maxima (pass A)
+    float* thr;                      // [R] m~ - 2 eps
+    float* eps2;                     // [R] 2 eps
+    unsigned long long* best_key;    // [R]
+    float e_max_norm;
+};
+
+__device__ __forceinline__ unsigned int ordered_bits(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float unordered_bits(unsigned int o) {
+    return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
+}
+
+// logits of one 32-item subtile (16x16x32 layout of the fast kernel), no log2(e) scaling
+template <bool CHECK_N, int OFF>
+__device__ __forceinline__ void screen_logits(const char* smem, const int off, const int64_t n0, const int64_t N,
+                                              const bf16x8 (&xb)[2][4], f32x4 (&acc)[2][2], const int a0, const int g) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[rt][ct][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 4)) + off + (OFF + rt * 4096)));
+            acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[0][s], acc[rt][0], 0, 0, 0);
+            acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[1][s], acc[rt][1], 0, 0, 0);
+        }
+    if (CHECK_N) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + 16 * rt + 4 * g + i >= N) { acc[rt][0][i] = -INFINITY; acc[rt][1][i] = -INFINITY; }
+    }
+}
+
+// exact fp32 score of (row, n) - k-ordered fmaf chain - folded into best_key[row]
+__device__ __forceinline__ void screen_rescore(const ScreenParams& p, const int64_t row, const int64_t n) {
+    const float4* e = reinterpret_cast<const float4*>(p.Ef + n * 128);
+    const float4* xr = reinterpret_cast<const float4*>(p.x + row * 128);
+    float sc = 0.f;
+#pragma unroll 1
+    for (int k = 0; k < 32; k += 8) {  // 16 independent 16-byte loads in flight, then 32 fmaf
+        float4 ev[8], xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ev[j] = e[k + j]; xv[j] = xr[k + j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sc = fmaf(ev[j].x, xv[j].x, sc); sc = fmaf(ev[j].y, xv[j].y, sc);
+            sc = fmaf(ev[j].z, xv[j].z, sc); sc = fmaf(ev[j].w, xv[j].w, sc);
+        }
+    }
+    const unsigned long long key =
+        ((unsigned long long)ordered_bits(sc) << 32) | (unsigned long long)(0xffffffffu - (unsigned int)n);
+    atomicMax(p.best_key + row, key);
+}
+
+// Candidates are parked in an LDS list (one ds_add_rtn + one ds_write) and rescored by the whole workgroup after the
+// catalog range is done: an inline rescoring stalls its wave for microseconds and, through the per-chunk barrier, the
+// seven other waves with it.  A full list degrades to inline rescoring (slow, still exact).
+constexpr int SCREEN_CAND_CAP = 3072;
+constexpr int SCREEN_LDS_BYTES = 4 * CBF + SCREEN_CAND_CAP * 8 + 16;
+
+template <int PASS, bool CHECK_N, int OFF>
+__device__ __forceinline__ void screen_subtile(const ScreenParams& p, char* smem, const int off, const int64_t n0,
+                                               const bf16x8 (&xb)[2][4], float (&m)[2], float (&thr)[2],
+                                               const float (&eps2)[2], const int64_t (&row)[2], const int a0,
+                                               const int g) {
+    f32x4 acc[2][2];
+    screen_logits<CHECK_N, OFF>(smem, off, n0, p.N, xb, acc, a0, g);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        float v = fmaxf(fmaxf(acc[0][ct][0], acc[0][ct][1]), fmaxf(acc[0][ct][2], acc[0][ct][3]));
+        v = fmaxf(v, fmaxf(fmaxf(acc[1][ct][0], acc[1][ct][1]), fmaxf(acc[1][ct][2], acc[1][ct][3])));
+        if (PASS == 0) {
+            m[ct] = fmaxf(m[ct], v);
+        } else if (v >= thr[ct]) {
+            unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + 4 * CBF + SCREEN_CAND_CAP * 8);
+            uint2* list = reinterpret_cast<uint2*>(smem + 4 * CBF);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (acc[rt][ct][i] >= thr[ct]) {
+                        const int64_t n = n0 + 16 * rt + 4 * g + i;
+                        const unsigned int slot = atomicAdd(cnt, 1u);
+                        if (slot < (unsigned)SCREEN_CAND_CAP) list[slot] = make_uint2((unsigned int)row[ct], (unsigned int)n);
+                        else screen_rescore(p, row[ct], n);
+                    }
+            // everything this lane meets later only matters if it comes within 2 eps of what it has already seen
+            thr[ct] = fmaxf(thr[ct], v - eps2[ct]);
+        }
+    }
+}
+
+template <int PASS>
+__global__ void __launch_bounds__(512, 1) catalog_screen_bf16_d128_kernel(ScreenParams p) {
+    constexpr int D = 128;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / p.nrb, rb = logical % p.nrb;
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int64_t nbase = (int64_t)t_beg * 32;
+    const int n_half = (t_end - t_beg + 1) / 2;
+    int n_full = (int)min((int64_t)n_half, (p.N - nbase) / BNF);
+    n_full = max(n_full, 0);
+    const int64_t rw = (int64_t)rb * ROWS_WG + wave * 32;
+    if (PASS == 1) {
+        if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(smem + 4 * CBF + SCREEN_CAND_CAP * 8) = 0u;
+        __syncthreads();
+    }
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int lane_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rr = (lane >> 4) | (((2 * (wave & 1) + i) & 3) << 2);
+        lane_off[i] = (lane >> 4) * 256 + (swz_chunk<128>(rr, lane & 15) << 4);
+    }
+#pragma unroll
+    for (int c0 = 0; c0 < 3; ++c0)
+        if (c0 < n_full) stage_chunk_f(p.Eb, nbase + (int64_t)c0 * BNF, smem + c0 * CBF, wave_u, lane_off);
+
+    bf16x8 xb[2][4];
+    int64_t row[2];
+    float thr[2] = {INFINITY, INFINITY}, eps2[2] = {0.f, 0.f}, m[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int64_t r = rw + 16 * ct + c;
+        row[ct] = r < p.R ? r : p.R - 1;
+        if (PASS == 1 && r < p.R) { thr[ct] = p.thr[r]; eps2[ct] = p.eps2[r]; }  // padding rows: never a candidate
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.x + row[ct] * D + 8 * (4 * g + s));
+            const float4 v1 = *reinterpret_cast<const float4*>(p.x + row[ct] * D + 8 * (4 * g + s) + 4);
+            xb[ct][s][0] = (__bf16)v0.x; xb[ct][s][1] = (__bf16)v0.y; xb[ct][s][2] = (__bf16)v0.z; xb[ct][s][3] = (__bf16)v0.w;
+            xb[ct][s][4] = (__bf16)v1.x; xb[ct][s][5] = (__bf16)v1.y; xb[ct][s][6] = (__bf16)v1.z; xb[ct][s][7] = (__bf16)v1.w;
+        }
+    }
+    const int wr = ((c & 3) << 2) | (((c >> 2) & 1) << 1) | ((c >> 3) & 1);
+    const int a0 = c * 256 + (((4 * g) ^ wr) << 4);
+
+#define PCVAE_SEAM(VMCNT) asm volatile("s_waitcnt vmcnt(" #VMCNT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    int cc = 0;
+    const int n_pipe = n_full >= 3 ? n_full - 2 : 0;
+    for (; cc + 4 <= n_pipe; cc += 4) {
+#define PCVAE_RING_STEP(UU)                                                                                          \
+        {                                                                                                            \
+            const int64_t nA = nbase + (int64_t)(cc + UU) * BNF;                                                     \
+            PCVAE_SEAM(4);                                                                                           \
+            if (cc + UU + 3 < n_full) stage_chunk_f(p.Eb, nA + 3 * BNF, smem + ((UU + 3) & 3) * CBF, wave_u, lane_off); \
+            screen_subtile<PASS, false, UU * CBF>(p, smem, 0, nA, xb, m, thr, eps2, row, a0, g);                           \
+            screen_subtile<PASS, false, UU * CBF + 8192>(p, smem, 0, nA + 32, xb, m, thr, eps2, row, a0, g);               \
+        }
+        PCVAE_RING_STEP(0)
+        PCVAE_RING_STEP(1)
+        PCVAE_RING_STEP(2)
+        PCVAE_RING_STEP(3)
+#undef PCVAE_RING_STEP
+    }
+    for (; cc < n_full; ++cc) {
+        const int64_t nA = nbase + (int64_t)cc * BNF;
+        PCVAE_SEAM(0);
+        if (cc + 3 < n_full) stage_chunk_f(p.Eb, nA + 3 * BNF, smem + ((cc + 3) & 3) * CBF, wave_u, lane_off);
+        const int boff = (cc & 3) * CBF;
+        screen_subtile<PASS, false, 0>(p, smem, boff, nA, xb, m, thr, eps2, row, a0, g);
+        screen_subtile<PASS, false, 8192>(p, smem, boff, nA + 32, xb, m, thr, eps2, row, a0, g);
+    }
+#undef PCVAE_SEAM
+    for (int t = t_beg + 2 * n_full; t < t_end; t += 4) {
+        __syncthreads();
+        stage_chunk<D>(p.Eb, p.N, (int64_t)t * 32, smem);
+        __syncthreads();
+        const int nsub = min(4, t_end - t);
+        for (int st = 0; st < nsub; ++st)
+            screen_subtile<PASS, true, 0>(p, smem, st * 8192, (int64_t)(t + st) * 32, xb, m, thr, eps2, row, a0, g);
+    }
+    if (PASS == 1) {  // rescore the parked candidates, one per thread
+        __syncthreads();
+        const unsigned int cnt =
+            min(*reinterpret_cast<const unsigned int*>(smem + 4 * CBF + SCREEN_CAND_CAP * 8), (unsigned)SCREEN_CAND_CAP);
+        const uint2* list = reinterpret_cast<const uint2*>(smem + 4 * CBF);
+        for (unsigned int j = threadIdx.x; j < cnt; j += 512) screen_rescore(p, (int64_t)list[j].x, (int64_t)list[j].y);
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float v = m[ct];
+            v = fmaxf(v, __shfl_xor(v, 16, 64));
+            v = fmaxf(v, __shfl_xor(v, 32, 64));
+            const int64_t r = rw + 16 * ct + c;
+            if (g == 0 && r < p.R) p.pm[(int64_t)split * p.R + r] = v;
+        }
+    }
+}
+
+// after pass A: thr[r] = max_j pm[j][r] - 2 eps_r ; best_key[r] = 0.  pass A may have seen only a PREFIX of the catalog:
+// any lower bound of the full approximate maximum m~ is a valid threshold base (more candidates, same answer).
+__global__ void catalog_screen_threshold_kernel(ScreenParams p) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.R) return;
+    float mm = -INFINITY;
+    for (int j = 0; j < p.nsplit; ++j) mm = fmaxf(mm, p.pm[(int64_t)j * p.R + r]);
+    float ss = 0.f;
+    for (int k = 0; k < 128; ++k) ss = fmaf(p.x[r * 128 + k], p.x[r * 128 + k], ss);
+    const float eps = (0.00390625f * 1.02f + 2e-5f) * sqrtf(ss) * p.e_max_norm;
+    p.thr[r] = mm - 2.f * eps - 1e-30f;
+    p.eps2[r] = 2.f * eps + 1e-30f;
+    p.best_key[r] = 0ull;
+}
+
+__global__ void catalog_screen_decode_kernel(ScreenParams p, int64_t* __restrict__ idx, float* __restrict__ best) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.R) return;
+    const unsigned long long key = p.best_key[r];
+    idx[r] = (int64_t)(0xffffffffu - (unsigned int)(key & 0xffffffffull));
+    if (best) best[r] = unordered_bits((unsigned int)(key >> 32));
+}
+
 }  // namespace
 
 namespace pcvae {
@@ -704,6 +956,38 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
     }
     set_error("catalog_ce(bf16): unsupported D=%d (64, 128, 256; smaller tables use the f32 kernel)", D);
     return PCVAE_EINVAL;
+}
+
+int catalog_argmax_screened_d128(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, float e_max_norm,
+                                 int64_t* idx, float* best, void* ws, hipStream_t st) {
+    // pass A over a prefix of the catalog is enough to seed the threshold: with N/16 items the expected number of
+    // later items above the prefix maximum is ~16 per row (plus the lane-local running maximum in pass B), each
+    // costing one 128-term fmaf chain - far cheaper than a second full bf16 pass.
+    const int64_t Ns = N >= 262144 ? (N / 16) / 128 * 128 : N;
+    const CatalogPlan pa = catalog_plan(R, Ns, 128, PCVAE_PREC_BF16), pb = catalog_plan(R, N, 128, PCVAE_PREC_BF16);
+    ScreenParams p{};
+    p.x = x; p.Eb = Eb; p.Ef = Ef; p.R = R; p.e_max_norm = e_max_norm;
+    p.best_key = reinterpret_cast<unsigned long long*>(ws);  // 8-byte atomics: keep first (ws is 16-byte aligned)
+    p.thr = reinterpret_cast<float*>(p.best_key + R);
+    p.eps2 = p.thr + R;
+    p.pm = p.eps2 + R;   // [nsplit(A) <= 64][R]
+    const size_t lds = SCREEN_LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_d128_kernel<0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_d128_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const dim3 block(512);
+    p.N = Ns; p.nrb = pa.nrb; p.nsplit = pa.nsplit; p.tiles_per_split = pa.tiles_per_split; p.ntiles = pa.ntiles;
+    hipLaunchKernelGGL(catalog_screen_bf16_d128_kernel<0>, dim3((unsigned)(pa.nrb * pa.nsplit)), block, lds, st, p);
+    hipLaunchKernelGGL(catalog_screen_threshold_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, p);
+    p.N = N; p.nrb = pb.nrb; p.nsplit = pb.nsplit; p.tiles_per_split = pb.tiles_per_split; p.ntiles = pb.ntiles;
+    hipLaunchKernelGGL(catalog_screen_bf16_d128_kernel<1>, dim3((unsigned)(pb.nrb * pb.nsplit)), block, lds, st, p);
+    hipLaunchKernelGGL(catalog_screen_decode_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, p, idx, best);
+    return check_launch("catalog_argmax_screened");
 }
 
 }  // namespace pcvae

@@ -50,6 +50,8 @@ int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D,
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
                     const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, hipStream_t st);
+int catalog_argmax_screened_d128(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, float e_max_norm,
+                                 int64_t* idx, float* best, void* ws, hipStream_t st);
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,
                        uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st);
 

@@ -155,3 +155,31 @@ def test_model_level_bf16_elbo(ops):
         if grads.get(k) is not None:
             gs = grads[k].abs().max()
             assert (prm.grad.cpu() - grads[k]).abs().max() < 3e-2 * gs + 1e-6, k
+
+
+def test_model_recommend_screened_ids_identical(ops, monkeypatch):
+    """recommend() at D=128 over a catalog large enough for the bf16-screened argmax: pivot + slot ids are identical to
+    the ones of the plain f32-MFMA argmax (itself bit-exact against oracle/catalog_oracle.c), for a pi and a pt model."""
+    import pivotcvae_amd as pa
+    S, D, Z, N, NU, B, H, HP = 5, 128, 8, 40000, 40, 96, 64, 32
+    C = S + 1
+    torch.manual_seed(0)
+    e_raw, u_raw = orc.synthetic_tables(N, NU, D, seed=0)
+    st = dict(enc=[S * D + C + D, H, H], psm=[Z + C + D, H, H, D], scm=[Z + C + 2 * D, H, H, (S - 1) * D],
+              prior=[C + D, HP, HP])
+    g = torch.Generator().manual_seed(1)
+    u = torch.randint(0, NU, (B, 1), generator=g).to(DEV)
+    r = (torch.rand(B, S, generator=g) < 0.5).float().to(DEV)
+    eps = torch.randn(B, Z, generator=g).to(DEV)
+    assert N >= ops.SCREENED_MIN_ITEMS
+    for name in ("pivotcvae_gt_pi", "pivotcvae_pt_pi"):
+        m = pa.PIVOTCVAE_MODELS[name](torch.nn.Embedding.from_pretrained(e_raw), torch.nn.Embedding.from_pretrained(u_raw),
+                                      S, D, Z, C, st["enc"], st["psm"], st["scm"], st["prior"], False, DEV)
+        m.set_catalog_precision("bf16")  # the loss precision must not leak into the ids
+        with torch.no_grad():
+            items_s, _ = m.recommend(r, u, return_item=True, eps=eps)
+            monkeypatch.setattr(ops, "SCREENED_MIN_ITEMS", 1 << 62)
+            items_f, _ = m.recommend(r, u, return_item=True, eps=eps)
+            monkeypatch.undo()
+        assert items_s.dtype == torch.int64 and items_s.numel() == B * S
+        assert torch.equal(items_s, items_f), name

@@ -288,6 +288,54 @@ def test_catalog_argmax_ties_pick_lowest_index(ops):
     assert idx[0] == 7 and idx[1] == 7
 
 
+@pytest.mark.parametrize("R,N", [(1, 32), (37, 1000), (300, 20001), (256, 65536), (513, 131075), (64, 300000)])
+def test_catalog_argmax_screened_bit_exact(ops, R, N):
+    """bf16 screening + exact fp32 rescoring returns the same ids AND the same winning scores as the fp32 chain."""
+    D = 128
+    x, E = rnd(R, D, seed=21, scale=2.0), unit_rows(N, D, seed=22)
+    idx, best = ops.catalog_argmax(x.to(DEV), E.to(DEV), return_best=True, screened=True)
+    wi, wb = co.argmax(x.numpy(), E.numpy())
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(best.cpu().numpy(), wb)
+    idx2 = ops.catalog_argmax(x.to(DEV), E.to(DEV), screened=False)
+    assert torch.equal(idx2, idx)
+
+
+def test_catalog_argmax_screened_near_ties_and_duplicates(ops):
+    """Rows whose bf16 images collide: duplicates (lowest index wins), items that differ by less than one bf16 ulp
+    (the fp32 rescoring must separate them), queries of very different norm, negative-only scores."""
+    N, D = 70000, 128
+    E = unit_rows(N, D, seed=5)
+    dup = [11, 4097, 33000, 69999]
+    E[dup] = E[11].clone()
+    E[500] = E[20000] * (1.0 + 3e-4)          # same bf16 image (almost), slightly larger fp32 score
+    E[60001] = E[123] * (1.0 - 1e-6)
+    x = torch.stack([E[11] * 3.0, E[11] * 1e-3, E[20000] * 2.0, E[123] * 5.0, -E[9] * 4.0, rnd(D, seed=6) * 50.0,
+                     torch.zeros(D)])
+    idx, best = ops.catalog_argmax(x.to(DEV), E.to(DEV), return_best=True, screened=True)
+    wi, wb = co.argmax(x.numpy(), E.numpy())
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(best.cpu().numpy(), wb)
+    assert idx[0] == 11 and idx[1] == 11 and idx[2] == 500 and idx[3] == 123 and idx[6] == 0
+
+
+def test_catalog_argmax_screened_unnormalised_table(ops):
+    """Row norms spread over 3 decades: the bound uses the LARGEST row norm, small rows can still win nothing wrongly."""
+    N, D, R = 50000, 128, 200
+    g = torch.Generator().manual_seed(9)
+    E = torch.randn(N, D, generator=g) * torch.logspace(-2, 1, N)[torch.randperm(N, generator=g)].unsqueeze(1)
+    x = rnd(R, D, seed=10)
+    idx, best = ops.catalog_argmax(x.to(DEV), E.to(DEV), return_best=True, screened=True)
+    wi, wb = co.argmax(x.numpy(), E.numpy())
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(best.cpu().numpy(), wb)
+
+
+def test_catalog_argmax_screened_rejects_other_widths(ops):
+    with pytest.raises(ValueError):
+        ops.catalog_argmax(rnd(4, 64, seed=1).to(DEV), unit_rows(100, 64, seed=2).to(DEV), screened=True)
+
+
 def test_catalog_sample_distribution(ops):
     """Categorical(sigmoid(scores)) by Gumbel-max: empirical frequencies match the probabilities."""
     N, D, R = 40, 16, 20000
