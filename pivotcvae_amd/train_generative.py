@@ -173,7 +173,7 @@ class Trainer:
             loss, rec, kld = st["out"]
         else:
             loss, rec, kld = self._local(s, r, u, eps, row_offset, eps_offset)
-        if W > 1:
+        if self.dist is not None:  # also with a 1-rank group: the collective path is then the one that is exercised
             self.dist.all_reduce(self.opt.grad, group=self.pg)  # SUM: one collective per step
             stats = torch.stack([loss, rec, kld])
             self.dist.all_reduce(stats, group=self.pg)
