@@ -4,9 +4,12 @@
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact fmaf chain), because the
 // parity contract is 1e-4 relative against an fp32 reference.  One 256-thread workgroup = 4 waves
-// (2x2), each wave owns one 32x32 accumulator tile of a 64x64 output tile; K is consumed 16 at a
+// (2x2), each wave owns one 32x32 accumulator tile of a 64x64 output tile; K is consumed 64 at a
 // time through K-MAJOR LDS tiles (row stride 65 floats) so both MFMA operands are fetched with
-// conflict-free ds_read_b32 (lane i reads element i of a k-row).
+// conflict-free ds_read_b32 (lane i reads element i of a k-row).  The layers are small (a rank holds
+// 1024 slates, hidden width 256: 64 workgroups), so a GEMM is a chain of dependent global-load ->
+// LDS -> MFMA rounds rather than a throughput problem: the deep K step keeps 32 loads per thread in
+// flight per round and cuts the number of rounds (K = 1419: 23 instead of 89).
 //
 // One kernel template covers the three layouts of a Linear layer:
 //    forward      Y[M,N]  = X[M,K]  . W[N,K]^T    A k-contiguous, B k-contiguous
@@ -20,7 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 65;
+constexpr int BM = 64, BN = 64, BK = 64, LDT = 65, TPT = BM * BK / 256;  // TPT: tile elements per thread
 
 enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
 
@@ -36,17 +39,18 @@ struct GemmParams {
     int64_t k_per_split;           // EPI_DW: reduction range per blockIdx.z
 };
 
-// Load a 64 x 16 (rows x k) tile of a logical operand P(row, k) into 4 registers per thread.
+// Load a 64 x 64 (rows x k) tile of a logical operand P(row, k) into 16 registers per thread; a wave reads 64
+// consecutive floats of one row (KC) or of one k (!KC) per load.
 //   KC  (k contiguous in memory):   P(row, k) = P[row * ld + k]
 //   !KC (row contiguous in memory): P(row, k) = P[k * ld + row]
 template <bool KC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
-                                          int64_t k0, int64_t kend, float (&v)[4]) {
+                                          int64_t k0, int64_t kend, float (&v)[TPT]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TPT; ++i) {
         int row, k;
-        if (KC) { k = t & 15; row = (t >> 4) + 16 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
+        if (KC) { k = t & 63; row = (t >> 6) + 4 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
         const int64_t gr = row0 + row, gk = k0 + k;
         const bool ok = gr < rows && gk < kend;
         v[i] = ok ? (KC ? P[gr * ld + gk] : P[gk * ld + gr]) : 0.f;
@@ -54,12 +58,12 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t l
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_tile(float* S, const float (&v)[4]) {
+__device__ __forceinline__ void store_tile(float* S, const float (&v)[TPT]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TPT; ++i) {
         int row, k;
-        if (KC) { k = t & 15; row = (t >> 4) + 16 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
+        if (KC) { k = t & 63; row = (t >> 6) + 4 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
         S[k * LDT + row] = v[i];
     }
 }
@@ -89,7 +93,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
     const bool do_bias = (EPI == EPI_DW) && p.bias_grad != nullptr && blockIdx.x == 0 && threadIdx.x < BM;
     float bsum = 0.f;
 
-    float va[4], vb[4];
+    float va[TPT], vb[TPT];
     load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, va);
     load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, vb);
 
@@ -139,6 +143,96 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
     }
 }
 
+// ---- small-M variant ------------------------------------------------------------------------------------------
+// A rank of the data-parallel job holds B/8 = 1024 slates: a [1024 x 256] layer is only 64 tiles of 64 x 64, a quarter
+// of the chip, and each of those workgroups is bound by its own MFMA chain (K = 1419: 23 rounds of 32 MFMAs per wave).
+// Here a workgroup owns a 32 x 32 tile and its four waves split every 64-deep K chunk between them (wave w multiplies
+// k in [16w, 16w + 16)), so the same layer is 256 workgroups with a 4x shorter chain each; the four partial tiles are
+// summed through LDS in a fixed order (wave 0 + 1 + 2 + 3: deterministic).
+constexpr int SM = 32, SLD = 33, STPT = SM * BK / 256;
+
+template <bool KC>
+__device__ __forceinline__ void load_tile_s(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
+                                            int64_t k0, int64_t kend, float (&v)[STPT]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < STPT; ++i) {
+        int row, k;
+        if (KC) { k = t & 63; row = (t >> 6) + 4 * i; } else { row = t & 31; k = (t >> 5) + 8 * i; }
+        const int64_t gr = row0 + row, gk = k0 + k;
+        const bool ok = gr < rows && gk < kend;
+        v[i] = ok ? (KC ? P[gr * ld + gk] : P[gk * ld + gr]) : 0.f;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile_s(float* S, const float (&v)[STPT]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < STPT; ++i) {
+        int row, k;
+        if (KC) { k = t & 63; row = (t >> 6) + 4 * i; } else { row = t & 31; k = (t >> 5) + 8 * i; }
+        S[k * SLD + row] = v[i];
+    }
+}
+
+template <bool A_KC, bool B_KC, int EPI>
+__global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
+    static_assert(EPI == EPI_FWD || EPI == EPI_DX, "the weight-gradient GEMM is already split over workgroups");
+    __shared__ float As[BK * SLD];
+    __shared__ float Bs[BK * SLD];
+    __shared__ float Red[4 * SM * SM];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * SM, n0 = (int64_t)blockIdx.x * SM;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    float va[STPT], vb[STPT];
+    load_tile_s<A_KC>(p.A, p.lda, m0, p.M, 0, p.K, va);
+    load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, 0, p.K, vb);
+    for (int64_t k0 = 0; k0 < p.K; k0 += BK) {
+        __syncthreads();
+        store_tile_s<A_KC>(As, va);
+        store_tile_s<B_KC>(Bs, vb);
+        __syncthreads();
+        if (k0 + BK < p.K) {
+            load_tile_s<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, p.K, va);
+            load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, p.K, vb);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            const int k = wave * (BK / 4) + 2 * s + h;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * SLD + li], Bs[k * SLD + li], acc, 0, 0, 0);
+        }
+    }
+    // partial tiles -> LDS as [wave][row][col]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Red[wave * SM * SM + ((r & 3) + 8 * (r >> 2) + 4 * h) * SM + li] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = threadIdx.x + 256 * i, row = e >> 5, col = e & 31;
+        const int64_t m = m0 + row, n = n0 + col;
+        if (m >= p.M || n >= p.N) continue;
+        float v = ((Red[e] + Red[SM * SM + e]) + Red[2 * SM * SM + e]) + Red[3 * SM * SM + e];
+        if (EPI == EPI_FWD) {
+            if (p.bias) v += p.bias[n];
+            if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
+            else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
+        } else {
+            if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
+        }
+        p.C[m * p.ldc + n] = v;
+    }
+}
+
+// 64 x 64 tiles once they fill the chip, else 32 x 32 tiles with the K chunk split over the waves
+static inline bool use_small_tiles(int64_t M, int64_t N) { return cdiv(M, BM) * cdiv(N, BN) < 256; }
+
 }  // namespace
 
 extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
@@ -150,8 +244,12 @@ extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int
     if (M == 0) return PCVAE_OK;
     PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_fwd: M too large");
     GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, nullptr, 0, act, 0};
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM)),
-                       dim3(256), 0, as_stream(stream), p);
+    if (use_small_tiles(M, N))
+        hipLaunchKernelGGL((gemm_f32_small_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, SM), (unsigned)cdiv(M, SM)),
+                           dim3(256), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM)),
+                           dim3(256), 0, as_stream(stream), p);
     return check_launch("linear_fwd");
 }
 
@@ -165,8 +263,12 @@ extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float
     PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_bwd_input: M too large");
     // C(m, kk) = sum_n dY[m, n] * W[n, kk]:  A = dY (reduction index contiguous), B(kk, n) = W[n * ldw + kk]
     GemmParams p{dY, lddy, W, ldw, dX, lddx, M, K, N, nullptr, nullptr, Xact, ldxa, 0, 0};
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(M, BM)),
-                       dim3(256), 0, as_stream(stream), p);
+    if (use_small_tiles(M, K))
+        hipLaunchKernelGGL((gemm_f32_small_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, SM), (unsigned)cdiv(M, SM)),
+                           dim3(256), 0, as_stream(stream), p);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(M, BM)),
+                           dim3(256), 0, as_stream(stream), p);
     return check_launch("linear_bwd_input");
 }
 
@@ -180,7 +282,7 @@ extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const floa
     // across blockIdx.z so that a [256 x 1419] gradient still fills the chip; partials land with
     // fp32 atomics in the (pre-zeroed, accumulating) gradient buffer.
     const int64_t tiles = cdiv(N, BM) * cdiv(K, BN);
-    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), cdiv(M, 4 * BK)));
+    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), cdiv(M, BK)));
     splits = std::min<int64_t>(splits, 64);
     int64_t kps = cdiv(cdiv(M, splits), BK) * BK;
     splits = cdiv(M, kps);
