@@ -33,6 +33,7 @@ CONFIGS = {
     "2": dict(N=10_000, S=5, D=32, B=1024),
     "3": dict(N=100_000, S=10, D=64, B=4096),
     "4": dict(N=1_000_000, S=10, D=128, B=8192),
+    "5": dict(N=10_000_000, S=20, D=256, B=8192),   # + response-model in-loop evaluation ("eval" block)
 }
 Z, H, HP, N_USER = 16, 256, 128, 10_000
 BETA, LR = 0.001, 3e-4
@@ -71,29 +72,102 @@ def synthetic_batch(cfg, B, device, seed=1):
     return s, r, u
 
 
-def gather_roofline(model, cfg, device):
-    """K1 on its own: the (S+2)*B embedding rows of one step, cold caches, against the 8 TB/s HBM peak."""
+def gather_roofline(model, cfg, device, tables=4):
+    """K1 on its own: the (S+2)*B embedding rows of one step against the 8 TB/s HBM peak, caches cold (512 MB written
+    before every measurement, > the 256 MB Infinity Cache).  `frac` is the average duration of `tables` launches issued
+    back to back between ONE HIP event pair, each launch on its OWN cold table / index set / output (so none re-reads
+    what an earlier one brought in); `single_launch` is one launch between one event pair, which also carries the event
+    pair's own ~2.4 us (an empty kernel: 6.0 us event-to-event, 3.6 us in rocprofv3's trace; tools/gather_probe.hip)."""
     from pivotcvae_amd import ops
     N, S, D, B = cfg["N"], cfg["S"], cfg["D"], cfg["B"]
     g = torch.Generator(device=device).manual_seed(3)
-    idx = torch.randint(0, N, (B * (S + 2),), device=device, generator=g)
-    out = torch.empty(idx.numel(), D, device=device)
+    n_idx = B * (S + 2)
+    tabs = [model.docEmbed.weight] + [torch.rand(N, D, device=device, generator=g) for _ in range(tables - 1)]
+    idxs = [torch.randint(0, N, (n_idx,), device=device, generator=g) for _ in range(tables)]
+    outs = [torch.empty(n_idx, D, device=device) for _ in range(tables)]
     flush = torch.empty(128 * 1024 * 1024, device=device)  # 512 MB > the 256 MB Infinity Cache
-    ts = []
-    for it in range(13):
-        flush.fill_(float(it))
+    nbytes = n_idx * (2 * D * 4 + 8)  # rows read + rows written + int64 indices (SURVEY.md 8d)
+    ms = {}
+    for mode, k in (("single", 1), ("back_to_back", tables)):
+        ts = []
+        for it in range(13):
+            flush.fill_(float(it))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for j in range(k):
+                ops.gather_rows(tabs[j], idxs[j], out=outs[j])
+            e1.record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                ts.append(e0.elapsed_time(e1) / k)
+        ms[mode] = sum(ts) / len(ts)
+    t = ms["back_to_back"]
+    return {"kernel": "gather_rows_vec4_kernel", "bound": "hbm", "achieved": nbytes / (t * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "frac": nbytes / (t * 1e-3) / 8e12, "bytes_per_launch": nbytes, "us_per_launch": t * 1e3,
+            "rows": n_idx, "timed_over": f"{tables} back-to-back launches on {tables} distinct cold tables between one event pair",
+            "single_launch": {"us_per_launch": ms["single"] * 1e3, "achieved": nbytes / (ms["single"] * 1e-3) / 1e9,
+                              "frac": nbytes / (ms["single"] * 1e-3) / 8e12,
+                              "note": "one launch per event pair: includes the pair's own ~2.4 us"},
+            "cache": "cold (512 MB written before every measurement)"}
+
+
+def mlp_roofline(trainer, s, r, u, B, lo, steps=3):
+    """MFMA utilisation of the MLP stacks (K3): every GEMM launch of `steps` eager train steps is bracketed with HIP
+    events on the launch stream; achieved = sum of 2*M*N*K over the launches / sum of their durations, against the
+    dense f32 MFMA peak (the MLPs compute in exact fp32: v_mfma_f32_32x32x2_f32).  The ~2.4 us an event pair costs is
+    inside every duration (launches are 5-90 us), so the figure is a lower bound of what rocprofv3 shows."""
+    from pivotcvae_amd import ops
+    ev = []
+
+    def begin(flops):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.gather_rows(model.docEmbed.weight, idx, out=out)
-        e1.record()
+        return flops, e0, e1
+
+    def end(tok):
+        tok[2].record()
+        ev.append(tok)
+
+    was = trainer.capture_graph
+    trainer.capture_graph = False
+    trainer.step(s, r, u, global_batch=B, row_offset=lo)
+    ops.GEMM_TIMING = (begin, end)
+    try:
+        for _ in range(steps):
+            trainer.step(s, r, u, global_batch=B, row_offset=lo)
         torch.cuda.synchronize()
-        if it >= 3:
-            ts.append(e0.elapsed_time(e1))
-    nbytes = idx.numel() * (2 * D * 4 + 8)  # rows read + rows written + int64 indices (SURVEY.md 8d)
-    ms = sum(ts) / len(ts)
-    return {"kernel": "gather_rows_vec4_kernel", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0,
-            "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 8e12, "bytes_per_launch": nbytes, "us_per_launch": ms * 1e3,
-            "rows": idx.numel(), "cache": "cold (512 MB written between launches)"}
+    finally:
+        ops.GEMM_TIMING = None
+        trainer.capture_graph = was
+    ms = sum(a.elapsed_time(b) for _, a, b in ev)
+    flops = sum(f for f, _, _ in ev)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "gemm_f32_kernel / gemm_f32_small_kernel (all MLP GEMMs of a train step: fwd, input-grad, weight-grad)",
+            "bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["f32"],
+            "launches_per_step": len(ev) // steps, "ms_per_step": ms / steps, "flops_per_step": flops / steps,
+            "note": "PSM stack skipped in gt training (it never receives a gradient: SURVEY 0.7)"}
+
+
+def eval_throughput(model, cfg, device, bs=1024, trials=2):
+    """Config 5: the in-loop evaluation of train_generative.py:169-195 (sample users -> 5 contexts x greedy slates ->
+    click model -> min/mean/max expected clicks), `trials` trials of `bs` users on the device."""
+    from pivotcvae_amd.env.response_model import UserResponseModel_MLP
+    from pivotcvae_amd.train_generative import recommendation_test
+    S, D = cfg["S"], cfg["D"]
+    torch.manual_seed(5)
+    resp = UserResponseModel_MLP(8, N_USER - 1, D, S, [(S + 1) * D, 256, 256, S], device, False)
+    resp.docEmbed = model.docEmbed  # same catalog (the click model's own table is a 10 GB duplicate at N = 10M)
+    resp.maxItemId = cfg["N"] - 1
+    resp = resp.to(device)
+    recommendation_test(model, resp, bs, n_test_trial=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = recommendation_test(model, resp, bs, n_test_trial=trials)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    n_slates = trials * 5 * bs
+    return {"value": n_slates / dt, "unit": "slates/s (generated AND scored)", "seconds": dt, "trials": trials, "users_per_trial": bs,
+            "expected_clicks_min_mean_max_per_context": [[round(float(v), 4) for v in row] for row in stats.cpu()]}
 
 
 def generate_throughput(model, cfg, device, iters=3):
@@ -139,7 +213,8 @@ def generate_throughput(model, cfg, device, iters=3):
 def cpu_baseline_and_parity(model, st, cfg, dtype):
     """Oracle train step on the host cores on a bounded sample + HIP-vs-oracle ELBO on that same sample."""
     from oracle import pivotcvae_oracle as orc
-    Bs = 16  # [Bs*S, N] fp32 logits + its autograd temporaries must fit host RAM: 160 x 1M x 4 B = 640 MB each
+    # [Bs*S, N] fp32 logits + its autograd temporaries must fit host RAM: config 4: 160 x 1M x 4 B = 640 MB each
+    Bs = max(1, min(16, int(160e6 // (cfg["S"] * cfg["N"]))))
     steps = 5
     dev = model.docEmbed.weight.device
     s, r, u = synthetic_batch(cfg, Bs, dev, seed=11)
@@ -153,9 +228,10 @@ def cpu_baseline_and_parity(model, st, cfg, dtype):
     best_t, best_dt = 1, float("inf")
     for th in sorted({min(t, ncpu) for t in (8, 16, 32, 64)}):
         torch.set_num_threads(th)
-        orc.loss_and_grads(sd, ocfg, sc[:4], rc[:4], uc[:4], eps[:4], BETA)
+        q = max(1, Bs // 4)
+        orc.loss_and_grads(sd, ocfg, sc[:q], rc[:q], uc[:q], eps[:q], BETA)
         t0 = time.perf_counter()
-        orc.loss_and_grads(sd, ocfg, sc[:4], rc[:4], uc[:4], eps[:4], BETA)
+        orc.loss_and_grads(sd, ocfg, sc[:q], rc[:q], uc[:q], eps[:q], BETA)
         if time.perf_counter() - t0 < best_dt:
             best_t, best_dt = th, time.perf_counter() - t0
     torch.set_num_threads(best_t)
@@ -191,7 +267,10 @@ def main():
                          "parity with the fp32 oracle is measured live in the 'parity' block) or exact f32 MFMA")
     ap.add_argument("--n_neg", type=int, default=None, help="default: N (full-catalog softmax)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the mlp_roofline / gather_roofline / generate / eval blocks")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay a hipGraph at any batch size (default: only when the "
+                                                         "per-rank batch is <= 2048 slates, where launches dominate)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="override the config's global batch (e.g. 1024 on one GPU = the per-rank load of the 8-GPU run)")
     args = ap.parse_args()
@@ -219,7 +298,11 @@ def main():
     if B % world:
         raise SystemExit("global batch not divisible by the number of GPUs")
     model, st = build_model(cfg, device, args.dtype)
-    trainer = Trainer(model, lr=LR, beta=BETA, n_neg=args.n_neg, capture_graph=not args.no_graph)
+    # hipGraph replay pays off when the step is launch-bound (B/W <= 2048 slates per rank: ~60 launches of 5-30 us);
+    # at a full single-GPU batch the catalog kernel is 96 % of the step and eager launches keep the HIP events that
+    # time it inside the timed region
+    use_graph = (not args.no_graph) and (B // world <= 2048 or args.graph)
+    trainer = Trainer(model, lr=LR, beta=BETA, n_neg=args.n_neg, capture_graph=use_graph)
     s, r, u = synthetic_batch(cfg, B, device)
     (s, r, u), lo = trainer.shard(s, r, u)
     s, r, u = s.contiguous(), r.contiguous(), u.contiguous()
@@ -304,8 +387,12 @@ def main():
         base, parity = cpu_baseline_and_parity(model, st, cfg, args.dtype)
         out["cpu_baseline"] = base
         out["parity"] = parity
-        out["gather_roofline"] = gather_roofline(model, cfg, device)
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["mlp_roofline"] = mlp_roofline(trainer, s, r, u, B, lo)
+        out["gather_roofline"] = gather_roofline(model, cfg, device, tables=4 if N * D * 4 <= (1 << 30) else 2)
         out["generate"] = generate_throughput(model, cfg, device)
+        if args.config == "5":
+            out["eval"] = eval_throughput(model, cfg, device)
     if use_dist:
         dist.destroy_process_group()
     # RCCL writes a version banner through C stdio; push it out first so that the JSON line is the LAST line of stdout

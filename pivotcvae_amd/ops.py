@@ -100,6 +100,20 @@ def concat(parts):
 
 
 # ------------------------------------------------------------------------------------------- K3
+# bench.py sets this to (begin(flops) -> token, end(token)) to bracket every MLP GEMM launch with HIP events on the
+# launch stream (MFMA utilisation of the MLP stacks); None in normal operation
+GEMM_TIMING = None
+
+
+def _timed_gemm(flops, launch):
+    t = GEMM_TIMING
+    if t is None:
+        return launch()
+    tok = t[0](flops)
+    launch()
+    t[1](tok)
+
+
 def linear_fwd_raw(x, W, b, act, out=None):
     x = _c2d(x)
     M, K = x.shape
@@ -108,8 +122,9 @@ def linear_fwd_raw(x, W, b, act, out=None):
         raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {W.shape[1]}x{N})")
     if out is None:
         out = torch.empty(M, N, dtype=F32, device=x.device)
-    check(lib().pcvae_linear_fwd(ptr(x, F32), _ld(x), ptr(W, F32), _ld(W), ptr(b, F32) if b is not None else None,
-                                 ptr(out, F32), _ld(out), M, N, K, act, stream()), "linear_fwd")
+    _timed_gemm(2.0 * M * N * K, lambda: check(
+        lib().pcvae_linear_fwd(ptr(x, F32), _ld(x), ptr(W, F32), _ld(W), ptr(b, F32) if b is not None else None,
+                               ptr(out, F32), _ld(out), M, N, K, act, stream()), "linear_fwd"))
     return out
 
 
@@ -119,10 +134,11 @@ def linear_bwd_input_raw(gy, W, xact=None, out=None):
     K = W.shape[1]
     if out is None:
         out = torch.empty(M, K, dtype=F32, device=gy.device)
-    check(lib().pcvae_linear_bwd_input(ptr(gy, F32), _ld(gy), ptr(W, F32), _ld(W),
-                                       ptr(xact, F32) if xact is not None else None,
-                                       _ld(xact) if xact is not None else 0, ptr(out, F32), _ld(out), M, N, K,
-                                       stream()), "linear_bwd_input")
+    _timed_gemm(2.0 * M * N * K, lambda: check(
+        lib().pcvae_linear_bwd_input(ptr(gy, F32), _ld(gy), ptr(W, F32), _ld(W),
+                                     ptr(xact, F32) if xact is not None else None,
+                                     _ld(xact) if xact is not None else 0, ptr(out, F32), _ld(out), M, N, K,
+                                     stream()), "linear_bwd_input"))
     return out
 
 
@@ -131,9 +147,10 @@ def linear_bwd_weight_raw(gy, x, dW, db):
     gy, x = _c2d(gy), _c2d(x)
     M, N = gy.shape
     K = x.shape[1]
-    check(lib().pcvae_linear_bwd_weight(ptr(gy, F32), _ld(gy), ptr(x, F32), _ld(x), ptr(dW, F32), _ld(dW),
-                                        ptr(db, F32) if db is not None else None, M, N, K, stream()),
-          "linear_bwd_weight")
+    _timed_gemm(2.0 * M * N * K, lambda: check(
+        lib().pcvae_linear_bwd_weight(ptr(gy, F32), _ld(gy), ptr(x, F32), _ld(x), ptr(dW, F32), _ld(dW),
+                                      ptr(db, F32) if db is not None else None, M, N, K, stream()),
+        "linear_bwd_weight"))
 
 
 def leaky_bwd_(g, y):
