@@ -173,7 +173,7 @@ def eval_throughput(model, cfg, device, bs=1024, trials=2):
 def generate_throughput(model, cfg, device, iters=3):
     """Greedy slate generation (recommend(return_item=True)): prior MLP -> z -> PSM -> catalog argmax (pivot) -> SCM ->
     catalog argmax (S slots).  Ids are always the exact fp32 ones (bit-exact against the reference arithmetic); for
-    D = 128 the argmax runs as bf16 MFMA screening + exact fp32 rescoring of the candidates, timed here next to the
+    D in (64, 128, 256) the argmax runs as bf16 MFMA screening + exact fp32 rescoring of the candidates, timed here next to the
     plain f32-MFMA kernel, and both id sets are compared."""
     from pivotcvae_amd import ops
     B, S = cfg["B"], cfg["S"]
@@ -199,7 +199,7 @@ def generate_throughput(model, cfg, device, iters=3):
             res[name] = {"slates_per_s": B / dt, "ms_per_batch": dt * 1e3, "algorithmic_TFLOPs": flops / dt / 1e12}
     finally:
         ops.SCREENED_MIN_ITEMS = saved
-    screened = cfg["D"] == 128 and cfg["N"] >= saved
+    screened = cfg["D"] in ops.BF16_DIMS and cfg["N"] >= saved
     best = res["screened"]
     # the screening pass does the algorithmic 2*R*N*D flops once over the whole catalog (+1/16 for the prefix pass)
     peak = PEAK_TFLOPS["bf16"] if screened else PEAK_TFLOPS["f32"]
@@ -375,7 +375,7 @@ def main():
                    "catalog_arithmetic": args.dtype, "mlp_arithmetic": "f32",
                    "launch": "hipGraph replay (zero-grad+fwd+bwd) + eager all-reduce + Adam" if graphed else "eager"},
         "elbo": {"loss": loss.item(), "recLoss": rec.item(), "KLD": kld.item()},
-        "roofline": {"kernel": (f"catalog_ce_bf16_d128_fast_kernel" if (args.dtype == "bf16" and D == 128) else
+        "roofline": {"kernel": (f"catalog_ce_bf16_fast_kernel<{D}>" if (args.dtype == "bf16" and D in ops.BF16_DIMS) else
                                 f"catalog_ce_{args.dtype}_kernel<{D}>") + " (events also span its row-bound prologue and "
                                "merge kernels, <1% together)", "bound": "mfma",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

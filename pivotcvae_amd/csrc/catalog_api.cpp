@@ -68,10 +68,11 @@ static int argmax_common(const float* x, int64_t R, const void* E, const void* E
                                   ws, as_stream(stream));
     }
     if (prec == PCVAE_PREC_SCREENED) {
-        PCVAE_REQUIRE(D == 128 && !sample && E_lo && e_max_norm > 0.f && N < 0xffffffffLL && R < 0xffffffffLL && ((uintptr_t)E_lo % 16 == 0),
-                      "catalog_argmax(screened): needs D=128, the fp32 table in E_lo, e_max_norm > 0 and N < 2^32");
-        return catalog_argmax_screened_d128(x, R, reinterpret_cast<const uint16_t*>(E), reinterpret_cast<const float*>(E_lo),
-                                            N, e_max_norm, idx, best, ws, as_stream(stream));
+        PCVAE_REQUIRE((D == 64 || D == 128 || D == 256) && !sample && E_lo && e_max_norm > 0.f && N < 0xffffffffLL &&
+                          R < 0xffffffffLL && ((uintptr_t)E_lo % 16 == 0),
+                      "catalog_argmax(screened): needs D in {64,128,256}, the fp32 table in E_lo, e_max_norm > 0 and N < 2^32");
+        return catalog_argmax_screened(x, R, reinterpret_cast<const uint16_t*>(E), reinterpret_cast<const float*>(E_lo),
+                                       N, D, e_max_norm, idx, best, ws, as_stream(stream));
     }
     set_error("catalog_argmax: precision mode %d not available in this build", prec);
     return PCVAE_EINVAL;

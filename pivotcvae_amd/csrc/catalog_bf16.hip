@@ -16,15 +16,17 @@
 //   * logits are produced "swapped" (C[n][r]): a lane holds 16 logits of one row, exp / sum are lane-local, and
 //     the exp2 values converted pairwise to bf16 are, in place, the B operand of U^T[d][r] += E^T[d][n] P[n][r].
 //
-// Three kernels:
-//   catalog_row_bound_kernel          per 256-row block: is ||rx|| * max||E|| * log2(e) <= 90 for every row?
-//   catalog_ce_bf16_d128_fast_kernel  D = 128, blocks that pass: NO running max (every exp2(logit) is a normal fp32
-//                                     number, sums of 10^7 of them stay < 2^114); 4-deep ring of 64-item LDS
-//                                     buffers requested three chunks ahead, counted s_waitcnt vmcnt(4) + raw
-//                                     s_barrier at the seams, all LDS offsets immediates, transposed reads
-//                                     through inline asm (the builtin makes hipcc drain every in-flight LDS-DMA)
-//   catalog_ce_bf16_kernel<D>         D = 64 / 128 / 256, any norms, masks, loss-only: lazy running max (raised
-//                                     only when a tile exceeds it by 2^8), 128-item double-buffered chunks
+// Kernels:
+//   catalog_row_bound_kernel<D>        per 256-row block: is ||rx|| * max||E|| * log2(e) <= 90 for every row?
+//   catalog_ce_bf16_fast_kernel<D>     D = 64 / 128 / 256, blocks that pass: NO running max (every exp2(logit) is a normal
+//                                      fp32 number, sums of 10^7 of them stay < 2^114); v_mfma_f32_16x16x32_bf16; 4-deep ring
+//                                      of 16 KB LDS buffers requested three chunks ahead, counted s_waitcnt vmcnt + raw
+//                                      s_barrier at the seams, all LDS offsets immediates, transposed reads through inline
+//                                      asm (the builtin makes hipcc drain every in-flight LDS-DMA), row sums of the
+//                                      numerators by an MFMA against ones
+//   catalog_ce_bf16_kernel<D>          any norms, masks, loss-only: lazy running max (raised only when a tile exceeds it
+//                                      by 2^8), 32x32x16 MFMA, 128-item double-buffered chunks
+//   catalog_screen_bf16_kernel<D,PASS> exact greedy argmax at bf16 speed (screening + fp32 rescoring of the candidates)
 //
 // Numerics: bf16 inputs (round-to-nearest-even), fp32 accumulation, softmax statistics in fp32.  Against
 // the fp32 reference the per-logit error is ~2^-9 relative per product and zero-mean, so the ELBO terms of
@@ -341,26 +343,136 @@ __device__ __forceinline__ void tr_wait() {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------------------------
-// The fast kernel computes with v_mfma_f32_16x16x32_bf16: at equal FLOPs per cycle the chip holds a ~12 % higher
+// The fast kernels compute with v_mfma_f32_16x16x32_bf16: at equal FLOPs per cycle the chip holds a ~12 % higher
 // clock on this shape than on 32x32x16 under MFMA-dense load (bare loops on random operands: 1.95 vs 1.74 PFLOP/s,
 // tools/mfma_shape_probe.hip), and the kernel runs at the power-limited ceiling.
 // Lane l: c = l & 15, g = l >> 4.  A wave owns 32 rows = two 16-row column tiles ct; a subtile = 32 items = two
 // 16-item row tiles rt.
-//   logits   acc[rt][ct] (f32x4) = sum over 4 k-steps; lane holds logit(n = 16 rt + 4 g + reg, r = 16 ct + c).
-//            Lane group g takes the 16-byte chunks 4g..4g+3 of a row over the 4 k-steps (any bijection of chunks to
-//            (k-step, lane group) is a valid k order as long as both operands use it) - this one keeps the row reads
-//            bank-conflict free.
+//   logits   acc[rt][ct] (f32x4) = sum over D/32 k-steps; lane holds logit(n = 16 rt + 4 g + reg, r = 16 ct + c).
+//            Lane group g takes a fixed set of 16-byte chunks of a row over the k-steps (any bijection of chunks to
+//            (k-step, lane group) is a valid k order as long as both operands use it) - chosen so that the row reads
+//            are bank-conflict free.
 //   softmax  16 exp2 per lane; the 8 values of column tile ct, [acc[0][ct][0..3], acc[1][ct][0..3]], are IN PLACE
-//            the B operand of the gradient MFMA (k slot (g, j) <-> item 16 (j >> 2) + 4 g + (j & 3)).
+//            the B operand of the gradient MFMA (k slot (g, j) <-> item 16 (j >> 2) + 4 g + (j & 3)); their row sums
+//            come from one more MFMA against an all-ones A operand (no v_add_f32 at all).
 //   gradient U[dt][ct] (f32x4) += E^T tile dt (16 d x 32 items, two transposed reads per lane) . P tile ct: one MFMA
 //            per (d tile, column tile) covers the whole subtile (K = 32 items).
+// Ring of 4 x 16 KB LDS buffers: chunk c lives in buffer c & 3 and is requested three chunks before it is consumed.
+// The seam between chunks is a counted s_waitcnt vmcnt (the two younger chunks stay in flight) + a raw s_barrier; all
+// LDS offsets of the reads are immediates.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool CHECK_N, int OFF>
-__device__ __forceinline__ void subtile16_d128(const char* smem, const int off, const int64_t n0, const int64_t N,
-                                               const bf16x8 (&xb)[2][4], f32x4 (&U)[8][2], float (&lsum)[2], const int a0,
-                                               const int t0, const int g) {
-    // ---- logits
-    f32x4 acc[2][2];
+
+// =============================================================================================
+// One template for D = 64 / 128 / 256: 16 KB ring chunks of 8192 / D items (128 / 64 / 32); a wave stages 16 / NW
+// 1 KiB pieces per chunk, so the seam is vmcnt(2 * 16 / NW) + s_barrier.
+//   D = 128  rows are 256 B = one bank row: 16 chunks XOR-swizzled by ((row & 3) << 2) | bitrev2((row >> 2) & 3).
+//   D = 256  rows are 512 B: the 16-chunk XOR swizzle of D = 128 applies inside each 256-B half (bank = address mod
+//            256 B, so the banking of both read patterns is that of D = 128); a k-step / d tile in the upper half is
+//            an immediate +256.  32 rows per wave: 128 accumulator registers (U) + 64 of rx fragments.
+//   D = 64   rows are 128 B (two per bank row): swizzle ((row >> 1) & 3) << 1 | (row >> 3) & 1 on the 3-bit chunk index,
+//            lane group g takes chunks 2g, 2g+1 over the two k-steps (tools/lds_bank_check.py: conflict-free).
+// =============================================================================================
+template <int D>
+struct FastGeo {
+    static constexpr int RB = 2 * D;        // bytes per table row
+    static constexpr int KS = D / 32;       // k-steps of the logits chain
+    static constexpr int NDT = D / 16;      // 16-wide d tiles of the gradient accumulator
+    static constexpr int BNF = 8192 / D;    // items per 16 KB ring chunk
+    static constexpr int SUB = BNF / 32;    // 32-item subtiles per chunk
+    static constexpr int RT = 16 * RB;      // byte stride between the two 16-item row tiles of a subtile
+    static constexpr int ST = 32 * RB;      // byte stride between subtiles
+    static constexpr int RPP = 1024 / RB;   // table rows per 1 KiB LDS-DMA piece
+    static constexpr int CPR = D / 8;       // 16-byte chunks per row
+    static constexpr int KMASK = D == 64 ? 1 : 3;
+    // D = 256: 32 rows of a wave are 128 accumulator + 64 fragment registers, more than the 256 a wave owns when two share
+    // a SIMD (181 spilled registers, 765 TFLOP/s) -> 4 waves per workgroup, one per SIMD with 512 registers each
+    static constexpr int NW = D == 256 ? 4 : 8;       // waves per workgroup
+    static constexpr int ROWS = NW * 32;              // rows of rx per workgroup
+    static constexpr int PPW = 16 / NW;               // 1 KiB LDS-DMA pieces per wave and ring chunk
+    // experiment switch: pin U in AGPRs through inline-asm MFMAs (6 % faster at D = 256 but produced NaNs - an unmanaged
+    // hazard around the asm MFMAs; the compiler-managed build is the product)
+#ifdef PCVAE_AGPR_ACC
+    static constexpr bool ACC_AGPR = NW == 4;
+#else
+    static constexpr bool ACC_AGPR = false;
+#endif
+};
+
+// U += A . B with the accumulator pinned in an AGPR quad (1 wave per SIMD: the compiler would otherwise move logits
+// accumulators there and pay a v_accvgpr_read per exponential)
+__device__ __forceinline__ void mfma_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <bool AG>
+__device__ __forceinline__ void mfma_u(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    if constexpr (AG) mfma_agpr(acc, a, b);
+    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
+// swizzle of the fast kernels' LDS image: chunk c of row `row` lives at chunk position fswz(row, c) (an involution)
+template <int D>
+__device__ __forceinline__ int fswz(int row, int c) {
+    if (D >= 128) return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1)));
+    return c ^ ((((row >> 1) & 3) << 1) | ((row >> 3) & 1));
+}
+// 16-byte chunk of a row that lane group g multiplies in k-step s
+template <int D>
+__device__ __forceinline__ constexpr int fchunk(int s, int g) {
+    return D == 64 ? 2 * g + s : (D == 128 ? 4 * g + s : 16 * (s >> 2) + 4 * g + (s & 3));
+}
+
+struct FastLane {  // lane bases of the two LDS read patterns: address = base ^ constant + immediate
+    int a0, t0, g;
+};
+
+template <int D>
+__device__ __forceinline__ FastLane fast_lane(int lane) {
+    using G = FastGeo<D>;
+    const int c = lane & 15, g = lane >> 4, q = c >> 2, pp = c & 3;
+    FastLane L;
+    L.g = g;
+    L.a0 = c * G::RB + ((fchunk<D>(0, g) ^ fswz<D>(c, 0)) << 4);
+    const int row = 4 * g + q;
+    L.t0 = row * G::RB + (((pp >> 1) ^ fswz<D>(row, 0)) << 4) + (pp & 1) * 8;
+    return L;
+}
+
+template <int D, int OFF, int DT>
+__device__ __forceinline__ void tr_issue(const unsigned lbase, const int t0, s16x4& lo, s16x4& hi) {
+    const unsigned ad = lbase + (unsigned)(t0 ^ ((DT & 7) << 5));
+    lo = tr_read<OFF + (DT >> 3) * 256>(ad);
+    hi = tr_read<OFF + (DT >> 3) * 256 + FastGeo<D>::RT>(ad);
+}
+
+// gradient chain, d tile DT: request d tile DT + 2, wait for the pieces of DT, two MFMAs
+template <int D, int OFF, int DT>
+__device__ __forceinline__ void grad_chain(const unsigned lbase, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
+                                           s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb)[2],
+                                           f32x4 (&U)[FastGeo<D>::NDT][2]) {
+    constexpr int NDT = FastGeo<D>::NDT;
+    if constexpr (DT < NDT) {
+        if constexpr (DT + 2 < NDT) {
+            tr_issue<D, OFF, DT + 2>(lbase, t0, tl[DT + 2], th[DT + 2]);
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // pieces of d tile DT landed, two d tiles in flight
+        } else if constexpr (DT + 2 == NDT) {
+            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+        mfma_u<FastGeo<D>::ACC_AGPR>(U[DT][0], a, pb[0]);
+        mfma_u<FastGeo<D>::ACC_AGPR>(U[DT][1], a, pb[1]);
+        grad_chain<D, OFF, DT + 1>(lbase, t0, tl, th, pb, U);
+    }
+}
+
+// logits of one 32-item subtile: acc[rt][ct][i] = <E[n0 + 16 rt + 4 g + i], x[16 ct + c]> (bf16 operands, fp32 accumulate)
+template <int D, bool CHECK_N, int OFF>
+__device__ __forceinline__ void fast_logits(const char* smem, const int off, const int64_t n0, const int64_t N,
+                                            const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&acc)[2][2], const FastLane& L) {
+    using G = FastGeo<D>;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -368,10 +480,11 @@ __device__ __forceinline__ void subtile16_d128(const char* smem, const int off, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[rt][ct][i] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < G::KS; ++s)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 4)) + off + (OFF + rt * 4096)));
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(
+                smem + ((L.a0 ^ ((s & G::KMASK) << 4)) + off + (OFF + rt * G::RT + (s >> 2) * 256)));
             acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[0][s], acc[rt][0], 0, 0, 0);
             acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[1][s], acc[rt][1], 0, 0, 0);
         }
@@ -380,9 +493,21 @@ __device__ __forceinline__ void subtile16_d128(const char* smem, const int off, 
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (n0 + 16 * rt + 4 * g + i >= N) { acc[rt][0][i] = -INFINITY; acc[rt][1][i] = -INFINITY; }
+                if (n0 + 16 * rt + 4 * L.g + i >= N) { acc[rt][0][i] = -INFINITY; acc[rt][1][i] = -INFINITY; }
     }
-    // ---- numerators
+}
+
+template <int D, bool CHECK_N, int OFF>
+__device__ __forceinline__ void fast_subtile(const char* smem, const int off, const int64_t n0, const int64_t N,
+                                             const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&U)[FastGeo<D>::NDT][2],
+                                             f32x4 (&lsum)[2], const FastLane& L) {
+    using G = FastGeo<D>;
+    f32x4 acc[2][2];
+    fast_logits<D, CHECK_N, OFF>(smem, off, n0, N, xb, acc, L);
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)off;
+    // ---- numerators.  Their row sums come from the matrix core as well: an all-ones A operand makes every row of the
+    // 16 x 16 result the sum over the 32 items of the bf16 numerators (the very values the gradient chain multiplies),
+    // which replaces 16 v_add_f32 per subtile - VALU issue, not the MFMA pipe, is the scarcer resource here
     bf16x8 pb[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -392,100 +517,126 @@ __device__ __forceinline__ void subtile16_d128(const char* smem, const int off, 
             for (int i = 0; i < 4; i += 2) {
                 const float e0 = __builtin_amdgcn_exp2f(acc[rt][ct][i]);
                 const float e1 = __builtin_amdgcn_exp2f(acc[rt][ct][i + 1]);
-                lsum[ct] += e0;
-                lsum[ct] += e1;
                 pb[ct][4 * rt + i] = (__bf16)e0;
                 pb[ct][4 * rt + i + 1] = (__bf16)e1;
             }
+    {
+        const s16x8 ones16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones16);
+        mfma_u<G::ACC_AGPR>(lsum[0], ones, pb[0]);
+        mfma_u<G::ACC_AGPR>(lsum[1], ones, pb[1]);
+    }
     // ---- gradient chain: E^T pieces by asm transposed reads, requested two d tiles ahead
-    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)off;
-    s16x4 tl[8], th[8];
-#define PCVAE_TR16(DT)                                                        \
-    {                                                                         \
-        const unsigned ad = lbase + (unsigned)(t0 ^ ((DT) << 5));             \
-        tl[DT] = tr_read<OFF>(ad);                                            \
-        th[DT] = tr_read<OFF + 4096>(ad);                                     \
-    }
-    PCVAE_TR16(0) PCVAE_TR16(1)
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-        if (dt + 2 < 8) {
-            if (dt == 0) PCVAE_TR16(2) else if (dt == 1) PCVAE_TR16(3) else if (dt == 2) PCVAE_TR16(4)
-            else if (dt == 3) PCVAE_TR16(5) else if (dt == 4) PCVAE_TR16(6) else PCVAE_TR16(7)
-            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");  // pieces of d tile dt landed, two d tiles in flight
-        } else if (dt == 6) {
-            asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const s16x8 a16 = __builtin_shufflevector(tl[dt], th[dt], 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
-        U[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[0], U[dt][0], 0, 0, 0);
-        U[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[1], U[dt][1], 0, 0, 0);
-    }
-#undef PCVAE_TR16
+    s16x4 tl[G::NDT], th[G::NDT];
+    tr_issue<D, OFF, 0>(lbase, L.t0, tl[0], th[0]);
+    tr_issue<D, OFF, 1>(lbase, L.t0, tl[1], th[1]);
+    grad_chain<D, OFF, 0>(lbase, L.t0, tl, th, pb, U);
 }
 
-// Ring of 4 x 64-item LDS buffers (16 KB each): chunk c lives in buffer c & 3 and is requested three chunks before
-// it is consumed.  The seam between chunks is a counted s_waitcnt vmcnt(4) (the two younger chunks stay in flight)
-// + a raw s_barrier; all LDS offsets of the reads are immediates.
-constexpr int BNF = 64;                 // items per chunk of the fast kernel
-constexpr int CBF = BNF * 256;          // bytes per chunk (D = 128, bf16)
+// all subtiles of the 16 KB ring chunk that starts at byte OFFB (+ runtime `off`)
+template <int D, int OFFB>
+__device__ __forceinline__ void fast_chunk(const char* smem, const int off, const int64_t nA, const int64_t N,
+                                           const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&U)[FastGeo<D>::NDT][2],
+                                           f32x4 (&lsum)[2], const FastLane& L) {
+    using G = FastGeo<D>;
+    fast_subtile<D, false, OFFB>(smem, off, nA, N, xb, U, lsum, L);
+    if constexpr (G::SUB >= 2) fast_subtile<D, false, OFFB + G::ST>(smem, off, nA + 32, N, xb, U, lsum, L);
+    if constexpr (G::SUB >= 4) {
+        fast_subtile<D, false, OFFB + 2 * G::ST>(smem, off, nA + 64, N, xb, U, lsum, L);
+        fast_subtile<D, false, OFFB + 3 * G::ST>(smem, off, nA + 96, N, xb, U, lsum, L);
+    }
+}
 
-// global -> LDS copy of one full 64-item chunk by 8 waves (2 one-KiB pieces each): wave-uniform base + one of two
-// per-lane 32-bit offsets (the swizzle depends on the piece only through piece & 3 = 2*(wave & 1) + i)
-__device__ __forceinline__ void stage_chunk_f(const uint16_t* __restrict__ E, int64_t n0, char* buf, const int wave_u,
-                                              const int (&lane_off)[2]) {
+// per-lane source offsets of the two 1 KiB LDS-DMA pieces a wave stages per ring chunk (swizzle on the SOURCE address)
+template <int D, int NW>
+__device__ __forceinline__ void fast_lane_off(int lane, int wave, int (&lane_off)[16 / NW]) {
+    using G = FastGeo<D>;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int pc = wave_u * 2 + i;
-        const char* base = reinterpret_cast<const char*>(E) + (n0 + pc * 4) * 256;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + lane_off[i]),
+    for (int i = 0; i < 16 / NW; ++i) {
+        const int pc = wave * (16 / NW) + i;
+        const int rip = lane / G::CPR, pos = lane % G::CPR;   // row inside the piece, chunk position inside the row
+        const int row16 = (pc * G::RPP + rip) & 15;
+        lane_off[i] = rip * G::RB + (fswz<D>(row16, pos) << 4);
+    }
+}
+
+template <int D, int NW>
+__device__ __forceinline__ void fast_stage(const uint16_t* __restrict__ E, int64_t n0, char* buf, const int wave_u,
+                                           const int (&lane_off)[16 / NW]) {
+    using G = FastGeo<D>;
+#pragma unroll
+    for (int i = 0; i < 16 / NW; ++i) {
+        const int pc = wave_u * (16 / NW) + i;
+        const char* base = reinterpret_cast<const char*>(E) + (n0 + pc * G::RPP) * G::RB;  // wave-uniform (SGPR pair)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(base + (uint64_t)(uint32_t)lane_off[i]),
+            (__attribute__((address_space(3))) void*)(buf + pc * 1024), 16, 0, 0);
+    }
+}
+
+// ragged tail: up to 128 items staged synchronously with clamped addresses (same image: row * RB, fswz)
+template <int D, int NW>
+__device__ __forceinline__ void fast_stage_tail(const uint16_t* __restrict__ E, int64_t N, int64_t n0, char* buf) {
+    using G = FastGeo<D>;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PIECES = 128 * G::RB / 1024;
+#pragma unroll
+    for (int i = 0; i < PIECES / NW; ++i) {
+        const int pc = wave * (PIECES / NW) + i;
+        const int row = pc * G::RPP + lane / G::CPR;
+        const int csrc = fswz<D>(row & 15, lane % G::CPR);
+        int64_t n = n0 + row;
+        n = n < N ? n : N - 1;
+        const char* src = reinterpret_cast<const char*>(E) + n * G::RB + (csrc << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(buf + pc * 1024), 16, 0, 0);
     }
 }
 
-__global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatParamsB p) {
-    constexpr int D = 128;
+template <int VM>
+__device__ __forceinline__ void fast_seam() {  // chunk landed for every wave: counted wait (the younger chunks stay in flight)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
+}
+
+template <int D>
+__global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_kernel(CatParamsB p) {
+    using G = FastGeo<D>;
+    constexpr int CB = 16384;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = logical / p.nrb, rb = logical % p.nrb;
-    if (p.safe_flags[rb] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
+    // p.nrb counts 256-row blocks (the lazy-max kernel's, and the flags'); this kernel's blocks are G::ROWS rows
+    const int nrb = p.nrb * (ROWS_WG / G::ROWS);
+    const int split = logical / nrb, rb = logical % nrb;
+    if ((int64_t)rb * G::ROWS >= p.R) return;
+    if (p.safe_flags[rb / (ROWS_WG / G::ROWS)] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
     const int64_t nbase = (int64_t)t_beg * 32;
-    // 64-item chunks of this range that exist in full (no per-element bound checks in their bodies)
-    const int n_half = (t_end - t_beg + 1) / 2;
-    int n_full = (int)min((int64_t)n_half, (p.N - nbase) / BNF);
+    // ring chunks of this range that exist in full (no per-element bound checks in their bodies)
+    int n_full = (int)min((int64_t)((t_end - t_beg) / G::SUB), (p.N - nbase) / G::BNF);
     n_full = max(n_full, 0);
 
-    const int64_t rw = (int64_t)rb * ROWS_WG + wave * 32;  // first row of this wave
-
+    const int64_t rw = (int64_t)rb * G::ROWS + wave * 32;  // first row of this wave
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int lane_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {  // row = 4*piece + (lane>>4), piece & 3 = 2*(wave&1) + i
-        const int rr = (lane >> 4) | (((2 * (wave & 1) + i) & 3) << 2);
-        lane_off[i] = (lane >> 4) * 256 + (swz_chunk<128>(rr, lane & 15) << 4);
-    }
+    int lane_off[G::PPW];
+    fast_lane_off<D, G::NW>(lane, wave, lane_off);
 #pragma unroll
     for (int c0 = 0; c0 < 3; ++c0)  // prologue: chunks 0..2 in flight
-        if (c0 < n_full) stage_chunk_f(p.E, nbase + (int64_t)c0 * BNF, smem + c0 * CBF, wave_u, lane_off);
+        if (c0 < n_full) fast_stage<D, G::NW>(p.E, nbase + (int64_t)c0 * G::BNF, smem + c0 * CB, wave_u, lane_off);
 
-    // B operand of the logits chain: column tile ct, k-step s: rx[row 16 ct + c][8 (4 g + s) .. + 7] * log2 e
-    bf16x8 xb[2][4];
+    // B operand of the logits chain: column tile ct, k-step s: rx[row 16 ct + c][8 fchunk(s, g) .. + 7] * log2 e
+    bf16x8 xb[2][G::KS];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const int64_t r = rw + 16 * ct + c;
         const int64_t rl = r < p.R ? r : p.R - 1;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * (4 * g + s));
-            const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * (4 * g + s) + 4);
+        for (int s = 0; s < G::KS; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * fchunk<D>(s, g));
+            const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * fchunk<D>(s, g) + 4);
             xb[ct][s][0] = (__bf16)(v0.x * kLog2e); xb[ct][s][1] = (__bf16)(v0.y * kLog2e);
             xb[ct][s][2] = (__bf16)(v0.z * kLog2e); xb[ct][s][3] = (__bf16)(v0.w * kLog2e);
             xb[ct][s][4] = (__bf16)(v1.x * kLog2e); xb[ct][s][5] = (__bf16)(v1.y * kLog2e);
@@ -493,34 +644,31 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
         }
     }
 
-    f32x4 U[8][2];
+    f32x4 U[G::NDT][2];
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
+    for (int dt = 0; dt < G::NDT; ++dt)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
             for (int i = 0; i < 4; ++i) U[dt][ct][i] = 0.f;
-    float lsum[2] = {0.f, 0.f};
+    f32x4 lsum[2];  // every register of lane (c, g): sum of the numerators of row 16 ct + c
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lsum[ct][i] = 0.f;
+    const FastLane L = fast_lane<D>(lane);
 
-    // lane bases of the two LDS read patterns (address = base ^ constant + immediate; tools/lds_bank_check.py)
-    const int q = c >> 2, pp = c & 3;
-    const int wr = ((c & 3) << 2) | (((c >> 2) & 1) << 1) | ((c >> 3) & 1);   // swizzle of row c (mod 16)
-    const int a0 = c * 256 + (((4 * g) ^ wr) << 4);
-    const int brg = ((g & 1) << 1) | (g >> 1);                                  // 2-bit reversal of g
-    const int t0 = (4 * g + q) * 256 + (((pp >> 1) ^ ((q << 2) | brg)) << 4) + (pp & 1) * 8;
-
-#define PCVAE_SEAM(VMCNT) asm volatile("s_waitcnt vmcnt(" #VMCNT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
     int cc = 0;
     const int n_pipe = n_full >= 3 ? n_full - 2 : 0;   // chunks consumed with two younger chunks in flight
     for (; cc + 4 <= n_pipe; cc += 4) {
 #define PCVAE_RING_STEP(UU)                                                                                          \
         {                                                                                                            \
-            const int64_t nA = nbase + (int64_t)(cc + UU) * BNF;                                                     \
-            PCVAE_SEAM(4);                                                                                           \
+            const int64_t nA = nbase + (int64_t)(cc + UU) * G::BNF;                                                  \
+            fast_seam<2 * G::PPW>();                                                                                 \
             /* buffer (UU+3)&3 held chunk cc+UU-1, which every wave has finished: refill it */                       \
-            if (cc + UU + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((UU + 3) & 3) * CBF, wave_u, lane_off); \
-            subtile16_d128<false, UU * CBF>(smem, 0, nA, p.N, xb, U, lsum, a0, t0, g);                               \
-            subtile16_d128<false, UU * CBF + 8192>(smem, 0, nA + 32, p.N, xb, U, lsum, a0, t0, g);                   \
+            if (cc + UU + 3 < n_full)                                                                                \
+                fast_stage<D, G::NW>(p.E, nA + 3 * G::BNF, smem + ((UU + 3) & 3) * CB, wave_u, lane_off);                   \
+            fast_chunk<D, UU * CB>(smem, 0, nA, p.N, xb, U, lsum, L);                                                \
         }
         PCVAE_RING_STEP(0)
         PCVAE_RING_STEP(1)
@@ -530,36 +678,30 @@ __global__ void __launch_bounds__(512, 1) catalog_ce_bf16_d128_fast_kernel(CatPa
     }
     // ---- remaining full chunks: drain the ring (vmcnt(0)), runtime offsets
     for (; cc < n_full; ++cc) {
-        const int64_t nA = nbase + (int64_t)cc * BNF;
-        PCVAE_SEAM(0);
-        if (cc + 3 < n_full) stage_chunk_f(p.E, nA + 3 * BNF, smem + ((cc + 3) & 3) * CBF, wave_u, lane_off);
-        const int boff = (cc & 3) * CBF;
-        subtile16_d128<false, 0>(smem, boff, nA, p.N, xb, U, lsum, a0, t0, g);
-        subtile16_d128<false, 8192>(smem, boff, nA + 32, p.N, xb, U, lsum, a0, t0, g);
+        const int64_t nA = nbase + (int64_t)cc * G::BNF;
+        fast_seam<0>();
+        if (cc + 3 < n_full) fast_stage<D, G::NW>(p.E, nA + 3 * G::BNF, smem + ((cc + 3) & 3) * CB, wave_u, lane_off);
+        fast_chunk<D, 0>(smem, (cc & 3) * CB, nA, p.N, xb, U, lsum, L);
     }
-#undef PCVAE_SEAM
     // ---- tail: short / ragged chunks (at most a few subtiles), staged synchronously with clamped addresses
-    for (int t = t_beg + 2 * n_full; t < t_end; t += 4) {
+    for (int t = t_beg + G::SUB * n_full; t < t_end; t += 4) {
         __syncthreads();
-        stage_chunk<D>(p.E, p.N, (int64_t)t * 32, smem);
+        fast_stage_tail<D, G::NW>(p.E, p.N, (int64_t)t * 32, smem);
         __syncthreads();
         const int nsub = min(4, t_end - t);
         for (int st = 0; st < nsub; ++st)
-            subtile16_d128<true, 0>(smem, st * 8192, (int64_t)(t + st) * 32, p.N, xb, U, lsum, a0, t0, g);
+            fast_subtile<D, true, 0>(smem, st * G::ST, (int64_t)(t + st) * 32, p.N, xb, U, lsum, L);
     }
 
-    // row 16 ct + c: its sum is spread over the four lane groups g
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        float l = lsum[ct];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        const float l = lsum[ct][0];
         const int64_t r = rw + 16 * ct + c;
         if (r < p.R) {
             const int64_t o = (int64_t)split * p.R + r;
             if (g == 0) { p.pm[o] = 0.f; p.pl[o] = l; }
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt)  // U[dt][ct][reg] = U^T[d = 16 dt + 4 g + reg][r]
+            for (int dt = 0; dt < G::NDT; ++dt)  // U[dt][ct][reg] = U^T[d = 16 dt + 4 g + reg][r]
                 *reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g) =
                     make_float4(U[dt][ct][0], U[dt][ct][1], U[dt][ct][2], U[dt][ct][3]);
         }
@@ -626,7 +768,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
     const dim3 grid((unsigned)(p.nrb * p.nsplit)), block(512);
     p.safe_flags = nullptr;
     p.run_if_flag = 1;
-    if (D == 128) {
+    {
         // row blocks with a small logit bound run the max-free kernel, the others the lazy-max kernel;
         // both launches cover the whole grid and each workgroup exits at once if the other kernel owns it
         // masked / loss-only calls (validation, n_neg < N) all take the lazy-max kernel
@@ -635,13 +777,15 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
                            fast_ok ? e_max_norm : 0.f, flags);
         p.safe_flags = flags;
         if (fast_ok) {
+            constexpr int lds_fast = 65536;  // ring of four 16 KB chunks (also holds the <= 64 KB synchronous tail image)
             static bool attr_set = false;
             if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_d128_fast_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_fast_kernel<D>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(catalog_ce_bf16_d128_fast_kernel, grid, block, lds, st, p);
+            const dim3 fgrid((unsigned)(p.nrb * (ROWS_WG / FastGeo<D>::ROWS) * p.nsplit)), fblock(FastGeo<D>::NW * 64);
+            hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), fgrid, fblock, lds_fast, st, p);
         }
         int rc0 = check_launch("catalog_ce_bf16_fast");
         if (rc0 != PCVAE_OK) return rc0;
@@ -674,7 +818,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
 }
 
 // =============================================================================================
-// K6 at bf16 speed with EXACT fp32 results ("screened" argmax), D = 128.
+// K6 at bf16 speed with EXACT fp32 results ("screened" argmax), D = 64 / 128 / 256.
 //
 // The greedy item id must be bit-exact against the fp32 arithmetic (k-ordered fmaf chain, lowest index on ties), but
 // the exact f32-MFMA kernel runs at 1/16 of the bf16 rate.  Two bf16 passes over the catalog give the same answer:
@@ -692,9 +836,9 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
 // (an adversarially ordered catalog only costs time - more candidates - never correctness).
 // =============================================================================================
 struct ScreenParams {
-    const float* x;        // [R, 128] fp32
-    const uint16_t* Eb;    // [N, 128] bf16 bits
-    const float* Ef;       // [N, 128] fp32 (exact rescoring)
+    const float* x;        // [R, D] fp32
+    const uint16_t* Eb;    // [N, D] bf16 bits
+    const float* Ef;       // [N, D] fp32 (exact rescoring)
     int64_t R, N;
     int nrb, nsplit, tiles_per_split, ntiles;
     float* pm;                       // [nsplit][R] approximate maxima (pass A)
@@ -712,40 +856,14 @@ __device__ __forceinline__ float unordered_bits(unsigned int o) {
     return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xffffffffu));
 }
 
-// logits of one 32-item subtile (16x16x32 layout of the fast kernel), no log2(e) scaling
-template <bool CHECK_N, int OFF>
-__device__ __forceinline__ void screen_logits(const char* smem, const int off, const int64_t n0, const int64_t N,
-                                              const bf16x8 (&xb)[2][4], f32x4 (&acc)[2][2], const int a0, const int g) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[rt][ct][i] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(smem + ((a0 ^ (s << 4)) + off + (OFF + rt * 4096)));
-            acc[rt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[0][s], acc[rt][0], 0, 0, 0);
-            acc[rt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xb[1][s], acc[rt][1], 0, 0, 0);
-        }
-    if (CHECK_N) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (n0 + 16 * rt + 4 * g + i >= N) { acc[rt][0][i] = -INFINITY; acc[rt][1][i] = -INFINITY; }
-    }
-}
-
 // exact fp32 score of (row, n) - k-ordered fmaf chain - folded into best_key[row]
+template <int D>
 __device__ __forceinline__ void screen_rescore(const ScreenParams& p, const int64_t row, const int64_t n) {
-    const float4* e = reinterpret_cast<const float4*>(p.Ef + n * 128);
-    const float4* xr = reinterpret_cast<const float4*>(p.x + row * 128);
+    const float4* e = reinterpret_cast<const float4*>(p.Ef + n * D);
+    const float4* xr = reinterpret_cast<const float4*>(p.x + row * D);
     float sc = 0.f;
 #pragma unroll 1
-    for (int k = 0; k < 32; k += 8) {  // 16 independent 16-byte loads in flight, then 32 fmaf
+    for (int k = 0; k < D / 4; k += 8) {  // 16 independent 16-byte loads in flight, then 32 fmaf
         float4 ev[8], xv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { ev[j] = e[k + j]; xv[j] = xr[k + j]; }
@@ -763,16 +881,17 @@ __device__ __forceinline__ void screen_rescore(const ScreenParams& p, const int6
 // Candidates are parked in an LDS list (one ds_add_rtn + one ds_write) and rescored by the whole workgroup after the
 // catalog range is done: an inline rescoring stalls its wave for microseconds and, through the per-chunk barrier, the
 // seven other waves with it.  A full list degrades to inline rescoring (slow, still exact).
+constexpr int SCREEN_RING = 4 * 16384;
 constexpr int SCREEN_CAND_CAP = 3072;
-constexpr int SCREEN_LDS_BYTES = 4 * CBF + SCREEN_CAND_CAP * 8 + 16;
+constexpr int SCREEN_LDS_BYTES = SCREEN_RING + SCREEN_CAND_CAP * 8 + 16;
+constexpr int SCREEN_NW = 8;  // no U accumulator here: 8 waves (two per SIMD) fit for every D
 
-template <int PASS, bool CHECK_N, int OFF>
+template <int D, int PASS, bool CHECK_N, int OFF>
 __device__ __forceinline__ void screen_subtile(const ScreenParams& p, char* smem, const int off, const int64_t n0,
-                                               const bf16x8 (&xb)[2][4], float (&m)[2], float (&thr)[2],
-                                               const float (&eps2)[2], const int64_t (&row)[2], const int a0,
-                                               const int g) {
+                                               const bf16x8 (&xb)[2][FastGeo<D>::KS], float (&m)[2], float (&thr)[2],
+                                               const float (&eps2)[2], const int64_t (&row)[2], const FastLane& L) {
     f32x4 acc[2][2];
-    screen_logits<CHECK_N, OFF>(smem, off, n0, p.N, xb, acc, a0, g);
+    fast_logits<D, CHECK_N, OFF>(smem, off, n0, p.N, xb, acc, L);
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         float v = fmaxf(fmaxf(acc[0][ct][0], acc[0][ct][1]), fmaxf(acc[0][ct][2], acc[0][ct][3]));
@@ -780,17 +899,17 @@ __device__ __forceinline__ void screen_subtile(const ScreenParams& p, char* smem
         if (PASS == 0) {
             m[ct] = fmaxf(m[ct], v);
         } else if (v >= thr[ct]) {
-            unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + 4 * CBF + SCREEN_CAND_CAP * 8);
-            uint2* list = reinterpret_cast<uint2*>(smem + 4 * CBF);
+            unsigned int* cnt = reinterpret_cast<unsigned int*>(smem + SCREEN_RING + SCREEN_CAND_CAP * 8);
+            uint2* list = reinterpret_cast<uint2*>(smem + SCREEN_RING);
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (acc[rt][ct][i] >= thr[ct]) {
-                        const int64_t n = n0 + 16 * rt + 4 * g + i;
+                        const int64_t n = n0 + 16 * rt + 4 * L.g + i;
                         const unsigned int slot = atomicAdd(cnt, 1u);
                         if (slot < (unsigned)SCREEN_CAND_CAP) list[slot] = make_uint2((unsigned int)row[ct], (unsigned int)n);
-                        else screen_rescore(p, row[ct], n);
+                        else screen_rescore<D>(p, row[ct], n);
                     }
             // everything this lane meets later only matters if it comes within 2 eps of what it has already seen
             thr[ct] = fmaxf(thr[ct], v - eps2[ct]);
@@ -798,9 +917,23 @@ __device__ __forceinline__ void screen_subtile(const ScreenParams& p, char* smem
     }
 }
 
-template <int PASS>
-__global__ void __launch_bounds__(512, 1) catalog_screen_bf16_d128_kernel(ScreenParams p) {
-    constexpr int D = 128;
+template <int D, int PASS, int OFFB>
+__device__ __forceinline__ void screen_chunk(const ScreenParams& p, char* smem, const int off, const int64_t nA,
+                                             const bf16x8 (&xb)[2][FastGeo<D>::KS], float (&m)[2], float (&thr)[2],
+                                             const float (&eps2)[2], const int64_t (&row)[2], const FastLane& L) {
+    using G = FastGeo<D>;
+    screen_subtile<D, PASS, false, OFFB>(p, smem, off, nA, xb, m, thr, eps2, row, L);
+    if constexpr (G::SUB >= 2) screen_subtile<D, PASS, false, OFFB + G::ST>(p, smem, off, nA + 32, xb, m, thr, eps2, row, L);
+    if constexpr (G::SUB >= 4) {
+        screen_subtile<D, PASS, false, OFFB + 2 * G::ST>(p, smem, off, nA + 64, xb, m, thr, eps2, row, L);
+        screen_subtile<D, PASS, false, OFFB + 3 * G::ST>(p, smem, off, nA + 96, xb, m, thr, eps2, row, L);
+    }
+}
+
+template <int D, int PASS>
+__global__ void __launch_bounds__(512, 1) catalog_screen_bf16_kernel(ScreenParams p) {
+    using G = FastGeo<D>;
+    constexpr int CB = 16384, NW = SCREEN_NW;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -809,27 +942,22 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_d128_kernel(Screen
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
     const int64_t nbase = (int64_t)t_beg * 32;
-    const int n_half = (t_end - t_beg + 1) / 2;
-    int n_full = (int)min((int64_t)n_half, (p.N - nbase) / BNF);
+    int n_full = (int)min((int64_t)((t_end - t_beg) / G::SUB), (p.N - nbase) / G::BNF);
     n_full = max(n_full, 0);
     const int64_t rw = (int64_t)rb * ROWS_WG + wave * 32;
     if (PASS == 1) {
-        if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(smem + 4 * CBF + SCREEN_CAND_CAP * 8) = 0u;
+        if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(smem + SCREEN_RING + SCREEN_CAND_CAP * 8) = 0u;
         __syncthreads();
     }
 
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    int lane_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int rr = (lane >> 4) | (((2 * (wave & 1) + i) & 3) << 2);
-        lane_off[i] = (lane >> 4) * 256 + (swz_chunk<128>(rr, lane & 15) << 4);
-    }
+    int lane_off[16 / NW];
+    fast_lane_off<D, NW>(lane, wave, lane_off);
 #pragma unroll
     for (int c0 = 0; c0 < 3; ++c0)
-        if (c0 < n_full) stage_chunk_f(p.Eb, nbase + (int64_t)c0 * BNF, smem + c0 * CBF, wave_u, lane_off);
+        if (c0 < n_full) fast_stage<D, NW>(p.Eb, nbase + (int64_t)c0 * G::BNF, smem + c0 * CB, wave_u, lane_off);
 
-    bf16x8 xb[2][4];
+    bf16x8 xb[2][G::KS];
     int64_t row[2];
     float thr[2] = {INFINITY, INFINITY}, eps2[2] = {0.f, 0.f}, m[2] = {-INFINITY, -INFINITY};
 #pragma unroll
@@ -838,27 +966,25 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_d128_kernel(Screen
         row[ct] = r < p.R ? r : p.R - 1;
         if (PASS == 1 && r < p.R) { thr[ct] = p.thr[r]; eps2[ct] = p.eps2[r]; }  // padding rows: never a candidate
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float4 v0 = *reinterpret_cast<const float4*>(p.x + row[ct] * D + 8 * (4 * g + s));
-            const float4 v1 = *reinterpret_cast<const float4*>(p.x + row[ct] * D + 8 * (4 * g + s) + 4);
+        for (int s = 0; s < G::KS; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.x + row[ct] * D + 8 * fchunk<D>(s, g));
+            const float4 v1 = *reinterpret_cast<const float4*>(p.x + row[ct] * D + 8 * fchunk<D>(s, g) + 4);
             xb[ct][s][0] = (__bf16)v0.x; xb[ct][s][1] = (__bf16)v0.y; xb[ct][s][2] = (__bf16)v0.z; xb[ct][s][3] = (__bf16)v0.w;
             xb[ct][s][4] = (__bf16)v1.x; xb[ct][s][5] = (__bf16)v1.y; xb[ct][s][6] = (__bf16)v1.z; xb[ct][s][7] = (__bf16)v1.w;
         }
     }
-    const int wr = ((c & 3) << 2) | (((c >> 2) & 1) << 1) | ((c >> 3) & 1);
-    const int a0 = c * 256 + (((4 * g) ^ wr) << 4);
+    const FastLane L = fast_lane<D>(lane);
 
-#define PCVAE_SEAM(VMCNT) asm volatile("s_waitcnt vmcnt(" #VMCNT ") lgkmcnt(0)\n\ts_barrier" ::: "memory")
     int cc = 0;
     const int n_pipe = n_full >= 3 ? n_full - 2 : 0;
     for (; cc + 4 <= n_pipe; cc += 4) {
 #define PCVAE_RING_STEP(UU)                                                                                          \
         {                                                                                                            \
-            const int64_t nA = nbase + (int64_t)(cc + UU) * BNF;                                                     \
-            PCVAE_SEAM(4);                                                                                           \
-            if (cc + UU + 3 < n_full) stage_chunk_f(p.Eb, nA + 3 * BNF, smem + ((UU + 3) & 3) * CBF, wave_u, lane_off); \
-            screen_subtile<PASS, false, UU * CBF>(p, smem, 0, nA, xb, m, thr, eps2, row, a0, g);                           \
-            screen_subtile<PASS, false, UU * CBF + 8192>(p, smem, 0, nA + 32, xb, m, thr, eps2, row, a0, g);               \
+            const int64_t nA = nbase + (int64_t)(cc + UU) * G::BNF;                                                  \
+            fast_seam<2 * (16 / NW)>();                                                                              \
+            if (cc + UU + 3 < n_full)                                                                                \
+                fast_stage<D, NW>(p.Eb, nA + 3 * G::BNF, smem + ((UU + 3) & 3) * CB, wave_u, lane_off);              \
+            screen_chunk<D, PASS, UU * CB>(p, smem, 0, nA, xb, m, thr, eps2, row, L);                                \
         }
         PCVAE_RING_STEP(0)
         PCVAE_RING_STEP(1)
@@ -867,28 +993,25 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_d128_kernel(Screen
 #undef PCVAE_RING_STEP
     }
     for (; cc < n_full; ++cc) {
-        const int64_t nA = nbase + (int64_t)cc * BNF;
-        PCVAE_SEAM(0);
-        if (cc + 3 < n_full) stage_chunk_f(p.Eb, nA + 3 * BNF, smem + ((cc + 3) & 3) * CBF, wave_u, lane_off);
-        const int boff = (cc & 3) * CBF;
-        screen_subtile<PASS, false, 0>(p, smem, boff, nA, xb, m, thr, eps2, row, a0, g);
-        screen_subtile<PASS, false, 8192>(p, smem, boff, nA + 32, xb, m, thr, eps2, row, a0, g);
+        const int64_t nA = nbase + (int64_t)cc * G::BNF;
+        fast_seam<0>();
+        if (cc + 3 < n_full) fast_stage<D, NW>(p.Eb, nA + 3 * G::BNF, smem + ((cc + 3) & 3) * CB, wave_u, lane_off);
+        screen_chunk<D, PASS, 0>(p, smem, (cc & 3) * CB, nA, xb, m, thr, eps2, row, L);
     }
-#undef PCVAE_SEAM
-    for (int t = t_beg + 2 * n_full; t < t_end; t += 4) {
+    for (int t = t_beg + G::SUB * n_full; t < t_end; t += 4) {
         __syncthreads();
-        stage_chunk<D>(p.Eb, p.N, (int64_t)t * 32, smem);
+        fast_stage_tail<D, NW>(p.Eb, p.N, (int64_t)t * 32, smem);
         __syncthreads();
         const int nsub = min(4, t_end - t);
         for (int st = 0; st < nsub; ++st)
-            screen_subtile<PASS, true, 0>(p, smem, st * 8192, (int64_t)(t + st) * 32, xb, m, thr, eps2, row, a0, g);
+            screen_subtile<D, PASS, true, 0>(p, smem, st * G::ST, (int64_t)(t + st) * 32, xb, m, thr, eps2, row, L);
     }
     if (PASS == 1) {  // rescore the parked candidates, one per thread
         __syncthreads();
         const unsigned int cnt =
-            min(*reinterpret_cast<const unsigned int*>(smem + 4 * CBF + SCREEN_CAND_CAP * 8), (unsigned)SCREEN_CAND_CAP);
-        const uint2* list = reinterpret_cast<const uint2*>(smem + 4 * CBF);
-        for (unsigned int j = threadIdx.x; j < cnt; j += 512) screen_rescore(p, (int64_t)list[j].x, (int64_t)list[j].y);
+            min(*reinterpret_cast<const unsigned int*>(smem + SCREEN_RING + SCREEN_CAND_CAP * 8), (unsigned)SCREEN_CAND_CAP);
+        const uint2* list = reinterpret_cast<const uint2*>(smem + SCREEN_RING);
+        for (unsigned int j = threadIdx.x; j < cnt; j += 512) screen_rescore<D>(p, (int64_t)list[j].x, (int64_t)list[j].y);
     }
     if (PASS == 0) {
 #pragma unroll
@@ -904,14 +1027,15 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_d128_kernel(Screen
 
 // after pass A: thr[r] = max_j pm[j][r] - 2 eps_r ; best_key[r] = 0.  pass A may have seen only a PREFIX of the catalog:
 // any lower bound of the full approximate maximum m~ is a valid threshold base (more candidates, same answer).
-__global__ void catalog_screen_threshold_kernel(ScreenParams p) {
+__global__ void catalog_screen_threshold_kernel(ScreenParams p, int D) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.R) return;
     float mm = -INFINITY;
     for (int j = 0; j < p.nsplit; ++j) mm = fmaxf(mm, p.pm[(int64_t)j * p.R + r]);
     float ss = 0.f;
-    for (int k = 0; k < 128; ++k) ss = fmaf(p.x[r * 128 + k], p.x[r * 128 + k], ss);
-    const float eps = (0.00390625f * 1.02f + 2e-5f) * sqrtf(ss) * p.e_max_norm;
+    for (int k = 0; k < D; ++k) ss = fmaf(p.x[r * D + k], p.x[r * D + k], ss);
+    // two RNE roundings per product (2^-9 each), fp32 accumulation slack growing with the chain length
+    const float eps = (0.00390625f * 1.02f + 2e-5f * (float)(D > 128 ? D / 128 : 1)) * sqrtf(ss) * p.e_max_norm;
     p.thr[r] = mm - 2.f * eps - 1e-30f;
     p.eps2[r] = 2.f * eps + 1e-30f;
     p.best_key[r] = 0ull;
@@ -958,12 +1082,35 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
     return PCVAE_EINVAL;
 }
 
-int catalog_argmax_screened_d128(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, float e_max_norm,
-                                 int64_t* idx, float* best, void* ws, hipStream_t st) {
+template <int D>
+static int launch_screened(ScreenParams p, const CatalogPlan& pa, const CatalogPlan& pb, int64_t Ns, int64_t N, int64_t* idx,
+                           float* best, hipStream_t st) {
+    const size_t lds = SCREEN_LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const dim3 block(512);
+    p.N = Ns; p.nrb = pa.nrb; p.nsplit = pa.nsplit; p.tiles_per_split = pa.tiles_per_split; p.ntiles = pa.ntiles;
+    hipLaunchKernelGGL((catalog_screen_bf16_kernel<D, 0>), dim3((unsigned)(pa.nrb * pa.nsplit)), block, lds, st, p);
+    hipLaunchKernelGGL(catalog_screen_threshold_kernel, dim3((unsigned)cdiv(p.R, 256)), dim3(256), 0, st, p, D);
+    p.N = N; p.nrb = pb.nrb; p.nsplit = pb.nsplit; p.tiles_per_split = pb.tiles_per_split; p.ntiles = pb.ntiles;
+    hipLaunchKernelGGL((catalog_screen_bf16_kernel<D, 1>), dim3((unsigned)(pb.nrb * pb.nsplit)), block, lds, st, p);
+    hipLaunchKernelGGL(catalog_screen_decode_kernel, dim3((unsigned)cdiv(p.R, 256)), dim3(256), 0, st, p, idx, best);
+    return check_launch("catalog_argmax_screened");
+}
+
+int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, int D, float e_max_norm,
+                            int64_t* idx, float* best, void* ws, hipStream_t st) {
     // pass A over a prefix of the catalog is enough to seed the threshold: with N/16 items the expected number of
     // later items above the prefix maximum is ~16 per row (plus the lane-local running maximum in pass B), each
-    // costing one 128-term fmaf chain - far cheaper than a second full bf16 pass.
+    // costing one D-term fmaf chain - far cheaper than a second full bf16 pass.
     const int64_t Ns = N >= 262144 ? (N / 16) / 128 * 128 : N;
+    // the screen kernels always run 256-row workgroups: plan them as the D = 128 case
     const CatalogPlan pa = catalog_plan(R, Ns, 128, PCVAE_PREC_BF16), pb = catalog_plan(R, N, 128, PCVAE_PREC_BF16);
     ScreenParams p{};
     p.x = x; p.Eb = Eb; p.Ef = Ef; p.R = R; p.e_max_norm = e_max_norm;
@@ -971,23 +1118,13 @@ int catalog_argmax_screened_d128(const float* x, int64_t R, const uint16_t* Eb, 
     p.thr = reinterpret_cast<float*>(p.best_key + R);
     p.eps2 = p.thr + R;
     p.pm = p.eps2 + R;   // [nsplit(A) <= 64][R]
-    const size_t lds = SCREEN_LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_d128_kernel<0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_d128_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
+    switch (D) {
+        case 64: return launch_screened<64>(p, pa, pb, Ns, N, idx, best, st);
+        case 128: return launch_screened<128>(p, pa, pb, Ns, N, idx, best, st);
+        case 256: return launch_screened<256>(p, pa, pb, Ns, N, idx, best, st);
     }
-    const dim3 block(512);
-    p.N = Ns; p.nrb = pa.nrb; p.nsplit = pa.nsplit; p.tiles_per_split = pa.tiles_per_split; p.ntiles = pa.ntiles;
-    hipLaunchKernelGGL(catalog_screen_bf16_d128_kernel<0>, dim3((unsigned)(pa.nrb * pa.nsplit)), block, lds, st, p);
-    hipLaunchKernelGGL(catalog_screen_threshold_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, p);
-    p.N = N; p.nrb = pb.nrb; p.nsplit = pb.nsplit; p.tiles_per_split = pb.tiles_per_split; p.ntiles = pb.ntiles;
-    hipLaunchKernelGGL(catalog_screen_bf16_d128_kernel<1>, dim3((unsigned)(pb.nrb * pb.nsplit)), block, lds, st, p);
-    hipLaunchKernelGGL(catalog_screen_decode_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, st, p, idx, best);
-    return check_launch("catalog_argmax_screened");
+    set_error("catalog_argmax(screened): unsupported D=%d (64, 128, 256)", D);
+    return PCVAE_EINVAL;
 }
 
 }  // namespace pcvae

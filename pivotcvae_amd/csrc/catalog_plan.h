@@ -16,7 +16,6 @@ struct CatalogPlan {
 //   f32 kernels : 128-row workgroups (4 waves), 2 resident per CU, any tile count per range
 //   bf16 kernels: 256-row workgroups (8 waves), 1 resident per CU, ranges are whole 128-item LDS chunks
 static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
-    (void)D;
     const bool f32 = prec == PCVAE_PREC_F32;
     const int rows_wg = f32 ? 128 : 256;
     const int quant = f32 ? 1 : 4;
@@ -28,12 +27,14 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // 4.06 rounds -> 5 rounds of 1202 tiles; 32 ranges = 1280 workgroups = exactly 5 rounds of 980 tiles, 19 % less).
     // Ranges stay long enough that the per-range prologue (rx fragments) and epilogue (partials) are amortised.
     const int64_t slots = 256 * (f32 ? 2 : 1);
+    // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
+    const int64_t nblk = (!f32 && D == 256) ? cdiv(R, 128) : p.nrb;
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
     int64_t best_cost = -1;
     for (int64_t ns = 1; ns <= cap; ++ns) {
         const int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;
         const int64_t ns_eff = cdiv(p.ntiles, tps);
-        const int64_t rounds = cdiv((int64_t)p.nrb * ns_eff, slots);
+        const int64_t rounds = cdiv(nblk * ns_eff, slots);
         const int64_t cost = rounds * tps;
         if (best_cost < 0 || cost < best_cost) {  // strict '<': ties keep the fewer, longer ranges
             best_cost = cost;
@@ -50,8 +51,8 @@ int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D,
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
                     const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, hipStream_t st);
-int catalog_argmax_screened_d128(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, float e_max_norm,
-                                 int64_t* idx, float* best, void* ws, hipStream_t st);
+int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, int D, float e_max_norm,
+                            int64_t* idx, float* best, void* ws, hipStream_t st);
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,
                        uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st);
 

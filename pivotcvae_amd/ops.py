@@ -443,7 +443,7 @@ def catalog_argmax(x, table, prec=PREC_F32, return_best=False, screened=None):
     """first-index argmax_n <x_r, E_n> (models/cvae.py:97-101) -> int64 [R].
 
     Always the exact fp32 answer (bit-exact ids against the fp32 oracle), independent of ``prec`` (kept for call
-    compatibility with the loss ops).  With D = 128 and a large catalog the same exact result is produced several
+    compatibility with the loss ops).  With D in (64, 128, 256) and a large catalog the same exact result is produced several
     times faster by bf16 screening + fp32 rescoring of the candidates (PCVAE_PREC_SCREENED); ``screened`` forces
     (True) or forbids (False) that route."""
     table = _as_table(table)
@@ -452,9 +452,9 @@ def catalog_argmax(x, table, prec=PREC_F32, return_best=False, screened=None):
     R, D = x.shape
     N = table.weight.shape[0]
     # ids are index work: whatever precision the training loss runs in, the argmax is the exact fp32 one
-    use = (D == 128 and N >= SCREENED_MIN_ITEMS) if screened is None else bool(screened)
-    if use and D != 128:
-        raise ValueError("screened argmax exists for D = 128 only")
+    use = (D in BF16_DIMS and N >= SCREENED_MIN_ITEMS) if screened is None else bool(screened)
+    if use and D not in BF16_DIMS:
+        raise ValueError(f"screened argmax exists for D in {BF16_DIMS} only")
     if use:
         E, _ = table.operands(PREC_BF16)
         E_lo = table.weight

@@ -288,10 +288,11 @@ def test_catalog_argmax_ties_pick_lowest_index(ops):
     assert idx[0] == 7 and idx[1] == 7
 
 
-@pytest.mark.parametrize("R,N", [(1, 32), (37, 1000), (300, 20001), (256, 65536), (513, 131075), (64, 300000)])
-def test_catalog_argmax_screened_bit_exact(ops, R, N):
+@pytest.mark.parametrize("R,N,D", [(1, 32, 128), (37, 1000, 128), (300, 20001, 128), (256, 65536, 128), (513, 131075, 128),
+                                   (64, 300000, 128), (1, 32, 64), (300, 20001, 64), (513, 131075, 64), (70, 300000, 64),
+                                   (1, 32, 256), (300, 20001, 256), (260, 131075, 256), (64, 300000, 256)])
+def test_catalog_argmax_screened_bit_exact(ops, R, N, D):
     """bf16 screening + exact fp32 rescoring returns the same ids AND the same winning scores as the fp32 chain."""
-    D = 128
     x, E = rnd(R, D, seed=21, scale=2.0), unit_rows(N, D, seed=22)
     idx, best = ops.catalog_argmax(x.to(DEV), E.to(DEV), return_best=True, screened=True)
     wi, wb = co.argmax(x.numpy(), E.numpy())
@@ -301,10 +302,11 @@ def test_catalog_argmax_screened_bit_exact(ops, R, N):
     assert torch.equal(idx2, idx)
 
 
-def test_catalog_argmax_screened_near_ties_and_duplicates(ops):
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_catalog_argmax_screened_near_ties_and_duplicates(ops, D):
     """Rows whose bf16 images collide: duplicates (lowest index wins), items that differ by less than one bf16 ulp
     (the fp32 rescoring must separate them), queries of very different norm, negative-only scores."""
-    N, D = 70000, 128
+    N = 70000
     E = unit_rows(N, D, seed=5)
     dup = [11, 4097, 33000, 69999]
     E[dup] = E[11].clone()
@@ -333,7 +335,7 @@ def test_catalog_argmax_screened_unnormalised_table(ops):
 
 def test_catalog_argmax_screened_rejects_other_widths(ops):
     with pytest.raises(ValueError):
-        ops.catalog_argmax(rnd(4, 64, seed=1).to(DEV), unit_rows(100, 64, seed=2).to(DEV), screened=True)
+        ops.catalog_argmax(rnd(4, 32, seed=1).to(DEV), unit_rows(100, 32, seed=2).to(DEV), screened=True)
 
 
 def test_catalog_sample_distribution(ops):
