@@ -401,7 +401,8 @@ struct FastGeo {
 // U += A . B with the accumulator pinned in an AGPR quad (1 wave per SIMD: the compiler would otherwise move logits
 // accumulators there and pay a v_accvgpr_read per exponential)
 __device__ __forceinline__ void mfma_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    // wait states on both sides: hipcc does not know this is an MFMA and may copy an operand / the result right next to it
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
 }
 template <bool AG>
 __device__ __forceinline__ void mfma_u(f32x4& acc, const bf16x8& a, const bf16x8& b) {
@@ -423,6 +424,7 @@ __device__ __forceinline__ constexpr int fchunk(int s, int g) {
 
 struct FastLane {  // lane bases of the two LDS read patterns: address = base ^ constant + immediate
     int a0, t0, g;
+    bf16x8 ones;   // bf16 1.0 x 8: A operand of the row-sum MFMA (laundered through an empty asm: never rematerialised)
 };
 
 template <int D>
@@ -434,18 +436,25 @@ __device__ __forceinline__ FastLane fast_lane(int lane) {
     L.a0 = c * G::RB + ((fchunk<D>(0, g) ^ fswz<D>(c, 0)) << 4);
     const int row = 4 * g + q;
     L.t0 = row * G::RB + (((pp >> 1) ^ fswz<D>(row, 0)) << 4) + (pp & 1) * 8;
+    const s16x8 ones16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    L.ones = __builtin_bit_cast(bf16x8, ones16);
+    asm volatile("" : "+v"(L.ones));
     return L;
 }
 
+// DS instructions carry a 16-bit immediate offset: ring offsets beyond 48 KB move into the base register
+constexpr int ds_hi(int off) { return (off / 49152) * 49152; }
+
 template <int D, int OFF, int DT>
 __device__ __forceinline__ void tr_issue(const unsigned lbase, const int t0, s16x4& lo, s16x4& hi) {
-    const unsigned ad = lbase + (unsigned)(t0 ^ ((DT & 7) << 5));
-    lo = tr_read<OFF + (DT >> 3) * 256>(ad);
-    hi = tr_read<OFF + (DT >> 3) * 256 + FastGeo<D>::RT>(ad);
+    constexpr int HI = ds_hi(OFF), LO = OFF - HI;
+    const unsigned ad = lbase + (unsigned)HI + (unsigned)(t0 ^ ((DT & 7) << 5));
+    lo = tr_read<LO + (DT >> 3) * 256>(ad);
+    hi = tr_read<LO + (DT >> 3) * 256 + FastGeo<D>::RT>(ad);
 }
 
 // gradient chain, d tile DT: request d tile DT + 2, wait for the pieces of DT, two MFMAs
-template <int D, int OFF, int DT>
+template <int D, int OFF, int DT, bool AG = FastGeo<D>::ACC_AGPR>
 __device__ __forceinline__ void grad_chain(const unsigned lbase, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
                                            s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb)[2],
                                            f32x4 (&U)[FastGeo<D>::NDT][2]) {
@@ -462,9 +471,9 @@ __device__ __forceinline__ void grad_chain(const unsigned lbase, const int t0, s
         __builtin_amdgcn_sched_barrier(0);
         const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
-        mfma_u<FastGeo<D>::ACC_AGPR>(U[DT][0], a, pb[0]);
-        mfma_u<FastGeo<D>::ACC_AGPR>(U[DT][1], a, pb[1]);
-        grad_chain<D, OFF, DT + 1>(lbase, t0, tl, th, pb, U);
+        mfma_u<AG>(U[DT][0], a, pb[0]);
+        mfma_u<AG>(U[DT][1], a, pb[1]);
+        grad_chain<D, OFF, DT + 1, AG>(lbase, t0, tl, th, pb, U);
     }
 }
 
@@ -497,7 +506,7 @@ __device__ __forceinline__ void fast_logits(const char* smem, const int off, con
     }
 }
 
-template <int D, bool CHECK_N, int OFF>
+template <int D, bool CHECK_N, int OFF, bool AG = FastGeo<D>::ACC_AGPR>
 __device__ __forceinline__ void fast_subtile(const char* smem, const int off, const int64_t n0, const int64_t N,
                                              const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&U)[FastGeo<D>::NDT][2],
                                              f32x4 (&lsum)[2], const FastLane& L) {
@@ -520,17 +529,15 @@ __device__ __forceinline__ void fast_subtile(const char* smem, const int off, co
                 pb[ct][4 * rt + i] = (__bf16)e0;
                 pb[ct][4 * rt + i + 1] = (__bf16)e1;
             }
-    {
-        const s16x8 ones16 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones16);
-        mfma_u<G::ACC_AGPR>(lsum[0], ones, pb[0]);
-        mfma_u<G::ACC_AGPR>(lsum[1], ones, pb[1]);
-    }
+    // (inline-asm MFMAs are opaque to hipcc's hazard recogniser: a VALU result needs 2 wait states before an MFMA reads it)
+    if constexpr (AG) asm volatile("s_nop 1" ::: "memory");
+    mfma_u<AG>(lsum[0], L.ones, pb[0]);
+    mfma_u<AG>(lsum[1], L.ones, pb[1]);
     // ---- gradient chain: E^T pieces by asm transposed reads, requested two d tiles ahead
     s16x4 tl[G::NDT], th[G::NDT];
     tr_issue<D, OFF, 0>(lbase, L.t0, tl[0], th[0]);
     tr_issue<D, OFF, 1>(lbase, L.t0, tl[1], th[1]);
-    grad_chain<D, OFF, 0>(lbase, L.t0, tl, th, pb, U);
+    grad_chain<D, OFF, 0, AG>(lbase, L.t0, tl, th, pb, U);
 }
 
 // all subtiles of the 16 KB ring chunk that starts at byte OFFB (+ runtime `off`)
@@ -656,6 +663,12 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int i = 0; i < 4; ++i) lsum[ct][i] = 0.f;
+    if constexpr (G::ACC_AGPR) {  // materialise the zeros HERE, far from the first asm MFMA that reads them
+#pragma unroll
+        for (int dt = 0; dt < G::NDT; ++dt) { asm volatile("" : "+a"(U[dt][0])); asm volatile("" : "+a"(U[dt][1])); }
+        asm volatile("" : "+a"(lsum[0]));
+        asm volatile("" : "+a"(lsum[1]));
+    }
     const FastLane L = fast_lane<D>(lane);
 
     int cc = 0;
@@ -693,6 +706,7 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
             fast_subtile<D, true, 0>(smem, st * G::ST, (int64_t)(t + st) * 32, p.N, xb, U, lsum, L);
     }
 
+    if constexpr (G::ACC_AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> v_accvgpr_read
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const float l = lsum[ct][0];
@@ -702,6 +716,375 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
             if (g == 0) { p.pm[o] = 0.f; p.pl[o] = l; }
 #pragma unroll
             for (int dt = 0; dt < G::NDT; ++dt)  // U[dt][ct][reg] = U^T[d = 16 dt + 4 g + reg][r]
+                *reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g) =
+                    make_float4(U[dt][ct][0], U[dt][ct][1], U[dt][ct][2], U[dt][ct][3]);
+        }
+    }
+}
+
+
+// =============================================================================================
+// Software-pipelined form of the fast kernel: ONE wave per SIMD (4 waves x 32 rows, 512 registers each), every MFMA and
+// LDS read an inline-asm statement so that the instruction order below IS the schedule.  hipcc, left to itself at this
+// occupancy, parks the logits accumulators in AGPRs (a v_accvgpr_read per exponential) and reloads one A fragment
+// register per k-step behind s_waitcnt lgkmcnt(0) - a fully exposed LDS latency sixteen times per subtile.
+//
+// Slot t of the pipeline (one 32-item subtile per slot):
+//     L(t)               logits chain of subtile t: D/16 A fragments (ds_read_b128, two ahead) x 2 MFMAs each
+//     G(t-1) || X(t)     gradient chain of the PREVIOUS subtile (2 + D/8 MFMAs, transposed reads two d tiles ahead) with
+//                        the exponentials / bf16 packing of THIS subtile in its issue gaps (an MFMA holds the issue
+//                        port for 8 of its 16 cycles, a v_exp_f32 for 8: one per MFMA fits)
+//     seam(t+1)          in the middle of that chain: counted vmcnt + s_barrier, refill of the ring buffer that held
+//                        chunk t-2, and the first two A fragments of L(t+1) - so no slot starts with a cold LDS read
+// Ring: 6 x 16 KB, chunks requested three ahead (chunk t is read by L(t) and by G(t) one slot later).
+// Hazards hipcc cannot see through inline asm are kept by construction: an accumulator is read by the VALU >= 7 MFMAs
+// after the MFMA that wrote it; the bf16 numerators are consumed by MFMAs one slot after they were packed.
+// =============================================================================================
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_b128(const unsigned addr) {
+    bf16x8 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// COLD = true: the statement carries its own wait states (2 before: a copy hipcc placed in front may have just written an
+// operand; 16 behind: a copy placed after may read the result).  Used everywhere except the steady-state loop, whose
+// generated code contains no such copies.
+template <bool COLD>
+__device__ __forceinline__ void mfma_v0(f32x4& acc, const bf16x8& a, const bf16x8& b) {  // acc = A . B
+    if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15" : "=&v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+template <bool COLD>
+__device__ __forceinline__ void mfma_v(f32x4& acc, const bf16x8& a, const bf16x8& b) {   // acc += A . B
+    if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+v"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <bool COLD>
+__device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& a, const bf16x8& b) {   // acc (AGPR) += A . B
+    if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// first consumer of operands hipcc may have just copied into place (a VALU result needs 2 wait states before an MFMA)
+__device__ __forceinline__ void mfma_agpr_guarded(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// hipcc cannot see that the asm statements are MFMAs, so it inserts no wait states around the register copies it
+// makes where control flow merges (v_accvgpr_mov of U between the cold paths' register assignments): every cold path is
+// fenced - 32 idle cycles let the last MFMA retire before a copy reads its result.  The steady-state loop body has no
+// copies (tests/test_host_logic.py checks the generated ISA) and is fenced once per trip, at its latch.
+__device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
+
+constexpr int PIPE_NB = 6;   // ring buffers
+constexpr int PIPE_PF = 3;   // chunks requested ahead
+
+template <int D, int OFF, int I>
+__device__ __forceinline__ void pipe_a_issue(const unsigned lbase, const int a0, bf16x8& a) {
+    using G = FastGeo<D>;
+    constexpr int s = I >> 1, rt = I & 1;
+    constexpr int HI = ds_hi(OFF), LO = OFF - HI;
+    a = lds_read_b128<LO + rt * G::RT + (s >> 2) * 256>(lbase + (unsigned)HI + (unsigned)(a0 ^ ((s & G::KMASK) << 4)));
+}
+
+// L(t): step I = (k-step s, row tile rt); A fragments I = 0, 1 are already in flight
+template <int D, int OFF, int I, bool COLD>
+__device__ __forceinline__ void pipe_logits(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS],
+                                            const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&acc)[2][2]) {
+    constexpr int NI = 2 * FastGeo<D>::KS;
+    if constexpr (I < NI) {
+        if constexpr (I + 2 < NI) {
+            pipe_a_issue<D, OFF, I + 2>(lbase, a0, af[I + 2]);
+            lgkm_wait<2>();
+        } else if constexpr (I + 2 == NI) {
+            lgkm_wait<1>();
+        } else {
+            lgkm_wait<0>();
+        }
+        constexpr int s = I >> 1, rt = I & 1;
+        if constexpr (s == 0) {
+            mfma_v0<COLD>(acc[rt][0], af[I], xb[0][s]);
+            mfma_v0<COLD>(acc[rt][1], af[I], xb[1][s]);
+        } else {
+            mfma_v<COLD>(acc[rt][0], af[I], xb[0][s]);
+            mfma_v<COLD>(acc[rt][1], af[I], xb[1][s]);
+        }
+        pipe_logits<D, OFF, I + 1, COLD>(lbase, a0, af, xb, acc);
+    }
+}
+
+// numerators, pinned in place by inline asm (plain builtins have no ordering against the asm MFMAs and end up bunched
+// behind the seam): pair k = (row tile rt, column tile ct, half h) is two exponentials at one point of the chain and one
+// packed conversion a step later (a transcendental result needs an independent instruction before a VALU consumer)
+struct PipeNum {
+    float e[8][2];      // exponentials of pair k
+    unsigned w[2][4];   // packed bf16 pairs: w[ct][2 rt + h]
+};
+template <int K>
+__device__ __forceinline__ void pipe_exp(const f32x4 (&acc)[2][2], PipeNum& nm) {
+    constexpr int rt = K >> 2, ct = (K >> 1) & 1, h = K & 1;
+    asm volatile("v_exp_f32 %0, %1" : "=v"(nm.e[K][0]) : "v"(acc[rt][ct][2 * h]));
+    asm volatile("v_exp_f32 %0, %1" : "=v"(nm.e[K][1]) : "v"(acc[rt][ct][2 * h + 1]));
+}
+template <int K>
+__device__ __forceinline__ void pipe_cvt(PipeNum& nm) {
+    constexpr int rt = K >> 2, ct = (K >> 1) & 1, h = K & 1;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(nm.w[ct][2 * rt + h]) : "v"(nm.e[K][0]), "v"(nm.e[K][1]));
+}
+__device__ __forceinline__ void pipe_pack(const PipeNum& nm, bf16x8 (&pb)[2]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const u32x4 v = {nm.w[ct][0], nm.w[ct][1], nm.w[ct][2], nm.w[ct][3]};
+        pb[ct] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+struct PipeSeam {           // what the seam in the middle of slot t does (all wave-uniform)
+    const uint16_t* E;
+    int64_t n_stage;        // first item of the chunk to request, < 0: nothing to request
+    char* stage_buf;        // its ring buffer
+    unsigned next_lbase;    // LDS address (minus the immediate) of the NEXT slot's chunk, for its first two A fragments
+};
+
+// G(t-1) || X(t) with seam(t+1) after d tile SEAM_AT
+template <int D, int OFFG, int OFFL_NEXT, int DT, bool HAS_G, int VM, bool COLD>
+__device__ __forceinline__ void pipe_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
+                                          s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb_prev)[2], bf16x8 (&pb_next)[2],
+                                          f32x4 (&acc)[2][2], f32x4 (&U)[FastGeo<D>::NDT][2], const PipeSeam& sm,
+                                          const int wave_u, const int (&lane_off)[4], const int a0,
+                                          bf16x8 (&af)[2 * FastGeo<D>::KS], PipeNum& nm) {
+    using G = FastGeo<D>;
+    constexpr int NDT = G::NDT, SEAM_AT = NDT / 2;       // seam after the MFMAs of d tile SEAM_AT - 1
+    constexpr int UNIT_EVERY = NDT / 8;                  // 8 numerator pairs spread over the NDT d tiles
+    if constexpr (DT < NDT) {
+        if constexpr (DT == SEAM_AT) {
+            if constexpr (COLD) pipe_fence();
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+            if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+            if constexpr (COLD) pipe_fence();
+            // first two A fragments of the next slot's logits chain (the last slot reads its own chunk again: the counted
+            // waits below assume these two reads are in flight)
+            pipe_a_issue<D, OFFL_NEXT, 0>(sm.next_lbase, a0, af[0]);
+            pipe_a_issue<D, OFFL_NEXT, 1>(sm.next_lbase, a0, af[1]);
+        }
+        if constexpr (HAS_G) {
+            // outstanding LDS reads younger than the pieces of d tile DT: d tiles DT+1, DT+2 (two reads each) and, for the
+            // two d tiles after the seam, the two A fragments issued there
+            constexpr int extra = (DT == SEAM_AT || DT == SEAM_AT + 1) ? 2 : 0;
+            if constexpr (DT + 2 < NDT) {
+                tr_issue<D, OFFG, DT + 2>(lbase_g, t0, tl[DT + 2], th[DT + 2]);
+                lgkm_wait<4 + extra>();
+            } else if constexpr (DT + 2 == NDT) {
+                lgkm_wait<2 + extra>();
+            } else {
+                lgkm_wait<0 + extra>();
+            }
+            const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
+            const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+            mfma_a<COLD>(U[DT][0], a, pb_prev[0]);
+            mfma_a<COLD>(U[DT][1], a, pb_prev[1]);
+        }
+        if constexpr (DT % UNIT_EVERY == 0) {             // pair K: exponentials now, conversion of pair K - 1
+            constexpr int K = DT / UNIT_EVERY;
+            pipe_exp<K>(acc, nm);
+            if constexpr (K > 0) pipe_cvt<K - 1>(nm);
+        }
+        if constexpr (DT == NDT - 1) {
+            pipe_cvt<7>(nm);
+            pipe_pack(nm, pb_next);
+        }
+        pipe_grad<D, OFFG, OFFL_NEXT, DT + 1, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pb_prev, pb_next, acc, U, sm, wave_u,
+                                                               lane_off, a0, af, nm);
+    } else if constexpr (COLD) {
+        pipe_fence();
+    }
+}
+
+// one slot.  lbase_l / lbase_g: LDS addresses (smem base + runtime ring offset) of subtile t / t-1
+template <int D, int OFFL, int OFFG, int OFFL_NEXT, bool HAS_G, int VM, bool COLD>
+__device__ __forceinline__ void pipe_slot(const unsigned lbase_l, const unsigned lbase_g, const FastLane& L,
+                                          const bf16x8 (&xb)[2][FastGeo<D>::KS], bf16x8 (&af)[2 * FastGeo<D>::KS],
+                                          f32x4 (&acc)[2][2], const bf16x8 (&pb_prev)[2], bf16x8 (&pb_next)[2],
+                                          f32x4 (&U)[FastGeo<D>::NDT][2], f32x4 (&lsum)[2], const PipeSeam& sm,
+                                          const int wave_u, const int (&lane_off)[4]) {
+    using G = FastGeo<D>;
+    if constexpr (COLD) pipe_fence();
+    pipe_logits<D, OFFL, 0, COLD>(lbase_l, L.a0, af, xb, acc);
+    s16x4 tl[G::NDT], th[G::NDT];
+    if constexpr (HAS_G) {
+        tr_issue<D, OFFG, 0>(lbase_g, L.t0, tl[0], th[0]);
+        tr_issue<D, OFFG, 1>(lbase_g, L.t0, tl[1], th[1]);
+        if constexpr (COLD) {
+            mfma_a<true>(lsum[0], L.ones, pb_prev[0]);
+            mfma_a<true>(lsum[1], L.ones, pb_prev[1]);
+        } else {
+            mfma_agpr_guarded(lsum[0], L.ones, pb_prev[0]);
+            mfma_agpr_guarded(lsum[1], L.ones, pb_prev[1]);
+        }
+    } else {
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // no MFMAs between the logits chain and the first exponential
+    }
+    PipeNum nm;
+    pipe_grad<D, OFFG, OFFL_NEXT, 0, HAS_G, VM, COLD>(lbase_g, L.t0, tl, th, pb_prev, pb_next, acc, U, sm, wave_u, lane_off,
+                                                      L.a0, af, nm);
+}
+
+// the gradient chain of the last subtile on its own (pipeline drain)
+template <int D>
+__device__ __forceinline__ void pipe_drain(const unsigned lbase_g, const FastLane& L, const bf16x8 (&pb_prev)[2],
+                                           f32x4 (&U)[FastGeo<D>::NDT][2], f32x4 (&lsum)[2]) {
+    using G = FastGeo<D>;
+    s16x4 tl[G::NDT], th[G::NDT];
+    pipe_fence();
+    tr_issue<D, 0, 0>(lbase_g, L.t0, tl[0], th[0]);
+    tr_issue<D, 0, 1>(lbase_g, L.t0, tl[1], th[1]);
+    mfma_a<true>(lsum[0], L.ones, pb_prev[0]);
+    mfma_a<true>(lsum[1], L.ones, pb_prev[1]);
+    grad_chain<D, 0, 0, true>(lbase_g, L.t0, tl, th, pb_prev, U);
+    pipe_fence();
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB p) {
+    using G = FastGeo<D>;
+    static_assert(G::SUB == 1, "one subtile per 16 KB ring chunk (D = 256)");
+    constexpr int CB = 16384, NW = 4, ROWS = NW * 32;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int nrb = p.nrb * (ROWS_WG / ROWS);
+    const int split = logical / nrb, rb = logical % nrb;
+    if ((int64_t)rb * ROWS >= p.R) return;
+    if (p.safe_flags[rb / (ROWS_WG / ROWS)] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int64_t nbase = (int64_t)t_beg * 32;
+    int T = (int)min((int64_t)(t_end - t_beg), (p.N - nbase) / 32);   // full 32-item chunks of this range
+    T = max(T, 0);
+
+    const int64_t rw = (int64_t)rb * ROWS + wave * 32;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int lane_off[4];
+    fast_lane_off<D, NW>(lane, wave, lane_off);
+#pragma unroll
+    for (int c0 = 0; c0 <= PIPE_PF; ++c0)  // prologue: chunks 0..3 in flight
+        if (c0 < T) fast_stage<D, NW>(p.E, nbase + (int64_t)c0 * 32, smem + c0 * CB, wave_u, lane_off);
+
+    bf16x8 xb[2][G::KS];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int64_t r = rw + 16 * ct + c;
+        const int64_t rl = r < p.R ? r : p.R - 1;
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * fchunk<D>(s, g));
+            const float4 v1 = *reinterpret_cast<const float4*>(p.rx + rl * D + 8 * fchunk<D>(s, g) + 4);
+            xb[ct][s][0] = (__bf16)(v0.x * kLog2e); xb[ct][s][1] = (__bf16)(v0.y * kLog2e);
+            xb[ct][s][2] = (__bf16)(v0.z * kLog2e); xb[ct][s][3] = (__bf16)(v0.w * kLog2e);
+            xb[ct][s][4] = (__bf16)(v1.x * kLog2e); xb[ct][s][5] = (__bf16)(v1.y * kLog2e);
+            xb[ct][s][6] = (__bf16)(v1.z * kLog2e); xb[ct][s][7] = (__bf16)(v1.w * kLog2e);
+        }
+    }
+    f32x4 U[G::NDT][2];
+#pragma unroll
+    for (int dt = 0; dt < G::NDT; ++dt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) U[dt][ct][i] = 0.f;
+    f32x4 lsum[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lsum[ct][i] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < G::NDT; ++dt) { asm volatile("" : "+a"(U[dt][0])); asm volatile("" : "+a"(U[dt][1])); }
+    asm volatile("" : "+a"(lsum[0]));
+    asm volatile("" : "+a"(lsum[1]));
+    const FastLane L = fast_lane<D>(lane);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    f32x4 acc[2][2];
+    bf16x8 af[2 * G::KS];
+    bf16x8 pb[2][2];   // numerators of the even / odd slots
+
+    // seam of slot t (executed in the middle of slot t): chunk t+1 landed, request chunk t+1+PF, first A fragments of L(t+1)
+    auto seam_of = [&](int t) {
+        PipeSeam sm;
+        sm.E = p.E;
+        const int cs = t + 1 + PIPE_PF;
+        sm.n_stage = cs < T ? nbase + (int64_t)cs * 32 : -1;
+        sm.stage_buf = smem + (cs % PIPE_NB) * CB;
+        sm.next_lbase = lds0;
+        return sm;
+    };
+
+    int t = 0;
+    if (T > 0) {
+        // seam(0): chunk 0 landed (chunks 1..3 may still be in flight), then the first two A fragments of L(0)
+        if (T > PIPE_PF) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        pipe_a_issue<D, 0, 0>(lds0, L.a0, af[0]);
+        pipe_a_issue<D, 0, 1>(lds0, L.a0, af[1]);
+        // slot 0: no gradient chain yet
+        PipeSeam sm = seam_of(0);
+        sm.next_lbase = T > 1 ? lds0 + 1 * CB : lds0;
+        if (T > 1 + PIPE_PF) pipe_slot<D, 0, 0, 0, false, 2 * 4, true>(lds0, lds0, L, xb, af, acc, pb[1], pb[0], U, lsum, sm, wave_u, lane_off);
+        else pipe_slot<D, 0, 0, 0, false, 0, true>(lds0, lds0, L, xb, af, acc, pb[1], pb[0], U, lsum, sm, wave_u, lane_off);
+        t = 1;
+        // steady state: 6 slots per trip, every LDS offset an immediate.  Slot t reads ring buffer t % 6 (L) and (t-1) % 6 (G).
+        for (; t + PIPE_NB - 1 + 1 + PIPE_PF < T; t += PIPE_NB) {
+#define PCVAE_PIPE_SLOT(UU)                                                                                               \
+            {                                                                                                             \
+                constexpr int BL = (1 + UU) % PIPE_NB, BG = UU % PIPE_NB, BN = (2 + UU) % PIPE_NB;                        \
+                PipeSeam s2 = seam_of(t + UU);                                                                            \
+                s2.next_lbase = lds0;                                                                                     \
+                pipe_slot<D, BL * CB, BG * CB, BN * CB, true, 2 * 4, false>(lds0, lds0, L, xb, af, acc, pb[UU & 1],       \
+                                                                            pb[(UU & 1) ^ 1], U, lsum, s2, wave_u, lane_off); \
+            }
+            PCVAE_PIPE_SLOT(0) PCVAE_PIPE_SLOT(1) PCVAE_PIPE_SLOT(2) PCVAE_PIPE_SLOT(3) PCVAE_PIPE_SLOT(4) PCVAE_PIPE_SLOT(5)
+#undef PCVAE_PIPE_SLOT
+            pipe_fence();  // latch: loop-carried copies (if hipcc ever makes any) read retired results
+        }
+        // the last slots: runtime ring offsets, seams that drain the ring (vmcnt(0))
+        for (; t < T; ++t) {
+            PipeSeam s2 = seam_of(t);
+            s2.next_lbase = lds0 + ((t + 1 < T ? t + 1 : t) % PIPE_NB) * CB;
+            const unsigned ll = lds0 + (t % PIPE_NB) * CB, lg = lds0 + ((t - 1) % PIPE_NB) * CB;
+            if (t & 1) pipe_slot<D, 0, 0, 0, true, 0, true>(ll, lg, L, xb, af, acc, pb[0], pb[1], U, lsum, s2, wave_u, lane_off);
+            else pipe_slot<D, 0, 0, 0, true, 0, true>(ll, lg, L, xb, af, acc, pb[1], pb[0], U, lsum, s2, wave_u, lane_off);
+        }
+        // drain: gradient chain of subtile T-1
+        if ((T - 1) & 1) pipe_drain<D>(lds0 + ((T - 1) % PIPE_NB) * CB, L, pb[1], U, lsum);
+        else pipe_drain<D>(lds0 + ((T - 1) % PIPE_NB) * CB, L, pb[0], U, lsum);
+    }
+    // ---- tail: short / ragged chunks, staged synchronously with clamped addresses (plain subtile code, asm accumulators)
+    for (int tt = t_beg + T; tt < t_end; tt += 4) {
+        __syncthreads();
+        fast_stage_tail<D, NW>(p.E, p.N, (int64_t)tt * 32, smem);
+        __syncthreads();
+        const int nsub = min(4, t_end - tt);
+        for (int st = 0; st < nsub; ++st) {
+            fast_subtile<D, true, 0, true>(smem, st * G::ST, (int64_t)(tt + st) * 32, p.N, xb, U, lsum, L);
+            pipe_fence();
+        }
+    }
+    pipe_fence();  // last asm MFMA -> the stores below read the accumulators
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const float l = lsum[ct][0];
+        const int64_t r = rw + 16 * ct + c;
+        if (r < p.R) {
+            const int64_t o = (int64_t)split * p.R + r;
+            if (g == 0) { p.pm[o] = 0.f; p.pl[o] = l; }
+#pragma unroll
+            for (int dt = 0; dt < G::NDT; ++dt)
                 *reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g) =
                     make_float4(U[dt][ct][0], U[dt][ct][1], U[dt][ct][2], U[dt][ct][3]);
         }
@@ -785,6 +1168,18 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
                 attr_set = true;
             }
             const dim3 fgrid((unsigned)(p.nrb * (ROWS_WG / FastGeo<D>::ROWS) * p.nsplit)), fblock(FastGeo<D>::NW * 64);
+#ifndef PCVAE_NO_PIPE
+            if constexpr (D == 256) {
+                constexpr int lds_pipe = PIPE_NB * 16384;
+                static bool attr_set2 = false;
+                if (!attr_set2) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_pipe_kernel<D>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
+                    attr_set2 = true;
+                }
+                hipLaunchKernelGGL((catalog_ce_bf16_pipe_kernel<D>), fgrid, dim3(256), lds_pipe, st, p);
+            } else
+#endif
             hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), fgrid, fblock, lds_fast, st, p);
         }
         int rc0 = check_launch("catalog_ce_bf16_fast");

@@ -1,0 +1,38 @@
+#!/bin/bash
+# profile_round.sh <tag>: the evidence behind bench.py's roofline block, for one round (run on the GPU box).
+#   1. bench.py (config 4, bf16) plain                                   -> gpurun_out/prof_<tag>/bench.json
+#   2. the same command under rocprofv3 --kernel-trace --stats            -> kernel_stats.csv, bench_under_rocprof.json
+#   3. separate --pmc passes (kernel-trace only) for HBM traffic and SQ    -> pmc_<set>.csv (per-kernel means)
+#   4. kernel stats of config 3 and config 5
+TAG=${1:-r01}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $ROOT/bench.py > $OUT/bench.log 2>&1 && grep '^{"metric"' $OUT/bench.log | tail -1 > $OUT/bench.json
+echo "[1] plain bench done" | tee -a $OUT/progress.log
+stats() {  # stats <name> <bench args...>
+  local name=$1; shift
+  rm -rf $OUT/trace_$name
+  timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- python3 $ROOT/bench.py "$@" > $OUT/trace_$name.log 2>&1
+  grep '^{"metric"' $OUT/trace_$name.log | tail -1 > $OUT/${name}_bench_under_rocprof.json
+  find $OUT/trace_$name -name "*kernel_stats.csv" -exec cp {} $OUT/${name}_kernel_stats.csv \;
+  rm -rf $OUT/trace_$name
+  echo "[stats] $name done" | tee -a $OUT/progress.log
+}
+stats config4 --steps 5 --warmup 2
+pmc() {  # pmc <name> "<counters>"
+  local name=$1
+  rm -rf $OUT/pmc_$name
+  timeout -k 10 600 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_$name.log 2>&1
+  python3 $ROOT/tools/summarize_pmc.py $OUT/pmc_$name > $OUT/config4_pmc_$name.csv
+  rm -rf $OUT/pmc_$name
+  echo "[pmc] $name done" | tee -a $OUT/progress.log
+}
+pmc FETCH_SIZE "FETCH_SIZE"
+pmc WRITE_SIZE "WRITE_SIZE"
+pmc SQ1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+pmc SQ2 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"
+stats config3 --config 3 --steps 5 --warmup 2
+stats config5 --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+ls -la $OUT
