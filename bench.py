@@ -375,7 +375,8 @@ def main():
                    "catalog_arithmetic": args.dtype, "mlp_arithmetic": "f32",
                    "launch": "hipGraph replay (zero-grad+fwd+bwd) + eager all-reduce + Adam" if graphed else "eager"},
         "elbo": {"loss": loss.item(), "recLoss": rec.item(), "KLD": kld.item()},
-        "roofline": {"kernel": (f"catalog_ce_bf16_fast_kernel<{D}>" if (args.dtype == "bf16" and D in ops.BF16_DIMS) else
+        "roofline": {"kernel": ((f"catalog_ce_bf16_pipe_kernel<{D}>" if D == 256 else f"catalog_ce_bf16_fast_kernel<{D}>")
+                                if (args.dtype == "bf16" and D in ops.BF16_DIMS) else
                                 f"catalog_ce_{args.dtype}_kernel<{D}>") + " (events also span its row-bound prologue and "
                                "merge kernels, <1% together)", "bound": "mfma",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

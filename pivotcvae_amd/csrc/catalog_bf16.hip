@@ -781,6 +781,12 @@ __device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 1
 
 constexpr int PIPE_NB = 6;   // ring buffers
 constexpr int PIPE_PF = 3;   // chunks requested ahead
+#ifndef PIPE_TD
+#define PIPE_TD 2            // transposed reads: d tiles requested ahead (2 reads each)
+#endif
+#ifndef PIPE_AD
+#define PIPE_AD 2            // logits chain: A fragments requested ahead (the first PIPE_AD are issued at the previous seam)
+#endif
 
 template <int D, int OFF, int I>
 __device__ __forceinline__ void pipe_a_issue(const unsigned lbase, const int a0, bf16x8& a) {
@@ -790,20 +796,14 @@ __device__ __forceinline__ void pipe_a_issue(const unsigned lbase, const int a0,
     a = lds_read_b128<LO + rt * G::RT + (s >> 2) * 256>(lbase + (unsigned)HI + (unsigned)(a0 ^ ((s & G::KMASK) << 4)));
 }
 
-// L(t): step I = (k-step s, row tile rt); A fragments I = 0, 1 are already in flight
+// L(t): step I = (k-step s, row tile rt); A fragments I = 0 .. PIPE_AD-1 are already in flight
 template <int D, int OFF, int I, bool COLD>
 __device__ __forceinline__ void pipe_logits(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS],
                                             const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&acc)[2][2]) {
     constexpr int NI = 2 * FastGeo<D>::KS;
     if constexpr (I < NI) {
-        if constexpr (I + 2 < NI) {
-            pipe_a_issue<D, OFF, I + 2>(lbase, a0, af[I + 2]);
-            lgkm_wait<2>();
-        } else if constexpr (I + 2 == NI) {
-            lgkm_wait<1>();
-        } else {
-            lgkm_wait<0>();
-        }
+        if constexpr (I + PIPE_AD < NI) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
+        lgkm_wait<(I + PIPE_AD < NI ? PIPE_AD : NI - 1 - I)>();   // fragments younger than I still in flight
         constexpr int s = I >> 1, rt = I & 1;
         if constexpr (s == 0) {
             mfma_v0<COLD>(acc[rt][0], af[I], xb[0][s]);
@@ -813,6 +813,23 @@ __device__ __forceinline__ void pipe_logits(const unsigned lbase, const int a0, 
             mfma_v<COLD>(acc[rt][1], af[I], xb[1][s]);
         }
         pipe_logits<D, OFF, I + 1, COLD>(lbase, a0, af, xb, acc);
+    }
+}
+
+// issue the first K A fragments of a logits chain
+template <int D, int OFF, int K>
+__device__ __forceinline__ void pipe_a_prologue(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS]) {
+    if constexpr (K > 0) {
+        pipe_a_prologue<D, OFF, K - 1>(lbase, a0, af);
+        pipe_a_issue<D, OFF, K - 1>(lbase, a0, af[K - 1]);
+    }
+}
+template <int D, int OFF, int K>
+__device__ __forceinline__ void pipe_tr_prologue(const unsigned lbase, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
+                                                 s16x4 (&th)[FastGeo<D>::NDT]) {
+    if constexpr (K > 0) {
+        pipe_tr_prologue<D, OFF, K - 1>(lbase, t0, tl, th);
+        tr_issue<D, OFF, K - 1>(lbase, t0, tl[K - 1], th[K - 1]);
     }
 }
 
@@ -826,6 +843,11 @@ struct PipeNum {
 template <int K>
 __device__ __forceinline__ void pipe_exp(const f32x4 (&acc)[2][2], PipeNum& nm) {
     constexpr int rt = K >> 2, ct = (K >> 1) & 1, h = K & 1;
+#ifdef PIPE_EXPERIMENT_NO_EXP   // timing experiment only (wrong results): what do the exponentials cost?
+    asm volatile("v_mov_b32 %0, %1" : "=v"(nm.e[K][0]) : "v"(acc[rt][ct][2 * h]));
+    nm.e[K][1] = nm.e[K][0];
+    return;
+#endif
     asm volatile("v_exp_f32 %0, %1" : "=v"(nm.e[K][0]) : "v"(acc[rt][ct][2 * h]));
     asm volatile("v_exp_f32 %0, %1" : "=v"(nm.e[K][1]) : "v"(acc[rt][ct][2 * h + 1]));
 }
@@ -863,26 +885,23 @@ __device__ __forceinline__ void pipe_grad(const unsigned lbase_g, const int t0, 
     if constexpr (DT < NDT) {
         if constexpr (DT == SEAM_AT) {
             if constexpr (COLD) pipe_fence();
+#ifdef PIPE_EXPERIMENT_NO_BARRIER   // timing experiment only (racy): what does the seam barrier cost?
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+#else
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+#endif
             if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
             if constexpr (COLD) pipe_fence();
             // first two A fragments of the next slot's logits chain (the last slot reads its own chunk again: the counted
             // waits below assume these two reads are in flight)
-            pipe_a_issue<D, OFFL_NEXT, 0>(sm.next_lbase, a0, af[0]);
-            pipe_a_issue<D, OFFL_NEXT, 1>(sm.next_lbase, a0, af[1]);
+            pipe_a_prologue<D, OFFL_NEXT, PIPE_AD>(sm.next_lbase, a0, af);
         }
         if constexpr (HAS_G) {
-            // outstanding LDS reads younger than the pieces of d tile DT: d tiles DT+1, DT+2 (two reads each) and, for the
-            // two d tiles after the seam, the two A fragments issued there
-            constexpr int extra = (DT == SEAM_AT || DT == SEAM_AT + 1) ? 2 : 0;
-            if constexpr (DT + 2 < NDT) {
-                tr_issue<D, OFFG, DT + 2>(lbase_g, t0, tl[DT + 2], th[DT + 2]);
-                lgkm_wait<4 + extra>();
-            } else if constexpr (DT + 2 == NDT) {
-                lgkm_wait<2 + extra>();
-            } else {
-                lgkm_wait<0 + extra>();
-            }
+            // LDS reads younger than the pieces of d tile DT and still in flight: the d tiles requested after it (two reads
+            // each) and, for the PIPE_TD d tiles whose pieces were requested before the seam, the A fragments issued there
+            constexpr int extra = (DT >= SEAM_AT && DT < SEAM_AT + PIPE_TD) ? PIPE_AD : 0;
+            if constexpr (DT + PIPE_TD < NDT) tr_issue<D, OFFG, DT + PIPE_TD>(lbase_g, t0, tl[DT + PIPE_TD], th[DT + PIPE_TD]);
+            lgkm_wait<2 * ((DT + PIPE_TD < NDT ? DT + PIPE_TD : NDT - 1) - DT) + extra>();
             const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
             const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
             mfma_a<COLD>(U[DT][0], a, pb_prev[0]);
@@ -916,8 +935,7 @@ __device__ __forceinline__ void pipe_slot(const unsigned lbase_l, const unsigned
     pipe_logits<D, OFFL, 0, COLD>(lbase_l, L.a0, af, xb, acc);
     s16x4 tl[G::NDT], th[G::NDT];
     if constexpr (HAS_G) {
-        tr_issue<D, OFFG, 0>(lbase_g, L.t0, tl[0], th[0]);
-        tr_issue<D, OFFG, 1>(lbase_g, L.t0, tl[1], th[1]);
+        pipe_tr_prologue<D, OFFG, PIPE_TD>(lbase_g, L.t0, tl, th);
         if constexpr (COLD) {
             mfma_a<true>(lsum[0], L.ones, pb_prev[0]);
             mfma_a<true>(lsum[1], L.ones, pb_prev[1]);
@@ -1030,8 +1048,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
         // seam(0): chunk 0 landed (chunks 1..3 may still be in flight), then the first two A fragments of L(0)
         if (T > PIPE_PF) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        pipe_a_issue<D, 0, 0>(lds0, L.a0, af[0]);
-        pipe_a_issue<D, 0, 1>(lds0, L.a0, af[1]);
+        pipe_a_prologue<D, 0, PIPE_AD>(lds0, L.a0, af);
         // slot 0: no gradient chain yet
         PipeSeam sm = seam_of(0);
         sm.next_lbase = T > 1 ? lds0 + 1 * CB : lds0;
