@@ -156,3 +156,18 @@ def test_lds_bank_model_of_the_catalog_kernels():
     import subprocess, sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lds_bank_check.py")], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
+    """The software-pipelined catalog kernel issues its MFMAs as inline asm; hipcc must not place register copies
+    (v_accvgpr_*, v_mov_*, scratch) inside its steady-state loop, where no wait states protect them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_loop_check", os.path.join(ROOT, "tools", "isa_loop_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    loops = mod.hot_loops()
+    assert loops, "pipelined kernel not found in the generated ISA"
+    for name, loop in loops.items():
+        bad = [l for l in loop if l.startswith(mod.FORBIDDEN)]
+        assert not bad, (name, bad[:5])
+        assert sum(l.startswith("v_mfma") for l in loop) >= 64

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Check of the generated ISA of the software-pipelined catalog kernel (catalog_bf16.hip).
+
+Its MFMAs are inline asm, so hipcc's hazard recogniser does not protect register copies it might place next to them.
+The steady-state loop is correct only while hipcc places NO such copy inside it; this script disassembles the kernel,
+finds the steady-state loop (the longest backward `s_branch` loop) and fails if it contains v_accvgpr_* / v_mov_* /
+scratch_* instructions.  Run by tests/test_host_logic.py (no GPU needed: hipcc cross-compiles)."""
+import collections
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FORBIDDEN = ("v_accvgpr_", "v_mov_b", "scratch_", "buffer_store", "v_readlane", "v_writelane")
+
+
+def hot_loops(pattern="pipe_kernel"):
+    src = os.path.join(ROOT, "pivotcvae_amd", "csrc", "catalog_bf16.hip")
+    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
+                          src, "-o", "-"], capture_output=True, text=True, check=True).stdout
+    out = {}
+    for m in re.finditer(r"^(_Z\S+):\s*; @", asm, re.M):
+        name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
+        if pattern not in name:
+            continue
+        body = asm[m.end():asm.find(".Lfunc_end", m.end())].split("\n")
+        lines = [l.split(";")[0].strip() for l in body]
+        labels = {mm.group(1): n for n, l in enumerate(lines) if (mm := re.match(r"(\.LBB\d+_\d+):", l))}
+        best = None
+        for n, l in enumerate(lines):
+            mm = re.match(r"s_branch\s+(\.LBB\d+_\d+)", l)
+            if mm and labels.get(mm.group(1), 1 << 30) < n:
+                lo = labels[mm.group(1)]
+                mf = sum("v_mfma" in x for x in lines[lo:n])
+                if best is None or mf > best[2]:
+                    best = (lo, n, mf)
+        loop = [l for l in lines[best[0]:best[1] + 1] if l and not l.startswith(".")]
+        out[re.sub(r"\(anonymous namespace\)::", "", name)] = loop
+    return out
+
+
+def main():
+    ok = True
+    for name, loop in hot_loops().items():
+        c = collections.Counter(l.split()[0] for l in loop)
+        bad = [l for l in loop if l.startswith(FORBIDDEN)]
+        print(f"{name[:70]}: {len(loop)} instructions, {c['v_mfma_f32_16x16x32_bf16']} MFMA, {len(bad)} forbidden")
+        for b in bad[:10]:
+            print("   ", b)
+        ok = ok and not bad and c["v_mfma_f32_16x16x32_bf16"] >= 64
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
