@@ -72,6 +72,14 @@ def synthetic_batch(cfg, B, device, seed=1):
     return s, r, u
 
 
+def kernel_name(R, N, D, dtype):
+    """the dominant kernel's name as rocprofv3 shows it (the library reports which variant a shape runs)"""
+    from pivotcvae_amd import _hip
+    v = _hip.lib().pcvae_catalog_ce_variant(R, N, D, _hip.PREC_NAMES[dtype])
+    return {0: f"catalog_ce_f32_kernel<{D}>", 1: f"catalog_ce_bf16_fast_kernel<{D}>",
+            2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>"}.get(v, "?")
+
+
 def gather_roofline(model, cfg, device, tables=4):
     """K1 on its own: the (S+2)*B embedding rows of one step against the 8 TB/s HBM peak, caches cold (512 MB written
     before every measurement, > the 256 MB Infinity Cache).  `frac` is the average duration of `tables` launches issued
@@ -375,9 +383,7 @@ def main():
                    "catalog_arithmetic": args.dtype, "mlp_arithmetic": "f32",
                    "launch": "hipGraph replay (zero-grad+fwd+bwd) + eager all-reduce + Adam" if graphed else "eager"},
         "elbo": {"loss": loss.item(), "recLoss": rec.item(), "KLD": kld.item()},
-        "roofline": {"kernel": ((f"catalog_ce_bf16_pipe_kernel<{D}>" if D == 256 else f"catalog_ce_bf16_fast_kernel<{D}>")
-                                if (args.dtype == "bf16" and D in ops.BF16_DIMS) else
-                                f"catalog_ce_{args.dtype}_kernel<{D}>") + " (events also span its row-bound prologue and "
+        "roofline": {"kernel": kernel_name(R_local, N, D, args.dtype) + " (events also span its row-bound prologue and "
                                "merge kernels, <1% together)", "bound": "mfma",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "traffic": traffic, "ms_per_launch": kern_ms, "algorithmic_flops_per_launch": flops,

@@ -59,8 +59,10 @@ int pcvae_gather_rows(const float* table, int64_t n_rows, int D, const int64_t* 
                       int group, float* out, int64_t out_ld, pcvae_stream_t stream);
 
 /* K2  click-count one-hot condition         models/cvae.py:85-92
- *     out[b * out_ld + c] = (c == sum_s r[b, s]),  c in [0, S]                                  */
-int pcvae_condition(const float* r, int64_t B, int S, float* out, int64_t out_ld, pcvae_stream_t stream);
+ *     out[b * out_ld + c] = (c == sum_{j < ncols} r[b, j]),  c in [0, S].  r is [B, ncols]: ncols is the slate size S in
+ *     training, but the reference's in-loop evaluation passes a 5-column context whatever S is
+ *     (train_generative.py:179) - only the row sum matters.                                       */
+int pcvae_condition(const float* r, int64_t B, int ncols, int S, float* out, int64_t out_ld, pcvae_stream_t stream);
 
 /* strided 2-D copy (the torch.cat of models/pivotcvae.py:167,203,213,236 becomes column windows) */
 int pcvae_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
@@ -148,6 +150,10 @@ int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t
  *     skips the running-max machinery; pass <= 0 when unknown (always take the running-max kernel).
  * ------------------------------------------------------------------------------------------- */
 size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_dx);
+/* which kernel an unmasked training call (dx wanted) of this shape runs - for reports, never needed for correctness:
+ * 0 = exact f32 MFMA kernel, 1 = bf16 kernel with two waves per SIMD, 2 = software-pipelined bf16 kernel (one wave per
+ * SIMD), -1 = unsupported shape.  Mirrors the launch logic, including the PCVAE_PIPE_MIN_TILES override. */
+int pcvae_catalog_ce_variant(int64_t R, int64_t N, int D, int prec);
 int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
                      float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
                      const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, size_t ws_bytes,

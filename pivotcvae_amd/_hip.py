@@ -25,7 +25,7 @@ SIGNATURES = {
     "pcvae_abi_version": [],
     "pcvae_last_error": [],
     "pcvae_gather_rows": [_P, _L, _I, _P, _L, _I, _P, _L, _P],
-    "pcvae_condition": [_P, _L, _I, _P, _L, _P],
+    "pcvae_condition": [_P, _L, _I, _I, _P, _L, _P],
     "pcvae_copy2d": [_P, _L, _P, _L, _L, _I, _P],
     "pcvae_scale_rows": [_P, _L, _P, _L, _L, _I, _P, _F, _P],
     "pcvae_normalize_rows": [_P, _L, _L, _I, _P],
@@ -42,6 +42,7 @@ SIGNATURES = {
     "pcvae_kld_bwd": [_P, _P, _P, _P, _L, _P, _F, _P, _P, _P, _P, _P],
     "pcvae_sum": [_P, _L, _F, _P, _P],
     "pcvae_catalog_ws_bytes": [_L, _L, _I, _I],
+    "pcvae_catalog_ce_variant": [_L, _L, _I, _I],
     "pcvae_catalog_ce": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _F, _U64, _U64, _P, _P, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_argmax": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_sample": [_P, _L, _P, _P, _L, _I, _I, _U64, _U64, _P, _P, _SZ, _P],

@@ -20,6 +20,13 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
     return need + 256;
 }
 
+extern "C" int pcvae_catalog_ce_variant(int64_t R, int64_t N, int D, int prec) {
+    if (R <= 0 || N <= 0 || !supported_d(D)) return -1;
+    if (prec == PCVAE_PREC_F32) return 0;
+    if (prec != PCVAE_PREC_BF16 || (D != 64 && D != 128 && D != 256)) return -1;
+    return catalog_bf16_pipelined(D, catalog_plan(R, N, D, PCVAE_PREC_BF16).tiles_per_split) ? 2 : 1;
+}
+
 extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
                                 int prec, float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed,
                                 uint64_t row_offset, const uint8_t* keep_mask, float* nll, float* lse, float* dx,

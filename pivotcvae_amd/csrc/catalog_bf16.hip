@@ -32,6 +32,7 @@
 // the fp32 reference the per-logit error is ~2^-9 relative per product and zero-mean, so the ELBO terms of
 // a batch agree to ~1e-6 while individual gradients agree to ~1e-3 (tests/test_hip_bf16.py).
 #include "catalog_plan.h"
+#include <cstdlib>
 
 using namespace pcvae;
 
@@ -384,31 +385,12 @@ struct FastGeo {
     static constexpr int RPP = 1024 / RB;   // table rows per 1 KiB LDS-DMA piece
     static constexpr int CPR = D / 8;       // 16-byte chunks per row
     static constexpr int KMASK = D == 64 ? 1 : 3;
-    // D = 256: 32 rows of a wave are 128 accumulator + 64 fragment registers, more than the 256 a wave owns when two share
-    // a SIMD (181 spilled registers, 765 TFLOP/s) -> 4 waves per workgroup, one per SIMD with 512 registers each
-    static constexpr int NW = D == 256 ? 4 : 8;       // waves per workgroup
+    // (D = 256 does not fit this kernel: 32 rows of a wave are 128 accumulator + 64 fragment registers, more than the 256 a
+    // wave owns when two share a SIMD - 181 spilled registers, 765 TFLOP/s; it runs the pipelined kernel below)
+    static constexpr int NW = 8;                      // waves per workgroup
     static constexpr int ROWS = NW * 32;              // rows of rx per workgroup
     static constexpr int PPW = 16 / NW;               // 1 KiB LDS-DMA pieces per wave and ring chunk
-    // experiment switch: pin U in AGPRs through inline-asm MFMAs (6 % faster at D = 256 but produced NaNs - an unmanaged
-    // hazard around the asm MFMAs; the compiler-managed build is the product)
-#ifdef PCVAE_AGPR_ACC
-    static constexpr bool ACC_AGPR = NW == 4;
-#else
-    static constexpr bool ACC_AGPR = false;
-#endif
 };
-
-// U += A . B with the accumulator pinned in an AGPR quad (1 wave per SIMD: the compiler would otherwise move logits
-// accumulators there and pay a v_accvgpr_read per exponential)
-__device__ __forceinline__ void mfma_agpr(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    // wait states on both sides: hipcc does not know this is an MFMA and may copy an operand / the result right next to it
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
-}
-template <bool AG>
-__device__ __forceinline__ void mfma_u(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    if constexpr (AG) mfma_agpr(acc, a, b);
-    else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-}
 
 // swizzle of the fast kernels' LDS image: chunk c of row `row` lives at chunk position fswz(row, c) (an involution)
 template <int D>
@@ -454,7 +436,7 @@ __device__ __forceinline__ void tr_issue(const unsigned lbase, const int t0, s16
 }
 
 // gradient chain, d tile DT: request d tile DT + 2, wait for the pieces of DT, two MFMAs
-template <int D, int OFF, int DT, bool AG = FastGeo<D>::ACC_AGPR>
+template <int D, int OFF, int DT>
 __device__ __forceinline__ void grad_chain(const unsigned lbase, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
                                            s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb)[2],
                                            f32x4 (&U)[FastGeo<D>::NDT][2]) {
@@ -471,9 +453,9 @@ __device__ __forceinline__ void grad_chain(const unsigned lbase, const int t0, s
         __builtin_amdgcn_sched_barrier(0);
         const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
-        mfma_u<AG>(U[DT][0], a, pb[0]);
-        mfma_u<AG>(U[DT][1], a, pb[1]);
-        grad_chain<D, OFF, DT + 1, AG>(lbase, t0, tl, th, pb, U);
+        U[DT][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[0], U[DT][0], 0, 0, 0);
+        U[DT][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[1], U[DT][1], 0, 0, 0);
+        grad_chain<D, OFF, DT + 1>(lbase, t0, tl, th, pb, U);
     }
 }
 
@@ -506,7 +488,7 @@ __device__ __forceinline__ void fast_logits(const char* smem, const int off, con
     }
 }
 
-template <int D, bool CHECK_N, int OFF, bool AG = FastGeo<D>::ACC_AGPR>
+template <int D, bool CHECK_N, int OFF>
 __device__ __forceinline__ void fast_subtile(const char* smem, const int off, const int64_t n0, const int64_t N,
                                              const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&U)[FastGeo<D>::NDT][2],
                                              f32x4 (&lsum)[2], const FastLane& L) {
@@ -529,15 +511,13 @@ __device__ __forceinline__ void fast_subtile(const char* smem, const int off, co
                 pb[ct][4 * rt + i] = (__bf16)e0;
                 pb[ct][4 * rt + i + 1] = (__bf16)e1;
             }
-    // (inline-asm MFMAs are opaque to hipcc's hazard recogniser: a VALU result needs 2 wait states before an MFMA reads it)
-    if constexpr (AG) asm volatile("s_nop 1" ::: "memory");
-    mfma_u<AG>(lsum[0], L.ones, pb[0]);
-    mfma_u<AG>(lsum[1], L.ones, pb[1]);
+    lsum[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(L.ones, pb[0], lsum[0], 0, 0, 0);
+    lsum[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(L.ones, pb[1], lsum[1], 0, 0, 0);
     // ---- gradient chain: E^T pieces by asm transposed reads, requested two d tiles ahead
     s16x4 tl[G::NDT], th[G::NDT];
     tr_issue<D, OFF, 0>(lbase, L.t0, tl[0], th[0]);
     tr_issue<D, OFF, 1>(lbase, L.t0, tl[1], th[1]);
-    grad_chain<D, OFF, 0, AG>(lbase, L.t0, tl, th, pb, U);
+    grad_chain<D, OFF, 0>(lbase, L.t0, tl, th, pb, U);
 }
 
 // all subtiles of the 16 KB ring chunk that starts at byte OFFB (+ runtime `off`)
@@ -663,12 +643,6 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
         for (int i = 0; i < 4; ++i) lsum[ct][i] = 0.f;
-    if constexpr (G::ACC_AGPR) {  // materialise the zeros HERE, far from the first asm MFMA that reads them
-#pragma unroll
-        for (int dt = 0; dt < G::NDT; ++dt) { asm volatile("" : "+a"(U[dt][0])); asm volatile("" : "+a"(U[dt][1])); }
-        asm volatile("" : "+a"(lsum[0]));
-        asm volatile("" : "+a"(lsum[1]));
-    }
     const FastLane L = fast_lane<D>(lane);
 
     int cc = 0;
@@ -706,7 +680,6 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
             fast_subtile<D, true, 0>(smem, st * G::ST, (int64_t)(t + st) * 32, p.N, xb, U, lsum, L);
     }
 
-    if constexpr (G::ACC_AGPR) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // last asm MFMA -> v_accvgpr_read
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const float l = lsum[ct][0];
@@ -796,26 +769,6 @@ __device__ __forceinline__ void pipe_a_issue(const unsigned lbase, const int a0,
     a = lds_read_b128<LO + rt * G::RT + (s >> 2) * 256>(lbase + (unsigned)HI + (unsigned)(a0 ^ ((s & G::KMASK) << 4)));
 }
 
-// L(t): step I = (k-step s, row tile rt); A fragments I = 0 .. PIPE_AD-1 are already in flight
-template <int D, int OFF, int I, bool COLD>
-__device__ __forceinline__ void pipe_logits(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS],
-                                            const bf16x8 (&xb)[2][FastGeo<D>::KS], f32x4 (&acc)[2][2]) {
-    constexpr int NI = 2 * FastGeo<D>::KS;
-    if constexpr (I < NI) {
-        if constexpr (I + PIPE_AD < NI) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
-        lgkm_wait<(I + PIPE_AD < NI ? PIPE_AD : NI - 1 - I)>();   // fragments younger than I still in flight
-        constexpr int s = I >> 1, rt = I & 1;
-        if constexpr (s == 0) {
-            mfma_v0<COLD>(acc[rt][0], af[I], xb[0][s]);
-            mfma_v0<COLD>(acc[rt][1], af[I], xb[1][s]);
-        } else {
-            mfma_v<COLD>(acc[rt][0], af[I], xb[0][s]);
-            mfma_v<COLD>(acc[rt][1], af[I], xb[1][s]);
-        }
-        pipe_logits<D, OFF, I + 1, COLD>(lbase, a0, af, xb, acc);
-    }
-}
-
 // issue the first K A fragments of a logits chain
 template <int D, int OFF, int K>
 __device__ __forceinline__ void pipe_a_prologue(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS]) {
@@ -833,170 +786,292 @@ __device__ __forceinline__ void pipe_tr_prologue(const unsigned lbase, const int
     }
 }
 
-// numerators, pinned in place by inline asm (plain builtins have no ordering against the asm MFMAs and end up bunched
-// behind the seam): pair k = (row tile rt, column tile ct, half h) is two exponentials at one point of the chain and one
-// packed conversion a step later (a transcendental result needs an independent instruction before a VALU consumer)
-struct PipeNum {
-    float e[8][2];      // exponentials of pair k
-    unsigned w[2][4];   // packed bf16 pairs: w[ct][2 rt + h]
+// =============================================================================================
+// The pipelined kernel generalised: CT column tiles (16 rows each) per wave and SUB subtiles per ring chunk.
+//   CT = 4 (64 rows per wave, D = 128 / 64): one A fragment / transposed pair feeds FOUR MFMAs - half the LDS reads, waits
+//   and issue slots per MFMA of the 32-row form.  Then the exponentials no longer fit under the gradient chain alone
+//   (48 VALU ops against 36 MFMAs at D = 128), so the logits accumulators are double-buffered and the numerators X(t) of
+//   slot t are spread over BOTH the gradient chain G(t-1) of their own slot and the logits chain L(t+1) of the next one:
+//   VALU op v of a slot sits behind MFMA position v * MPOS / VOPS of that stretch (a compile-time schedule).
+//     slot t:   L(t)   || second part of X(t-1)        (acc[t&1] written, acc[(t-1)&1] read)
+//               G(t-1) || first part of X(t)            with the seam / next A fragments in the middle
+// =============================================================================================
+template <int D, int CT>
+struct PipeGeo {
+    using G = FastGeo<D>;
+    static constexpr int NI = 2 * G::KS;            // steps of the logits chain (k-step, row tile)
+    static constexpr int ML = NI * CT;              // MFMAs of L
+    static constexpr int MG = CT + G::NDT * CT;     // MFMAs of G (row sums first)
+    static constexpr int P = 4 * CT;                // numerator pairs per slot: (row tile, column tile, half)
+    static constexpr int VOPS = 3 * P;              // 2 exponentials + 1 packed conversion per pair
+    static constexpr int MPOS = MG + ML - 2;        // MFMA positions that may carry VALU ops (the last two of L stay free:
+                                                    // the packed numerators are MFMA operands right after L)
+    static constexpr int ROWS = 4 * 16 * CT;        // rows per workgroup (4 waves)
+    static constexpr int TR = PIPE_NB * G::SUB;     // slots per steady-state trip
+    static constexpr int first_op(int m) { return (m * VOPS + MPOS - 1) / MPOS; }
 };
-template <int K>
-__device__ __forceinline__ void pipe_exp(const f32x4 (&acc)[2][2], PipeNum& nm) {
-    constexpr int rt = K >> 2, ct = (K >> 1) & 1, h = K & 1;
-#ifdef PIPE_EXPERIMENT_NO_EXP   // timing experiment only (wrong results): what do the exponentials cost?
-    asm volatile("v_mov_b32 %0, %1" : "=v"(nm.e[K][0]) : "v"(acc[rt][ct][2 * h]));
-    nm.e[K][1] = nm.e[K][0];
-    return;
-#endif
-    asm volatile("v_exp_f32 %0, %1" : "=v"(nm.e[K][0]) : "v"(acc[rt][ct][2 * h]));
-    asm volatile("v_exp_f32 %0, %1" : "=v"(nm.e[K][1]) : "v"(acc[rt][ct][2 * h + 1]));
+
+template <int CT>
+struct PipeRegs {                 // per parity: logits accumulators and packed numerators
+    f32x4 acc[2][CT];             // [row tile][column tile]
+    unsigned w[CT][4];            // w[ct][2 rt + h]: bf16 pair (half h of row tile rt, column tile ct)
+};
+
+// VALU op V of a slot's numerator stream: v = 0, 1: exponentials of pair 0; then for pair j >= 1: exp, exp, conversion of
+// pair j - 1 (a transcendental result needs an independent instruction before its VALU consumer); last: conversion P-1
+template <int CT, int V>
+__device__ __forceinline__ void pipe2_op(const PipeRegs<CT>& src, PipeRegs<CT>& dst, float (&e)[4 * CT][2]) {
+    constexpr int P = 4 * CT, VOPS = 3 * P;
+    if constexpr (V < 2 || (V < VOPS - 1 && (V + 1) % 3 != 2)) {            // an exponential
+        constexpr int k = V < 2 ? 0 : (V + 1) / 3, which = V < 2 ? V : (V + 1) % 3;
+        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+        asm volatile("v_exp_f32 %0, %1" : "=v"(e[k][which]) : "v"(src.acc[rt][ct][2 * h + which]));
+    } else {                                                                // a packed conversion
+        constexpr int k = V == VOPS - 1 ? P - 1 : (V + 1) / 3 - 1;
+        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(dst.w[ct][2 * rt + h]) : "v"(e[k][0]), "v"(e[k][1]));
+    }
 }
-template <int K>
-__device__ __forceinline__ void pipe_cvt(PipeNum& nm) {
-    constexpr int rt = K >> 2, ct = (K >> 1) & 1, h = K & 1;
-    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(nm.w[ct][2 * rt + h]) : "v"(nm.e[K][0]), "v"(nm.e[K][1]));
+// all ops scheduled behind MFMA position M
+template <int D, int CT, int M, int V = PipeGeo<D, CT>::first_op(M)>
+__device__ __forceinline__ void pipe2_ops(const PipeRegs<CT>& src, PipeRegs<CT>& dst, float (&e)[4 * CT][2]) {
+    using PG = PipeGeo<D, CT>;
+    if constexpr (M < PG::MPOS && V < PG::first_op(M + 1) && V < PG::VOPS) {
+        pipe2_op<CT, V>(src, dst, e);
+        pipe2_ops<D, CT, M, V + 1>(src, dst, e);
+    }
 }
-__device__ __forceinline__ void pipe_pack(const PipeNum& nm, bf16x8 (&pb)[2]) {
+template <int CT>
+__device__ __forceinline__ void pipe2_pack(const PipeRegs<CT>& r, bf16x8 (&pb)[CT]) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const u32x4 v = {nm.w[ct][0], nm.w[ct][1], nm.w[ct][2], nm.w[ct][3]};
+    for (int ct = 0; ct < CT; ++ct) {
+        const u32x4 v = {r.w[ct][0], r.w[ct][1], r.w[ct][2], r.w[ct][3]};
         pb[ct] = __builtin_bit_cast(bf16x8, v);
     }
 }
 
-struct PipeSeam {           // what the seam in the middle of slot t does (all wave-uniform)
+struct Pipe2Seam {          // all wave-uniform
     const uint16_t* E;
+    bool do_seam;           // this slot ends a ring chunk: wait for the next chunk + barrier (+ request one more)
     int64_t n_stage;        // first item of the chunk to request, < 0: nothing to request
-    char* stage_buf;        // its ring buffer
-    unsigned next_lbase;    // LDS address (minus the immediate) of the NEXT slot's chunk, for its first two A fragments
+    char* stage_buf;
+    unsigned next_lbase;    // LDS address (minus the immediate) of the NEXT slot's subtile
 };
 
-// G(t-1) || X(t) with seam(t+1) after d tile SEAM_AT
-template <int D, int OFFG, int OFFL_NEXT, int DT, bool HAS_G, int VM, bool COLD>
-__device__ __forceinline__ void pipe_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
-                                          s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb_prev)[2], bf16x8 (&pb_next)[2],
-                                          f32x4 (&acc)[2][2], f32x4 (&U)[FastGeo<D>::NDT][2], const PipeSeam& sm,
-                                          const int wave_u, const int (&lane_off)[4], const int a0,
-                                          bf16x8 (&af)[2 * FastGeo<D>::KS], PipeNum& nm) {
+// phase B: logits chain of slot t (into `cur`) with the second part of the previous slot's numerators (prev -> prev.w)
+template <int D, int CT, int OFF, int I, bool HAS_XPREV, bool COLD>
+__device__ __forceinline__ void pipe2_logits(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS],
+                                             const bf16x8 (&xb)[CT][FastGeo<D>::KS], PipeRegs<CT>& cur, PipeRegs<CT>& prev,
+                                             float (&e)[4 * CT][2]) {
+    using PG = PipeGeo<D, CT>;
+    if constexpr (I < PG::NI) {
+        if constexpr (I + PIPE_AD < PG::NI) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
+        lgkm_wait<(I + PIPE_AD < PG::NI ? PIPE_AD : PG::NI - 1 - I)>();
+        constexpr int s = I >> 1, rt = I & 1;
+#define PCVAE_L_MFMA(CTI)                                                                                  \
+        if constexpr (CTI < CT) {                                                                          \
+            if constexpr (s == 0) mfma_v0<COLD>(cur.acc[rt][CTI], af[I], xb[CTI][s]);                      \
+            else mfma_v<COLD>(cur.acc[rt][CTI], af[I], xb[CTI][s]);                                        \
+            if constexpr (HAS_XPREV) pipe2_ops<D, CT, PG::MG + I * CT + CTI>(prev, prev, e);               \
+        }
+        PCVAE_L_MFMA(0) PCVAE_L_MFMA(1) PCVAE_L_MFMA(2) PCVAE_L_MFMA(3)
+#undef PCVAE_L_MFMA
+        pipe2_logits<D, CT, OFF, I + 1, HAS_XPREV, COLD>(lbase, a0, af, xb, cur, prev, e);
+    }
+}
+
+// phase A: gradient chain of slot t-1 (numerators pb_prev) with the first part of slot t's numerators (cur.acc -> cur.w)
+template <int D, int CT, int OFFG, int OFFL_NEXT, int DT, bool SEAM, bool HAS_G, int VM, bool COLD>
+__device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
+                                           s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb_prev)[CT], PipeRegs<CT>& cur,
+                                           float (&e)[4 * CT][2], f32x4 (&U)[FastGeo<D>::NDT][CT], const Pipe2Seam& sm,
+                                           const int wave_u, const int (&lane_off)[4], const int a0,
+                                           bf16x8 (&af)[2 * FastGeo<D>::KS]) {
     using G = FastGeo<D>;
-    constexpr int NDT = G::NDT, SEAM_AT = NDT / 2;       // seam after the MFMAs of d tile SEAM_AT - 1
-    constexpr int UNIT_EVERY = NDT / 8;                  // 8 numerator pairs spread over the NDT d tiles
+    constexpr int NDT = G::NDT, SEAM_AT = NDT / 2;
     if constexpr (DT < NDT) {
         if constexpr (DT == SEAM_AT) {
-            if constexpr (COLD) pipe_fence();
-#ifdef PIPE_EXPERIMENT_NO_BARRIER   // timing experiment only (racy): what does the seam barrier cost?
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
-#else
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
-#endif
-            if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
-            if constexpr (COLD) pipe_fence();
-            // first two A fragments of the next slot's logits chain (the last slot reads its own chunk again: the counted
-            // waits below assume these two reads are in flight)
-            pipe_a_prologue<D, OFFL_NEXT, PIPE_AD>(sm.next_lbase, a0, af);
+            if constexpr (SEAM) {
+                if constexpr (COLD) {
+                    pipe_fence();
+                    if (sm.do_seam) {
+                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                        if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                    }
+                    pipe_fence();
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+                    if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                }
+            }
+            pipe_a_prologue<D, OFFL_NEXT, PIPE_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
         }
         if constexpr (HAS_G) {
-            // LDS reads younger than the pieces of d tile DT and still in flight: the d tiles requested after it (two reads
-            // each) and, for the PIPE_TD d tiles whose pieces were requested before the seam, the A fragments issued there
             constexpr int extra = (DT >= SEAM_AT && DT < SEAM_AT + PIPE_TD) ? PIPE_AD : 0;
             if constexpr (DT + PIPE_TD < NDT) tr_issue<D, OFFG, DT + PIPE_TD>(lbase_g, t0, tl[DT + PIPE_TD], th[DT + PIPE_TD]);
             lgkm_wait<2 * ((DT + PIPE_TD < NDT ? DT + PIPE_TD : NDT - 1) - DT) + extra>();
-            const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
-            const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
-            mfma_a<COLD>(U[DT][0], a, pb_prev[0]);
-            mfma_a<COLD>(U[DT][1], a, pb_prev[1]);
         }
-        if constexpr (DT % UNIT_EVERY == 0) {             // pair K: exponentials now, conversion of pair K - 1
-            constexpr int K = DT / UNIT_EVERY;
-            pipe_exp<K>(acc, nm);
-            if constexpr (K > 0) pipe_cvt<K - 1>(nm);
+        const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+#define PCVAE_G_MFMA(CTI)                                                                                  \
+        if constexpr (CTI < CT) {                                                                          \
+            if constexpr (HAS_G) mfma_a<COLD>(U[DT][CTI], a, pb_prev[CTI]);                                \
+            pipe2_ops<D, CT, CT + DT * CT + CTI>(cur, cur, e);                                             \
         }
-        if constexpr (DT == NDT - 1) {
-            pipe_cvt<7>(nm);
-            pipe_pack(nm, pb_next);
-        }
-        pipe_grad<D, OFFG, OFFL_NEXT, DT + 1, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pb_prev, pb_next, acc, U, sm, wave_u,
-                                                               lane_off, a0, af, nm);
+        PCVAE_G_MFMA(0) PCVAE_G_MFMA(1) PCVAE_G_MFMA(2) PCVAE_G_MFMA(3)
+#undef PCVAE_G_MFMA
+        pipe2_grad<D, CT, OFFG, OFFL_NEXT, DT + 1, SEAM, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pb_prev, cur, e, U, sm, wave_u,
+                                                                           lane_off, a0, af);
     } else if constexpr (COLD) {
         pipe_fence();
     }
 }
 
-// one slot.  lbase_l / lbase_g: LDS addresses (smem base + runtime ring offset) of subtile t / t-1
-template <int D, int OFFL, int OFFG, int OFFL_NEXT, bool HAS_G, int VM, bool COLD>
-__device__ __forceinline__ void pipe_slot(const unsigned lbase_l, const unsigned lbase_g, const FastLane& L,
-                                          const bf16x8 (&xb)[2][FastGeo<D>::KS], bf16x8 (&af)[2 * FastGeo<D>::KS],
-                                          f32x4 (&acc)[2][2], const bf16x8 (&pb_prev)[2], bf16x8 (&pb_next)[2],
-                                          f32x4 (&U)[FastGeo<D>::NDT][2], f32x4 (&lsum)[2], const PipeSeam& sm,
-                                          const int wave_u, const int (&lane_off)[4]) {
+template <int D, int CT, int OFFL, int OFFG, int OFFL_NEXT, bool SEAM, bool HAS_G, int VM, bool COLD>
+__device__ __forceinline__ void pipe2_slot(const unsigned lbase_l, const unsigned lbase_g, const FastLane& L,
+                                           const bf16x8 (&xb)[CT][FastGeo<D>::KS], bf16x8 (&af)[2 * FastGeo<D>::KS],
+                                           PipeRegs<CT>& cur, PipeRegs<CT>& prev, f32x4 (&U)[FastGeo<D>::NDT][CT],
+                                           f32x4 (&lsum)[CT], const Pipe2Seam& sm, const int wave_u,
+                                           const int (&lane_off)[4], float (&e)[4 * CT][2]) {
     using G = FastGeo<D>;
     if constexpr (COLD) pipe_fence();
-    pipe_logits<D, OFFL, 0, COLD>(lbase_l, L.a0, af, xb, acc);
+    pipe2_logits<D, CT, OFFL, 0, HAS_G, COLD>(lbase_l, L.a0, af, xb, cur, prev, e);
+    bf16x8 pb_prev[CT];
+    pipe2_pack<CT>(prev, pb_prev);
     s16x4 tl[G::NDT], th[G::NDT];
     if constexpr (HAS_G) {
         pipe_tr_prologue<D, OFFG, PIPE_TD>(lbase_g, L.t0, tl, th);
-        if constexpr (COLD) {
-            mfma_a<true>(lsum[0], L.ones, pb_prev[0]);
-            mfma_a<true>(lsum[1], L.ones, pb_prev[1]);
-        } else {
-            mfma_agpr_guarded(lsum[0], L.ones, pb_prev[0]);
-            mfma_agpr_guarded(lsum[1], L.ones, pb_prev[1]);
+#define PCVAE_ONES(CTI)                                                                                    \
+        if constexpr (CTI < CT) {                                                                          \
+            if constexpr (COLD) mfma_a<true>(lsum[CTI], L.ones, pb_prev[CTI]);                             \
+            else mfma_agpr_guarded(lsum[CTI], L.ones, pb_prev[CTI]);                                       \
+            pipe2_ops<D, CT, CTI>(cur, cur, e);                                                            \
         }
+        PCVAE_ONES(0) PCVAE_ONES(1) PCVAE_ONES(2) PCVAE_ONES(3)
+#undef PCVAE_ONES
     } else {
-        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // no MFMAs between the logits chain and the first exponential
+        pipe_fence();  // no MFMAs between the logits chain and the first exponential
+        pipe2_ops<D, CT, 0>(cur, cur, e);
+        if constexpr (CT > 1) pipe2_ops<D, CT, 1>(cur, cur, e);
+        if constexpr (CT > 2) { pipe2_ops<D, CT, 2>(cur, cur, e); pipe2_ops<D, CT, 3>(cur, cur, e); }
     }
-    PipeNum nm;
-    pipe_grad<D, OFFG, OFFL_NEXT, 0, HAS_G, VM, COLD>(lbase_g, L.t0, tl, th, pb_prev, pb_next, acc, U, sm, wave_u, lane_off,
-                                                      L.a0, af, nm);
+    pipe2_grad<D, CT, OFFG, OFFL_NEXT, 0, SEAM, HAS_G, VM, COLD>(lbase_g, L.t0, tl, th, pb_prev, cur, e, U, sm, wave_u, lane_off,
+                                                                 L.a0, af);
 }
 
-// the gradient chain of the last subtile on its own (pipeline drain)
-template <int D>
-__device__ __forceinline__ void pipe_drain(const unsigned lbase_g, const FastLane& L, const bf16x8 (&pb_prev)[2],
-                                           f32x4 (&U)[FastGeo<D>::NDT][2], f32x4 (&lsum)[2]) {
+// pipeline drain after the last slot: the rest of its numerators, then its gradient chain
+template <int D, int CT, int M = PipeGeo<D, CT>::MG>
+__device__ __forceinline__ void pipe2_drain_ops(PipeRegs<CT>& last, float (&e)[4 * CT][2]) {
+    if constexpr (M < PipeGeo<D, CT>::MPOS) {
+        pipe2_ops<D, CT, M>(last, last, e);
+        pipe2_drain_ops<D, CT, M + 1>(last, e);
+    }
+}
+template <int D, int CT, int DT = 0>
+__device__ __forceinline__ void pipe2_cold_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
+                                                s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb)[CT],
+                                                f32x4 (&U)[FastGeo<D>::NDT][CT]) {
+    constexpr int NDT = FastGeo<D>::NDT;
+    if constexpr (DT < NDT) {
+        if constexpr (DT + 2 < NDT) tr_issue<D, 0, DT + 2>(lbase_g, t0, tl[DT + 2], th[DT + 2]);
+        lgkm_wait<2 * ((DT + 2 < NDT ? DT + 2 : NDT - 1) - DT)>();
+        const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) mfma_a<true>(U[DT][ct], a, pb[ct]);
+        pipe2_cold_grad<D, CT, DT + 1>(lbase_g, t0, tl, th, pb, U);
+    }
+}
+template <int D, int CT>
+__device__ __forceinline__ void pipe2_cold_gradient(const unsigned lbase_g, const FastLane& L, const bf16x8 (&pb)[CT],
+                                                    f32x4 (&U)[FastGeo<D>::NDT][CT], f32x4 (&lsum)[CT]) {
     using G = FastGeo<D>;
     s16x4 tl[G::NDT], th[G::NDT];
     pipe_fence();
     tr_issue<D, 0, 0>(lbase_g, L.t0, tl[0], th[0]);
     tr_issue<D, 0, 1>(lbase_g, L.t0, tl[1], th[1]);
-    mfma_a<true>(lsum[0], L.ones, pb_prev[0]);
-    mfma_a<true>(lsum[1], L.ones, pb_prev[1]);
-    grad_chain<D, 0, 0, true>(lbase_g, L.t0, tl, th, pb_prev, U);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) mfma_a<true>(lsum[ct], L.ones, pb[ct]);
+    pipe2_cold_grad<D, CT>(lbase_g, L.t0, tl, th, pb, U);
     pipe_fence();
 }
 
-template <int D>
+// one subtile on its own (ragged tail): logits, bound check, numerators, gradient - nothing overlapped, every MFMA fenced
+template <int D, int CT, int I = 0>
+__device__ __forceinline__ void pipe2_cold_logits(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS],
+                                                  const bf16x8 (&xb)[CT][FastGeo<D>::KS], PipeRegs<CT>& r) {
+    constexpr int NI = 2 * FastGeo<D>::KS;
+    if constexpr (I < NI) {
+        pipe_a_issue<D, 0, I>(lbase, a0, af[I]);
+        lgkm_wait<0>();
+        constexpr int s = I >> 1, rt = I & 1;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if constexpr (s == 0) mfma_v0<true>(r.acc[rt][ct], af[I], xb[ct][s]);
+            else mfma_v<true>(r.acc[rt][ct], af[I], xb[ct][s]);
+        }
+        pipe2_cold_logits<D, CT, I + 1>(lbase, a0, af, xb, r);
+    }
+}
+template <int D, int CT>
+__device__ __forceinline__ void pipe2_solo(const unsigned lbase, const int64_t n0, const int64_t N, const FastLane& L,
+                                           const bf16x8 (&xb)[CT][FastGeo<D>::KS], f32x4 (&U)[FastGeo<D>::NDT][CT],
+                                           f32x4 (&lsum)[CT]) {
+    PipeRegs<CT> r;
+    bf16x8 af[2 * FastGeo<D>::KS];
+    pipe_fence();
+    pipe2_cold_logits<D, CT>(lbase, L.a0, af, xb, r);
+    pipe_fence();
+    bf16x8 pb[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const bool ok0 = n0 + 16 * rt + 4 * L.g + i < N, ok1 = n0 + 16 * rt + 4 * L.g + i + 1 < N;
+                const float e0 = ok0 ? __builtin_amdgcn_exp2f(r.acc[rt][ct][i]) : 0.f;
+                const float e1 = ok1 ? __builtin_amdgcn_exp2f(r.acc[rt][ct][i + 1]) : 0.f;
+                pb[ct][4 * rt + i] = (__bf16)e0;
+                pb[ct][4 * rt + i + 1] = (__bf16)e1;
+            }
+    pipe2_cold_gradient<D, CT>(lbase, L, pb, U, lsum);
+}
+
+template <int D, int CT>
 __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB p) {
     using G = FastGeo<D>;
-    static_assert(G::SUB == 1, "one subtile per 16 KB ring chunk (D = 256)");
-    constexpr int CB = 16384, NW = 4, ROWS = NW * 32;
+    using PG = PipeGeo<D, CT>;
+    constexpr int CB = 16384, NW = 4, ROWS = PG::ROWS, SUB = G::SUB, TR = PG::TR;
+    static_assert(TR % 2 == 0, "the accumulator parity must repeat every trip");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int nrb = p.nrb * (ROWS_WG / ROWS);
+    const int nrb = (int)((p.R + ROWS - 1) / ROWS);
     const int split = logical / nrb, rb = logical % nrb;
-    if ((int64_t)rb * ROWS >= p.R) return;
-    if (p.safe_flags[rb / (ROWS_WG / ROWS)] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
+    if (p.safe_flags[(int)(((int64_t)rb * ROWS) / ROWS_WG)] != 0) return;  // large |rx|: the lazy-max kernel handles this block
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
     const int64_t nbase = (int64_t)t_beg * 32;
-    int T = (int)min((int64_t)(t_end - t_beg), (p.N - nbase) / 32);   // full 32-item chunks of this range
-    T = max(T, 0);
+    // ring chunks of this range that exist in full; T = pipelined slots (32-item subtiles)
+    int Cn = (int)min((int64_t)((t_end - t_beg) / SUB), (p.N - nbase) / G::BNF);
+    Cn = max(Cn, 0);
+    const int T = Cn * SUB;
 
-    const int64_t rw = (int64_t)rb * ROWS + wave * 32;
+    const int64_t rw = (int64_t)rb * ROWS + wave * 16 * CT;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int lane_off[4];
     fast_lane_off<D, NW>(lane, wave, lane_off);
 #pragma unroll
-    for (int c0 = 0; c0 <= PIPE_PF; ++c0)  // prologue: chunks 0..3 in flight
-        if (c0 < T) fast_stage<D, NW>(p.E, nbase + (int64_t)c0 * 32, smem + c0 * CB, wave_u, lane_off);
+    for (int c0 = 0; c0 <= PIPE_PF; ++c0)
+        if (c0 < Cn) fast_stage<D, NW>(p.E, nbase + (int64_t)c0 * G::BNF, smem + c0 * CB, wave_u, lane_off);
 
-    bf16x8 xb[2][G::KS];
+    bf16x8 xb[CT][G::KS];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
         const int64_t r = rw + 16 * ct + c;
         const int64_t rl = r < p.R ? r : p.R - 1;
 #pragma unroll
@@ -1009,35 +1084,37 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
             xb[ct][s][6] = (__bf16)(v1.z * kLog2e); xb[ct][s][7] = (__bf16)(v1.w * kLog2e);
         }
     }
-    f32x4 U[G::NDT][2];
+    f32x4 U[G::NDT][CT];
+    f32x4 lsum[CT];
 #pragma unroll
     for (int dt = 0; dt < G::NDT; ++dt)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) U[dt][ct][i] = 0.f;
-    f32x4 lsum[2];
+            asm volatile("" : "+a"(U[dt][ct]));
+        }
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
+    for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) lsum[ct][i] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < G::NDT; ++dt) { asm volatile("" : "+a"(U[dt][0])); asm volatile("" : "+a"(U[dt][1])); }
-    asm volatile("" : "+a"(lsum[0]));
-    asm volatile("" : "+a"(lsum[1]));
+        asm volatile("" : "+a"(lsum[ct]));
+    }
     const FastLane L = fast_lane<D>(lane);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
-    f32x4 acc[2][2];
+    PipeRegs<CT> R2[2];
     bf16x8 af[2 * G::KS];
-    bf16x8 pb[2][2];   // numerators of the even / odd slots
+    float e[4 * CT][2];   // exponentials of the numerator stream in progress (it spans two slots)
 
-    // seam of slot t (executed in the middle of slot t): chunk t+1 landed, request chunk t+1+PF, first A fragments of L(t+1)
+    // LDS address of slot t's subtile and the seam a slot carries (runtime forms)
+    auto lds_of = [&](int t) { return lds0 + (unsigned)(((t / SUB) % PIPE_NB) * CB + (t % SUB) * G::ST); };
     auto seam_of = [&](int t) {
-        PipeSeam sm;
+        Pipe2Seam sm;
         sm.E = p.E;
-        const int cs = t + 1 + PIPE_PF;
-        sm.n_stage = cs < T ? nbase + (int64_t)cs * 32 : -1;
+        sm.do_seam = (t % SUB) == SUB - 1;
+        const int cs = t / SUB + 1 + PIPE_PF;
+        sm.n_stage = (sm.do_seam && cs < Cn) ? nbase + (int64_t)cs * G::BNF : -1;
         sm.stage_buf = smem + (cs % PIPE_NB) * CB;
         sm.next_lbase = lds0;
         return sm;
@@ -1045,56 +1122,82 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
 
     int t = 0;
     if (T > 0) {
-        // seam(0): chunk 0 landed (chunks 1..3 may still be in flight), then the first two A fragments of L(0)
-        if (T > PIPE_PF) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        if (Cn > PIPE_PF) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         pipe_a_prologue<D, 0, PIPE_AD>(lds0, L.a0, af);
-        // slot 0: no gradient chain yet
-        PipeSeam sm = seam_of(0);
-        sm.next_lbase = T > 1 ? lds0 + 1 * CB : lds0;
-        if (T > 1 + PIPE_PF) pipe_slot<D, 0, 0, 0, false, 2 * 4, true>(lds0, lds0, L, xb, af, acc, pb[1], pb[0], U, lsum, sm, wave_u, lane_off);
-        else pipe_slot<D, 0, 0, 0, false, 0, true>(lds0, lds0, L, xb, af, acc, pb[1], pb[0], U, lsum, sm, wave_u, lane_off);
+        {   // slot 0: nothing to drain yet
+            Pipe2Seam sm = seam_of(0);
+            sm.next_lbase = lds_of(T > 1 ? 1 : 0);
+            pipe2_slot<D, CT, 0, 0, 0, true, false, 0, true>(lds0, lds0, L, xb, af, R2[0], R2[1], U, lsum, sm, wave_u, lane_off, e);
+        }
         t = 1;
-        // steady state: 6 slots per trip, every LDS offset an immediate.  Slot t reads ring buffer t % 6 (L) and (t-1) % 6 (G).
-        for (; t + PIPE_NB - 1 + 1 + PIPE_PF < T; t += PIPE_NB) {
-#define PCVAE_PIPE_SLOT(UU)                                                                                               \
-            {                                                                                                             \
-                constexpr int BL = (1 + UU) % PIPE_NB, BG = UU % PIPE_NB, BN = (2 + UU) % PIPE_NB;                        \
-                PipeSeam s2 = seam_of(t + UU);                                                                            \
-                s2.next_lbase = lds0;                                                                                     \
-                pipe_slot<D, BL * CB, BG * CB, BN * CB, true, 2 * 4, false>(lds0, lds0, L, xb, af, acc, pb[UU & 1],       \
-                                                                            pb[(UU & 1) ^ 1], U, lsum, s2, wave_u, lane_off); \
+        // steady state: TR slots per trip, every LDS offset an immediate
+        for (; (t + TR - 1) / SUB + 3 <= Cn - 1; t += TR) {
+#define PCVAE_P2(UU)                                                                                                      \
+            if constexpr (UU < TR) {                                                                                      \
+                constexpr int TL = 1 + UU, TG = UU, TN = 2 + UU;                                                          \
+                constexpr int OL = ((TL / SUB) % PIPE_NB) * CB + (TL % SUB) * G::ST;                                      \
+                constexpr int OG = ((TG / SUB) % PIPE_NB) * CB + (TG % SUB) * G::ST;                                      \
+                constexpr int ON = ((TN / SUB) % PIPE_NB) * CB + (TN % SUB) * G::ST;                                      \
+                constexpr bool SEAM = (TL % SUB) == SUB - 1;                                                              \
+                const Pipe2Seam s2 = seam_of(t + UU);                                                                     \
+                pipe2_slot<D, CT, OL, OG, ON, SEAM, true, 2 * 4, false>(lds0, lds0, L, xb, af, R2[TL & 1], R2[TG & 1], U, \
+                                                                        lsum, s2, wave_u, lane_off, e);                   \
             }
-            PCVAE_PIPE_SLOT(0) PCVAE_PIPE_SLOT(1) PCVAE_PIPE_SLOT(2) PCVAE_PIPE_SLOT(3) PCVAE_PIPE_SLOT(4) PCVAE_PIPE_SLOT(5)
-#undef PCVAE_PIPE_SLOT
-            pipe_fence();  // latch: loop-carried copies (if hipcc ever makes any) read retired results
+            PCVAE_P2(0) PCVAE_P2(1) PCVAE_P2(2) PCVAE_P2(3) PCVAE_P2(4) PCVAE_P2(5) PCVAE_P2(6) PCVAE_P2(7)
+            PCVAE_P2(8) PCVAE_P2(9) PCVAE_P2(10) PCVAE_P2(11) PCVAE_P2(12) PCVAE_P2(13) PCVAE_P2(14) PCVAE_P2(15)
+            PCVAE_P2(16) PCVAE_P2(17) PCVAE_P2(18) PCVAE_P2(19) PCVAE_P2(20) PCVAE_P2(21) PCVAE_P2(22) PCVAE_P2(23)
+#undef PCVAE_P2
+            pipe_fence();  // latch
         }
-        // the last slots: runtime ring offsets, seams that drain the ring (vmcnt(0))
+        // the slots after the last full trip, at steady-state speed: a short trip (one chunk; two for SUB = 1) whose ring
+        // position is a runtime base register; its seams drain the ring (vmcnt(0): how many chunks are still in flight is
+        // no longer a compile-time number)
+        // (D = 128: hipcc spills registers in this loop - a spill next to an unfenced asm MFMA stores stale data - so those
+        // slots take the fenced path below; tools/isa_loop_check.py guards every unfenced loop)
+        constexpr int TR2 = SUB > 2 ? SUB : 2;
+        constexpr bool REM_FAST = D == 64;
+        for (; REM_FAST && t + TR2 <= T; t += TR2) {
+#define PCVAE_P2R(UU)                                                                                                     \
+            if constexpr (UU < TR2) {                                                                                     \
+                constexpr bool SEAM = ((1 + UU) % SUB) == SUB - 1;                                                        \
+                Pipe2Seam s2 = seam_of(t + UU);                                                                           \
+                s2.next_lbase = lds_of(t + UU + 1 < T ? t + UU + 1 : t + UU);                                             \
+                pipe2_slot<D, CT, 0, 0, 0, SEAM, true, 0, false>(lds_of(t + UU), lds_of(t + UU - 1), L, xb, af,           \
+                                                                 R2[(1 + UU) & 1], R2[UU & 1], U, lsum, s2, wave_u, lane_off, e); \
+            }
+            PCVAE_P2R(0) PCVAE_P2R(1) PCVAE_P2R(2) PCVAE_P2R(3)
+#undef PCVAE_P2R
+            pipe_fence();  // latch
+        }
+        // at most TR2 - 1 slots are left: fenced (cold) slots
         for (; t < T; ++t) {
-            PipeSeam s2 = seam_of(t);
-            s2.next_lbase = lds0 + ((t + 1 < T ? t + 1 : t) % PIPE_NB) * CB;
-            const unsigned ll = lds0 + (t % PIPE_NB) * CB, lg = lds0 + ((t - 1) % PIPE_NB) * CB;
-            if (t & 1) pipe_slot<D, 0, 0, 0, true, 0, true>(ll, lg, L, xb, af, acc, pb[0], pb[1], U, lsum, s2, wave_u, lane_off);
-            else pipe_slot<D, 0, 0, 0, true, 0, true>(ll, lg, L, xb, af, acc, pb[1], pb[0], U, lsum, s2, wave_u, lane_off);
+            Pipe2Seam s2 = seam_of(t);
+            s2.next_lbase = lds_of(t + 1 < T ? t + 1 : t);
+            if (t & 1) pipe2_slot<D, CT, 0, 0, 0, true, true, 0, true>(lds_of(t), lds_of(t - 1), L, xb, af, R2[1], R2[0], U, lsum, s2, wave_u, lane_off, e);
+            else pipe2_slot<D, CT, 0, 0, 0, true, true, 0, true>(lds_of(t), lds_of(t - 1), L, xb, af, R2[0], R2[1], U, lsum, s2, wave_u, lane_off, e);
         }
-        // drain: gradient chain of subtile T-1
-        if ((T - 1) & 1) pipe_drain<D>(lds0 + ((T - 1) % PIPE_NB) * CB, L, pb[1], U, lsum);
-        else pipe_drain<D>(lds0 + ((T - 1) % PIPE_NB) * CB, L, pb[0], U, lsum);
+        {   // drain: the rest of the last slot's numerators, then its gradient chain
+            bf16x8 pb[CT];
+            pipe_fence();
+            if ((T - 1) & 1) { pipe2_drain_ops<D, CT>(R2[1], e); pipe2_pack<CT>(R2[1], pb); }
+            else { pipe2_drain_ops<D, CT>(R2[0], e); pipe2_pack<CT>(R2[0], pb); }
+            asm volatile("s_nop 1" ::: "memory");
+            pipe2_cold_gradient<D, CT>(lds_of(T - 1), L, pb, U, lsum);
+        }
     }
-    // ---- tail: short / ragged chunks, staged synchronously with clamped addresses (plain subtile code, asm accumulators)
+    // ---- tail: short / ragged chunks, staged synchronously with clamped addresses, one subtile at a time
     for (int tt = t_beg + T; tt < t_end; tt += 4) {
         __syncthreads();
         fast_stage_tail<D, NW>(p.E, p.N, (int64_t)tt * 32, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const int nsub = min(4, t_end - tt);
-        for (int st = 0; st < nsub; ++st) {
-            fast_subtile<D, true, 0, true>(smem, st * G::ST, (int64_t)(tt + st) * 32, p.N, xb, U, lsum, L);
-            pipe_fence();
-        }
+        for (int st = 0; st < nsub; ++st) pipe2_solo<D, CT>(lds0 + st * G::ST, (int64_t)(tt + st) * 32, p.N, L, xb, U, lsum);
     }
-    pipe_fence();  // last asm MFMA -> the stores below read the accumulators
+    pipe_fence();
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
+    for (int ct = 0; ct < CT; ++ct) {
         const float l = lsum[ct][0];
         const int64_t r = rw + 16 * ct + c;
         if (r < p.R) {
@@ -1177,27 +1280,32 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
                            fast_ok ? e_max_norm : 0.f, flags);
         p.safe_flags = flags;
         if (fast_ok) {
-            constexpr int lds_fast = 65536;  // ring of four 16 KB chunks (also holds the <= 64 KB synchronous tail image)
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_fast_kernel<D>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast);
-                attr_set = true;
-            }
-            const dim3 fgrid((unsigned)(p.nrb * (ROWS_WG / FastGeo<D>::ROWS) * p.nsplit)), fblock(FastGeo<D>::NW * 64);
-#ifndef PCVAE_NO_PIPE
-            if constexpr (D == 256) {
+            // D = 256 always, D = 128 / 64 on long catalog ranges: the software-pipelined kernel (64 rows per wave for
+            // D <= 128).  Its fill / drain / last slots run fenced at about half speed, so short ranges (the 8-GPU shards,
+            // small catalogs) stay on the two-waves-per-SIMD kernel.  PCVAE_PIPE_MIN_TILES (read per launch) moves the
+            // threshold: the tests force the pipelined kernels onto small shapes with it.
+            constexpr bool ALWAYS_PIPE = D == 256;
+            constexpr int CT = D == 256 ? 2 : 4;
+            if (catalog_bf16_pipelined(D, p.tiles_per_split)) {
                 constexpr int lds_pipe = PIPE_NB * 16384;
-                static bool attr_set2 = false;
-                if (!attr_set2) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_pipe_kernel<D>),
+                static bool attr_set3 = false;
+                if (!attr_set3) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_pipe_kernel<D, CT>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
-                    attr_set2 = true;
+                    attr_set3 = true;
                 }
-                hipLaunchKernelGGL((catalog_ce_bf16_pipe_kernel<D>), fgrid, dim3(256), lds_pipe, st, p);
-            } else
-#endif
-            hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), fgrid, fblock, lds_fast, st, p);
+                const dim3 g2((unsigned)(cdiv(p.R, PipeGeo<D, CT>::ROWS) * p.nsplit));
+                hipLaunchKernelGGL((catalog_ce_bf16_pipe_kernel<D, CT>), g2, dim3(256), lds_pipe, st, p);
+            } else if constexpr (!ALWAYS_PIPE) {
+                constexpr int lds_fast = 65536;  // ring of four 16 KB chunks (also holds the <= 64 KB synchronous tail image)
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_fast_kernel<D>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast);
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), grid, block, lds_fast, st, p);
+            }
         }
         int rc0 = check_launch("catalog_ce_bf16_fast");
         if (rc0 != PCVAE_OK) return rc0;

@@ -2,6 +2,8 @@
 // pcvae_catalog_ws_bytes, so the host sizes the workspace exactly as the kernels index it).
 #pragma once
 #include "common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace pcvae {
 
@@ -43,6 +45,15 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
         }
     }
     return p;
+}
+
+// bf16 training call: software-pipelined kernel (one wave per SIMD) or the two-waves-per-SIMD kernel?  D = 256 always
+// pipelined; D = 128 / 64 on long catalog ranges only (the pipeline's fill / drain / last slots run fenced, at about half
+// speed).  PCVAE_PIPE_MIN_TILES (environment, read per call) overrides the threshold: the tests use it.
+static inline bool catalog_bf16_pipelined(int D, int tiles_per_split) {
+    if (D == 256) return true;
+    const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
+    return tiles_per_split >= (env_min ? atoi(env_min) : 2048);
 }
 
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,

@@ -100,21 +100,22 @@ extern "C" int pcvae_gather_rows(const float* table, int64_t n_rows, int D, cons
 // =============================================================================================
 // K2: condition one-hot
 // =============================================================================================
-__global__ void condition_kernel(const float* __restrict__ r, int64_t B, int S, float* __restrict__ out,
+__global__ void condition_kernel(const float* __restrict__ r, int64_t B, int ncols, int S, float* __restrict__ out,
                                  int64_t out_ld) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float cnt = 0.f;
-    for (int s = 0; s < S; ++s) cnt += r[b * S + s];
+    for (int s = 0; s < ncols; ++s) cnt += r[b * ncols + s];
     const int c = (int)cnt;  // torch: sum(r).to(long) truncates
     for (int j = 0; j <= S; ++j) out[b * out_ld + j] = (j == c) ? 1.f : 0.f;
 }
 
-extern "C" int pcvae_condition(const float* r, int64_t B, int S, float* out, int64_t out_ld, pcvae_stream_t stream) {
-    PCVAE_REQUIRE(r && out && S > 0 && out_ld >= S + 1, "condition: bad arguments");
+extern "C" int pcvae_condition(const float* r, int64_t B, int ncols, int S, float* out, int64_t out_ld,
+                               pcvae_stream_t stream) {
+    PCVAE_REQUIRE(r && out && S > 0 && ncols > 0 && out_ld >= S + 1, "condition: bad arguments");
     if (B == 0) return PCVAE_OK;
-    hipLaunchKernelGGL(condition_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), r, B, S, out,
-                       out_ld);
+    hipLaunchKernelGGL(condition_kernel, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), r, B, ncols, S,
+                       out, out_ld);
     return check_launch("condition");
 }
 

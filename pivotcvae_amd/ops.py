@@ -52,13 +52,16 @@ def gather_rows(table, idx, out=None, group=1):
 
 
 def condition(r, S, out=None):
-    """one-hot of the click count, [B, S+1] (models/cvae.py:85-92)."""
+    """one-hot of the click count, [B, S+1] (models/cvae.py:85-92).  r is [B, any width]: the reference's in-loop
+    evaluation passes a 5-column context whatever the slate size is (train_generative.py:179)."""
     require_device(r, out)
+    if r.dim() != 2:
+        raise RuntimeError(f"condition: r must be [B, columns], got {tuple(r.shape)}")
     r = r.to(F32).contiguous()
-    B = r.shape[0]
+    B, ncols = r.shape
     if out is None:
         out = torch.empty(B, S + 1, dtype=F32, device=r.device)
-    check(lib().pcvae_condition(ptr(r, F32), B, S, ptr(out, F32), _ld(out), stream()), "condition")
+    check(lib().pcvae_condition(ptr(r, F32), B, ncols, S, ptr(out, F32), _ld(out), stream()), "condition")
     return out
 
 

@@ -71,12 +71,18 @@ def emulate(rx, E, tgt, keep=None):
 
 
 SHAPES = [(70, 1000, 64), (300, 4099, 128), (257, 9000, 128), (64, 333, 128), (600, 20000, 64), (300, 4099, 256),
-          (520, 9000, 256), (33, 100, 256), (130, 50000, 64), (257, 70000, 128), (260, 40001, 256)]
+          (520, 9000, 256), (33, 100, 256), (130, 50000, 64), (257, 70000, 128), (260, 40001, 256), (256, 32, 128),
+          (256, 2048 + 96, 128), (100, 300000, 128), (100, 300000, 64)]
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("R,N,D", SHAPES)
-def test_bf16_ce_matches_its_own_arithmetic(ops, R, N, D):
+def test_bf16_ce_matches_its_own_arithmetic(ops, R, N, D, pipelined, monkeypatch):
     from pivotcvae_amd._hip import PREC_BF16
+    # the software-pipelined kernels (64 rows per wave) normally take only long catalog ranges (>= 2048 tiles per
+    # workgroup); PCVAE_PIPE_MIN_TILES (read at every launch) forces them onto these small shapes: fill, drain, fenced last
+    # slots and the ragged tail are then most of the work
+    monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1" if pipelined else "1000000000")
     rx, E = rnd(R, D, seed=1, scale=2.0 * (128.0 / D) ** 0.5), orc.normalize_rows(rnd(N, D, seed=2))
     tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
     tgt[0], tgt[-1] = 0, N - 1
@@ -93,7 +99,11 @@ def test_bf16_ce_matches_its_own_arithmetic(ops, R, N, D):
     assert none is None
     wn2, _, _ = emulate(rx, E, tgt)
     torch.testing.assert_close(nll2.cpu(), wn2, rtol=2e-5, atol=3e-5)
-    torch.testing.assert_close(nll2, nll, rtol=2e-4, atol=3e-4)
+    # (bound: every numerator rounds by at most 2^-9 relative, so |d lse| <= log(1 + 2^-9) = 1.95e-3 - reached only by
+    # tiny catalogs where a handful of items carry the whole sum)
+    torch.testing.assert_close(nll2, nll, rtol=0, atol=2.5e-3)
+    if N >= 4096:
+        torch.testing.assert_close(nll2, nll, rtol=2e-4, atol=3e-4)
 
 
 @pytest.mark.parametrize("R,N,D", [(70, 1000, 64), (300, 4099, 128)])

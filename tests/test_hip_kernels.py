@@ -60,6 +60,20 @@ def test_condition(ops):
     assert torch.equal(ops.condition(r.to(DEV), 5).cpu(), orc.condition(r, 5))
 
 
+def test_condition_context_narrower_than_the_slate(ops):
+    """train_generative.py:179 builds a 5-column context whatever the slate size is; only its row sum is used.  The
+    kernel once read S columns from it (out of bounds for S > 5: a memory fault at config 5 when the context happened to
+    sit at the end of a mapped region).  Each context gets its own allocation-sized tensor here, S = 20."""
+    S = 20
+    for B in (1, 3, 1024):
+        ctx = torch.zeros(B, 5)
+        for i in range(5):
+            ctx[:, i] = 1
+            got = ops.condition(ctx.clone().to(DEV), S).cpu()
+            assert torch.equal(got, orc.condition(ctx, S))
+            assert got[:, i + 1].sum() == B
+
+
 def test_concat_and_backward(ops):
     a, b, c = rnd(9, 4, seed=1), rnd(9, 6, seed=2), rnd(9, 16, seed=3)
     ad = a.to(DEV).requires_grad_(True)

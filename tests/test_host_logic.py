@@ -165,9 +165,10 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
     spec = importlib.util.spec_from_file_location("isa_loop_check", os.path.join(ROOT, "tools", "isa_loop_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    loops = mod.hot_loops()
-    assert loops, "pipelined kernel not found in the generated ISA"
-    for name, loop in loops.items():
-        bad = [l for l in loop if l.startswith(mod.FORBIDDEN)]
-        assert not bad, (name, bad[:5])
-        assert sum(l.startswith("v_mfma") for l in loop) >= 64
+    kernels = mod.hot_loops()
+    assert len(kernels) >= 3, "pipelined kernels not found in the generated ISA"
+    for name, loops in kernels.items():
+        assert loops, f"{name}: no steady-state loop found"
+        for loop in loops:
+            bad = [l for l in loop if l.startswith(mod.FORBIDDEN)]
+            assert not bad, (name, bad[:5])
