@@ -752,8 +752,6 @@ __device__ __forceinline__ void lgkm_wait() {
 // copies (tests/test_host_logic.py checks the generated ISA) and is fenced once per trip, at its latch.
 __device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-constexpr int PIPE_NB = 6;   // ring buffers
-constexpr int PIPE_PF = 3;   // chunks requested ahead
 #ifndef PIPE_TD
 #define PIPE_TD 2            // transposed reads: d tiles requested ahead (2 reads each)
 #endif
@@ -807,7 +805,18 @@ struct PipeGeo {
     static constexpr int MPOS = MG + ML - 2;        // MFMA positions that may carry VALU ops (the last two of L stay free:
                                                     // the packed numerators are MFMA operands right after L)
     static constexpr int ROWS = 4 * 16 * CT;        // rows per workgroup (4 waves)
-    static constexpr int TR = PIPE_NB * G::SUB;     // slots per steady-state trip
+    // ring: a chunk is read by L of its slots and, one slot later, by G.  With one subtile per chunk (D = 256) the chunk
+    // before the current one is still in use: 6 buffers, 3 chunks requested ahead.  With 2 or 4 subtiles per chunk 4
+    // buffers / 2 ahead do - 64 KB, every DS offset inside the 16-bit immediate (one base register per read pattern
+    // instead of two: D = 128 sits at the 256-VGPR limit)
+    static constexpr int NB = G::SUB == 4 ? 4 : 6;  // ring buffers
+    static constexpr int PF = G::SUB == 4 ? 2 : 3;  // chunks requested ahead
+    // requests beyond the last chunk repeat it, so that a constant number of chunks is in flight and the steady-state trips
+    // (counted vmcnt) can run to the end of the range.  Not for D = 128 CT = 4: that instantiation sits at the 256-VGPR
+    // limit and hipcc's allocation of its steady-state loop only stays copy-free with the simpler protocol (trips stop three
+    // chunks early, nothing is requested past the end) - tools/isa_loop_check.py is the judge.
+    static constexpr bool DUMMY = !(D == 128 && CT == 4);
+    static constexpr int TR = NB * G::SUB;          // slots per steady-state trip
     static constexpr int first_op(int m) { return (m * VOPS + MPOS - 1) / MPOS; }
 };
 
@@ -1066,8 +1075,14 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
     int lane_off[4];
     fast_lane_off<D, NW>(lane, wave, lane_off);
 #pragma unroll
-    for (int c0 = 0; c0 <= PIPE_PF; ++c0)
-        if (c0 < Cn) fast_stage<D, NW>(p.E, nbase + (int64_t)c0 * G::BNF, smem + c0 * CB, wave_u, lane_off);
+    // (requests beyond the last chunk repeat it: a constant number of chunks in flight keeps every counted vmcnt valid)
+    for (int c0 = 0; c0 <= PG::PF; ++c0) {
+        if constexpr (PG::DUMMY) {
+            if (Cn > 0) fast_stage<D, NW>(p.E, nbase + (int64_t)min(c0, Cn - 1) * G::BNF, smem + c0 * CB, wave_u, lane_off);
+        } else {
+            if (c0 < Cn) fast_stage<D, NW>(p.E, nbase + (int64_t)c0 * G::BNF, smem + c0 * CB, wave_u, lane_off);
+        }
+    }
 
     bf16x8 xb[CT][G::KS];
 #pragma unroll
@@ -1108,21 +1123,22 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
     float e[4 * CT][2];   // exponentials of the numerator stream in progress (it spans two slots)
 
     // LDS address of slot t's subtile and the seam a slot carries (runtime forms)
-    auto lds_of = [&](int t) { return lds0 + (unsigned)(((t / SUB) % PIPE_NB) * CB + (t % SUB) * G::ST); };
+    auto lds_of = [&](int t) { return lds0 + (unsigned)(((t / SUB) % PG::NB) * CB + (t % SUB) * G::ST); };
     auto seam_of = [&](int t) {
         Pipe2Seam sm;
         sm.E = p.E;
         sm.do_seam = (t % SUB) == SUB - 1;
-        const int cs = t / SUB + 1 + PIPE_PF;
-        sm.n_stage = (sm.do_seam && cs < Cn) ? nbase + (int64_t)cs * G::BNF : -1;
-        sm.stage_buf = smem + (cs % PIPE_NB) * CB;
+        const int cs = t / SUB + 1 + PG::PF;   // beyond the last chunk: request the last one again (never read)
+        if constexpr (PG::DUMMY) sm.n_stage = sm.do_seam ? nbase + (int64_t)min(cs, Cn - 1) * G::BNF : -1;
+        else sm.n_stage = (sm.do_seam && cs < Cn) ? nbase + (int64_t)cs * G::BNF : -1;
+        sm.stage_buf = smem + (cs % PG::NB) * CB;
         sm.next_lbase = lds0;
         return sm;
     };
 
     int t = 0;
     if (T > 0) {
-        if (Cn > PIPE_PF) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        if (PG::DUMMY || Cn > PG::PF) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PG::PF * 4) : "memory");   // chunk 0 landed
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         pipe_a_prologue<D, 0, PIPE_AD>(lds0, L.a0, af);
         {   // slot 0: nothing to drain yet
@@ -1132,16 +1148,16 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
         }
         t = 1;
         // steady state: TR slots per trip, every LDS offset an immediate
-        for (; (t + TR - 1) / SUB + 3 <= Cn - 1; t += TR) {
+        for (; PG::DUMMY ? (t + TR <= T) : ((t + TR - 1) / SUB + 3 <= Cn - 1); t += TR) {
 #define PCVAE_P2(UU)                                                                                                      \
             if constexpr (UU < TR) {                                                                                      \
                 constexpr int TL = 1 + UU, TG = UU, TN = 2 + UU;                                                          \
-                constexpr int OL = ((TL / SUB) % PIPE_NB) * CB + (TL % SUB) * G::ST;                                      \
-                constexpr int OG = ((TG / SUB) % PIPE_NB) * CB + (TG % SUB) * G::ST;                                      \
-                constexpr int ON = ((TN / SUB) % PIPE_NB) * CB + (TN % SUB) * G::ST;                                      \
+                constexpr int OL = ((TL / SUB) % PG::NB) * CB + (TL % SUB) * G::ST;                                      \
+                constexpr int OG = ((TG / SUB) % PG::NB) * CB + (TG % SUB) * G::ST;                                      \
+                constexpr int ON = ((TN / SUB) % PG::NB) * CB + (TN % SUB) * G::ST;                                      \
                 constexpr bool SEAM = (TL % SUB) == SUB - 1;                                                              \
                 const Pipe2Seam s2 = seam_of(t + UU);                                                                     \
-                pipe2_slot<D, CT, OL, OG, ON, SEAM, true, 2 * 4, false>(lds0, lds0, L, xb, af, R2[TL & 1], R2[TG & 1], U, \
+                pipe2_slot<D, CT, OL, OG, ON, SEAM, true, (PG::PF - 1) * 4, false>(lds0, lds0, L, xb, af, R2[TL & 1], R2[TG & 1], U, \
                                                                         lsum, s2, wave_u, lane_off, e);                   \
             }
             PCVAE_P2(0) PCVAE_P2(1) PCVAE_P2(2) PCVAE_P2(3) PCVAE_P2(4) PCVAE_P2(5) PCVAE_P2(6) PCVAE_P2(7)
@@ -1185,6 +1201,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
             asm volatile("s_nop 1" ::: "memory");
             pipe2_cold_gradient<D, CT>(lds_of(T - 1), L, pb, U, lsum);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive its wave
     }
     // ---- tail: short / ragged chunks, staged synchronously with clamped addresses, one subtile at a time
     for (int tt = t_beg + T; tt < t_end; tt += 4) {
@@ -1287,7 +1304,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
             constexpr bool ALWAYS_PIPE = D == 256;
             constexpr int CT = D == 256 ? 2 : 4;
             if (catalog_bf16_pipelined(D, p.tiles_per_split)) {
-                constexpr int lds_pipe = PIPE_NB * 16384;
+                constexpr int lds_pipe = PipeGeo<D, CT>::NB * 16384;
                 static bool attr_set3 = false;
                 if (!attr_set3) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_pipe_kernel<D, CT>),

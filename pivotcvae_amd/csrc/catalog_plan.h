@@ -34,7 +34,14 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
     int64_t best_cost = -1;
     for (int64_t ns = 1; ns <= cap; ++ns) {
-        const int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;
+        int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;
+        // software-pipelined bf16 kernels: their steady-state trip is 12 slots (D = 128: 6 ring chunks x 2 subtiles) resp. 6
+        // (D = 256) after one fill slot; what is left over runs fenced.  A range of 12k+4 (resp. 12k+8) tiles leaves 3
+        // (resp. 1) such slots instead of up to 11 (5).
+        if (!f32 && (D == 128 || D == 256) && tps >= 64) {
+            const int64_t want = D == 128 ? 4 : 8;
+            tps += ((want - tps % 12) + 12) % 12;
+        }
         const int64_t ns_eff = cdiv(p.ntiles, tps);
         const int64_t rounds = cdiv(nblk * ns_eff, slots);
         const int64_t cost = rounds * tps;
@@ -53,7 +60,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
 static inline bool catalog_bf16_pipelined(int D, int tiles_per_split) {
     if (D == 256) return true;
     const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
-    return tiles_per_split >= (env_min ? atoi(env_min) : 2048);
+    return tiles_per_split >= (env_min ? atoi(env_min) : (D == 128 ? 2048 : 512));
 }
 
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
