@@ -818,23 +818,29 @@ struct PipeGeo {
     static constexpr bool DUMMY = !(D == 128 && CT == 4);
     static constexpr int TR = NB * G::SUB;          // slots per steady-state trip
     static constexpr int first_op(int m) { return (m * VOPS + MPOS - 1) / MPOS; }
+    // the last exponential of a row-tile-0 pair is op 3 (2 CT - 1): it must sit behind a gradient-chain MFMA
+    static_assert(3 * (2 * CT - 1) < (MG * VOPS + MPOS - 1) / MPOS, "row tile 0 numerators must finish in their own slot");
 };
 
 template <int CT>
-struct PipeRegs {                 // per parity: logits accumulators and packed numerators
-    f32x4 acc[2][CT];             // [row tile][column tile]
+struct PipeRegs {                 // per slot parity
+    f32x4 acc1[CT];               // logits accumulators of row tile 1 (their numerators are taken during the NEXT logits chain)
     unsigned w[CT][4];            // w[ct][2 rt + h]: bf16 pair (half h of row tile rt, column tile ct)
 };
+// The accumulators of row tile 0 (acc0[CT]) are NOT double-buffered: the op schedule takes all their exponentials during
+// the gradient chain of their own slot (static_assert in PipeGeo), before the next logits chain overwrites them.
 
 // VALU op V of a slot's numerator stream: v = 0, 1: exponentials of pair 0; then for pair j >= 1: exp, exp, conversion of
 // pair j - 1 (a transcendental result needs an independent instruction before its VALU consumer); last: conversion P-1
 template <int CT, int V>
-__device__ __forceinline__ void pipe2_op(const PipeRegs<CT>& src, PipeRegs<CT>& dst, float (&e)[4 * CT][2]) {
+__device__ __forceinline__ void pipe2_op(const f32x4 (&acc0)[CT], const PipeRegs<CT>& src, PipeRegs<CT>& dst,
+                                         float (&e)[4 * CT][2]) {
     constexpr int P = 4 * CT, VOPS = 3 * P;
     if constexpr (V < 2 || (V < VOPS - 1 && (V + 1) % 3 != 2)) {            // an exponential
         constexpr int k = V < 2 ? 0 : (V + 1) / 3, which = V < 2 ? V : (V + 1) % 3;
         constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
-        asm volatile("v_exp_f32 %0, %1" : "=v"(e[k][which]) : "v"(src.acc[rt][ct][2 * h + which]));
+        if constexpr (rt == 0) asm volatile("v_exp_f32 %0, %1" : "=v"(e[k][which]) : "v"(acc0[ct][2 * h + which]));
+        else asm volatile("v_exp_f32 %0, %1" : "=v"(e[k][which]) : "v"(src.acc1[ct][2 * h + which]));
     } else {                                                                // a packed conversion
         constexpr int k = V == VOPS - 1 ? P - 1 : (V + 1) / 3 - 1;
         constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
@@ -843,11 +849,12 @@ __device__ __forceinline__ void pipe2_op(const PipeRegs<CT>& src, PipeRegs<CT>& 
 }
 // all ops scheduled behind MFMA position M
 template <int D, int CT, int M, int V = PipeGeo<D, CT>::first_op(M)>
-__device__ __forceinline__ void pipe2_ops(const PipeRegs<CT>& src, PipeRegs<CT>& dst, float (&e)[4 * CT][2]) {
+__device__ __forceinline__ void pipe2_ops(const f32x4 (&acc0)[CT], const PipeRegs<CT>& src, PipeRegs<CT>& dst,
+                                          float (&e)[4 * CT][2]) {
     using PG = PipeGeo<D, CT>;
     if constexpr (M < PG::MPOS && V < PG::first_op(M + 1) && V < PG::VOPS) {
-        pipe2_op<CT, V>(src, dst, e);
-        pipe2_ops<D, CT, M, V + 1>(src, dst, e);
+        pipe2_op<CT, V>(acc0, src, dst, e);
+        pipe2_ops<D, CT, M, V + 1>(acc0, src, dst, e);
     }
 }
 template <int CT>
@@ -871,8 +878,8 @@ struct Pipe2Seam {          // all wave-uniform
 // phase B: logits chain of slot t (into `cur`) with the second part of the previous slot's numerators (prev -> prev.w)
 template <int D, int CT, int OFF, int I, bool HAS_XPREV, bool COLD>
 __device__ __forceinline__ void pipe2_logits(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS],
-                                             const bf16x8 (&xb)[CT][FastGeo<D>::KS], PipeRegs<CT>& cur, PipeRegs<CT>& prev,
-                                             float (&e)[4 * CT][2]) {
+                                             const bf16x8 (&xb)[CT][FastGeo<D>::KS], f32x4 (&acc0)[CT], PipeRegs<CT>& cur,
+                                             PipeRegs<CT>& prev, float (&e)[4 * CT][2]) {
     using PG = PipeGeo<D, CT>;
     if constexpr (I < PG::NI) {
         if constexpr (I + PIPE_AD < PG::NI) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
@@ -880,21 +887,23 @@ __device__ __forceinline__ void pipe2_logits(const unsigned lbase, const int a0,
         constexpr int s = I >> 1, rt = I & 1;
 #define PCVAE_L_MFMA(CTI)                                                                                  \
         if constexpr (CTI < CT) {                                                                          \
-            if constexpr (s == 0) mfma_v0<COLD>(cur.acc[rt][CTI], af[I], xb[CTI][s]);                      \
-            else mfma_v<COLD>(cur.acc[rt][CTI], af[I], xb[CTI][s]);                                        \
-            if constexpr (HAS_XPREV) pipe2_ops<D, CT, PG::MG + I * CT + CTI>(prev, prev, e);               \
+            f32x4& a_ = rt == 0 ? acc0[CTI] : cur.acc1[CTI];                                               \
+            if constexpr (s == 0) mfma_v0<COLD>(a_, af[I], xb[CTI][s]);                                    \
+            else mfma_v<COLD>(a_, af[I], xb[CTI][s]);                                                      \
+            if constexpr (HAS_XPREV) pipe2_ops<D, CT, PG::MG + I * CT + CTI>(acc0, prev, prev, e);         \
         }
         PCVAE_L_MFMA(0) PCVAE_L_MFMA(1) PCVAE_L_MFMA(2) PCVAE_L_MFMA(3)
 #undef PCVAE_L_MFMA
-        pipe2_logits<D, CT, OFF, I + 1, HAS_XPREV, COLD>(lbase, a0, af, xb, cur, prev, e);
+        pipe2_logits<D, CT, OFF, I + 1, HAS_XPREV, COLD>(lbase, a0, af, xb, acc0, cur, prev, e);
     }
 }
 
 // phase A: gradient chain of slot t-1 (numerators pb_prev) with the first part of slot t's numerators (cur.acc -> cur.w)
 template <int D, int CT, int OFFG, int OFFL_NEXT, int DT, bool SEAM, bool HAS_G, int VM, bool COLD>
 __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[FastGeo<D>::NDT],
-                                           s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb_prev)[CT], PipeRegs<CT>& cur,
-                                           float (&e)[4 * CT][2], f32x4 (&U)[FastGeo<D>::NDT][CT], const Pipe2Seam& sm,
+                                           s16x4 (&th)[FastGeo<D>::NDT], const bf16x8 (&pb_prev)[CT], const f32x4 (&acc0)[CT],
+                                           PipeRegs<CT>& cur, float (&e)[4 * CT][2], f32x4 (&U)[FastGeo<D>::NDT][CT],
+                                           const Pipe2Seam& sm,
                                            const int wave_u, const int (&lane_off)[4], const int a0,
                                            bf16x8 (&af)[2 * FastGeo<D>::KS]) {
     using G = FastGeo<D>;
@@ -926,12 +935,12 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
 #define PCVAE_G_MFMA(CTI)                                                                                  \
         if constexpr (CTI < CT) {                                                                          \
             if constexpr (HAS_G) mfma_a<COLD>(U[DT][CTI], a, pb_prev[CTI]);                                \
-            pipe2_ops<D, CT, CT + DT * CT + CTI>(cur, cur, e);                                             \
+            pipe2_ops<D, CT, CT + DT * CT + CTI>(acc0, cur, cur, e);                                       \
         }
         PCVAE_G_MFMA(0) PCVAE_G_MFMA(1) PCVAE_G_MFMA(2) PCVAE_G_MFMA(3)
 #undef PCVAE_G_MFMA
-        pipe2_grad<D, CT, OFFG, OFFL_NEXT, DT + 1, SEAM, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pb_prev, cur, e, U, sm, wave_u,
-                                                                           lane_off, a0, af);
+        pipe2_grad<D, CT, OFFG, OFFL_NEXT, DT + 1, SEAM, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pb_prev, acc0, cur, e, U, sm,
+                                                                           wave_u, lane_off, a0, af);
     } else if constexpr (COLD) {
         pipe_fence();
     }
@@ -940,12 +949,12 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
 template <int D, int CT, int OFFL, int OFFG, int OFFL_NEXT, bool SEAM, bool HAS_G, int VM, bool COLD>
 __device__ __forceinline__ void pipe2_slot(const unsigned lbase_l, const unsigned lbase_g, const FastLane& L,
                                            const bf16x8 (&xb)[CT][FastGeo<D>::KS], bf16x8 (&af)[2 * FastGeo<D>::KS],
-                                           PipeRegs<CT>& cur, PipeRegs<CT>& prev, f32x4 (&U)[FastGeo<D>::NDT][CT],
-                                           f32x4 (&lsum)[CT], const Pipe2Seam& sm, const int wave_u,
-                                           const int (&lane_off)[4], float (&e)[4 * CT][2]) {
+                                           f32x4 (&acc0)[CT], PipeRegs<CT>& cur, PipeRegs<CT>& prev,
+                                           f32x4 (&U)[FastGeo<D>::NDT][CT], f32x4 (&lsum)[CT], const Pipe2Seam& sm,
+                                           const int wave_u, const int (&lane_off)[4], float (&e)[4 * CT][2]) {
     using G = FastGeo<D>;
     if constexpr (COLD) pipe_fence();
-    pipe2_logits<D, CT, OFFL, 0, HAS_G, COLD>(lbase_l, L.a0, af, xb, cur, prev, e);
+    pipe2_logits<D, CT, OFFL, 0, HAS_G, COLD>(lbase_l, L.a0, af, xb, acc0, cur, prev, e);
     bf16x8 pb_prev[CT];
     pipe2_pack<CT>(prev, pb_prev);
     s16x4 tl[G::NDT], th[G::NDT];
@@ -955,26 +964,26 @@ __device__ __forceinline__ void pipe2_slot(const unsigned lbase_l, const unsigne
         if constexpr (CTI < CT) {                                                                          \
             if constexpr (COLD) mfma_a<true>(lsum[CTI], L.ones, pb_prev[CTI]);                             \
             else mfma_agpr_guarded(lsum[CTI], L.ones, pb_prev[CTI]);                                       \
-            pipe2_ops<D, CT, CTI>(cur, cur, e);                                                            \
+            pipe2_ops<D, CT, CTI>(acc0, cur, cur, e);                                                      \
         }
         PCVAE_ONES(0) PCVAE_ONES(1) PCVAE_ONES(2) PCVAE_ONES(3)
 #undef PCVAE_ONES
     } else {
         pipe_fence();  // no MFMAs between the logits chain and the first exponential
-        pipe2_ops<D, CT, 0>(cur, cur, e);
-        if constexpr (CT > 1) pipe2_ops<D, CT, 1>(cur, cur, e);
-        if constexpr (CT > 2) { pipe2_ops<D, CT, 2>(cur, cur, e); pipe2_ops<D, CT, 3>(cur, cur, e); }
+        pipe2_ops<D, CT, 0>(acc0, cur, cur, e);
+        if constexpr (CT > 1) pipe2_ops<D, CT, 1>(acc0, cur, cur, e);
+        if constexpr (CT > 2) { pipe2_ops<D, CT, 2>(acc0, cur, cur, e); pipe2_ops<D, CT, 3>(acc0, cur, cur, e); }
     }
-    pipe2_grad<D, CT, OFFG, OFFL_NEXT, 0, SEAM, HAS_G, VM, COLD>(lbase_g, L.t0, tl, th, pb_prev, cur, e, U, sm, wave_u, lane_off,
-                                                                 L.a0, af);
+    pipe2_grad<D, CT, OFFG, OFFL_NEXT, 0, SEAM, HAS_G, VM, COLD>(lbase_g, L.t0, tl, th, pb_prev, acc0, cur, e, U, sm, wave_u,
+                                                                 lane_off, L.a0, af);
 }
 
 // pipeline drain after the last slot: the rest of its numerators, then its gradient chain
 template <int D, int CT, int M = PipeGeo<D, CT>::MG>
-__device__ __forceinline__ void pipe2_drain_ops(PipeRegs<CT>& last, float (&e)[4 * CT][2]) {
+__device__ __forceinline__ void pipe2_drain_ops(const f32x4 (&acc0)[CT], PipeRegs<CT>& last, float (&e)[4 * CT][2]) {
     if constexpr (M < PipeGeo<D, CT>::MPOS) {
-        pipe2_ops<D, CT, M>(last, last, e);
-        pipe2_drain_ops<D, CT, M + 1>(last, e);
+        pipe2_ops<D, CT, M>(acc0, last, last, e);
+        pipe2_drain_ops<D, CT, M + 1>(acc0, last, e);
     }
 }
 template <int D, int CT, int DT = 0>
@@ -1009,7 +1018,7 @@ __device__ __forceinline__ void pipe2_cold_gradient(const unsigned lbase_g, cons
 // one subtile on its own (ragged tail): logits, bound check, numerators, gradient - nothing overlapped, every MFMA fenced
 template <int D, int CT, int I = 0>
 __device__ __forceinline__ void pipe2_cold_logits(const unsigned lbase, const int a0, bf16x8 (&af)[2 * FastGeo<D>::KS],
-                                                  const bf16x8 (&xb)[CT][FastGeo<D>::KS], PipeRegs<CT>& r) {
+                                                  const bf16x8 (&xb)[CT][FastGeo<D>::KS], f32x4 (&acc)[2][CT]) {
     constexpr int NI = 2 * FastGeo<D>::KS;
     if constexpr (I < NI) {
         pipe_a_issue<D, 0, I>(lbase, a0, af[I]);
@@ -1017,20 +1026,20 @@ __device__ __forceinline__ void pipe2_cold_logits(const unsigned lbase, const in
         constexpr int s = I >> 1, rt = I & 1;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            if constexpr (s == 0) mfma_v0<true>(r.acc[rt][ct], af[I], xb[ct][s]);
-            else mfma_v<true>(r.acc[rt][ct], af[I], xb[ct][s]);
+            if constexpr (s == 0) mfma_v0<true>(acc[rt][ct], af[I], xb[ct][s]);
+            else mfma_v<true>(acc[rt][ct], af[I], xb[ct][s]);
         }
-        pipe2_cold_logits<D, CT, I + 1>(lbase, a0, af, xb, r);
+        pipe2_cold_logits<D, CT, I + 1>(lbase, a0, af, xb, acc);
     }
 }
 template <int D, int CT>
 __device__ __forceinline__ void pipe2_solo(const unsigned lbase, const int64_t n0, const int64_t N, const FastLane& L,
                                            const bf16x8 (&xb)[CT][FastGeo<D>::KS], f32x4 (&U)[FastGeo<D>::NDT][CT],
                                            f32x4 (&lsum)[CT]) {
-    PipeRegs<CT> r;
+    f32x4 acc[2][CT];
     bf16x8 af[2 * FastGeo<D>::KS];
     pipe_fence();
-    pipe2_cold_logits<D, CT>(lbase, L.a0, af, xb, r);
+    pipe2_cold_logits<D, CT>(lbase, L.a0, af, xb, acc);
     pipe_fence();
     bf16x8 pb[CT];
 #pragma unroll
@@ -1040,8 +1049,8 @@ __device__ __forceinline__ void pipe2_solo(const unsigned lbase, const int64_t n
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
                 const bool ok0 = n0 + 16 * rt + 4 * L.g + i < N, ok1 = n0 + 16 * rt + 4 * L.g + i + 1 < N;
-                const float e0 = ok0 ? __builtin_amdgcn_exp2f(r.acc[rt][ct][i]) : 0.f;
-                const float e1 = ok1 ? __builtin_amdgcn_exp2f(r.acc[rt][ct][i + 1]) : 0.f;
+                const float e0 = ok0 ? __builtin_amdgcn_exp2f(acc[rt][ct][i]) : 0.f;
+                const float e1 = ok1 ? __builtin_amdgcn_exp2f(acc[rt][ct][i + 1]) : 0.f;
                 pb[ct][4 * rt + i] = (__bf16)e0;
                 pb[ct][4 * rt + i + 1] = (__bf16)e1;
             }
@@ -1119,6 +1128,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
     PipeRegs<CT> R2[2];
+    f32x4 acc0[CT];
     bf16x8 af[2 * G::KS];
     float e[4 * CT][2];   // exponentials of the numerator stream in progress (it spans two slots)
 
@@ -1144,7 +1154,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
         {   // slot 0: nothing to drain yet
             Pipe2Seam sm = seam_of(0);
             sm.next_lbase = lds_of(T > 1 ? 1 : 0);
-            pipe2_slot<D, CT, 0, 0, 0, true, false, 0, true>(lds0, lds0, L, xb, af, R2[0], R2[1], U, lsum, sm, wave_u, lane_off, e);
+            pipe2_slot<D, CT, 0, 0, 0, true, false, 0, true>(lds0, lds0, L, xb, af, acc0, R2[0], R2[1], U, lsum, sm, wave_u, lane_off, e);
         }
         t = 1;
         // steady state: TR slots per trip, every LDS offset an immediate
@@ -1157,7 +1167,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
                 constexpr int ON = ((TN / SUB) % PG::NB) * CB + (TN % SUB) * G::ST;                                      \
                 constexpr bool SEAM = (TL % SUB) == SUB - 1;                                                              \
                 const Pipe2Seam s2 = seam_of(t + UU);                                                                     \
-                pipe2_slot<D, CT, OL, OG, ON, SEAM, true, (PG::PF - 1) * 4, false>(lds0, lds0, L, xb, af, R2[TL & 1], R2[TG & 1], U, \
+                pipe2_slot<D, CT, OL, OG, ON, SEAM, true, (PG::PF - 1) * 4, false>(lds0, lds0, L, xb, af, acc0, R2[TL & 1], R2[TG & 1], U, \
                                                                         lsum, s2, wave_u, lane_off, e);                   \
             }
             PCVAE_P2(0) PCVAE_P2(1) PCVAE_P2(2) PCVAE_P2(3) PCVAE_P2(4) PCVAE_P2(5) PCVAE_P2(6) PCVAE_P2(7)
@@ -1179,7 +1189,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
                 constexpr bool SEAM = ((1 + UU) % SUB) == SUB - 1;                                                        \
                 Pipe2Seam s2 = seam_of(t + UU);                                                                           \
                 s2.next_lbase = lds_of(t + UU + 1 < T ? t + UU + 1 : t + UU);                                             \
-                pipe2_slot<D, CT, 0, 0, 0, SEAM, true, 0, false>(lds_of(t + UU), lds_of(t + UU - 1), L, xb, af,           \
+                pipe2_slot<D, CT, 0, 0, 0, SEAM, true, 0, false>(lds_of(t + UU), lds_of(t + UU - 1), L, xb, af, acc0,     \
                                                                  R2[(1 + UU) & 1], R2[UU & 1], U, lsum, s2, wave_u, lane_off, e); \
             }
             PCVAE_P2R(0) PCVAE_P2R(1) PCVAE_P2R(2) PCVAE_P2R(3)
@@ -1190,14 +1200,14 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
         for (; t < T; ++t) {
             Pipe2Seam s2 = seam_of(t);
             s2.next_lbase = lds_of(t + 1 < T ? t + 1 : t);
-            if (t & 1) pipe2_slot<D, CT, 0, 0, 0, true, true, 0, true>(lds_of(t), lds_of(t - 1), L, xb, af, R2[1], R2[0], U, lsum, s2, wave_u, lane_off, e);
-            else pipe2_slot<D, CT, 0, 0, 0, true, true, 0, true>(lds_of(t), lds_of(t - 1), L, xb, af, R2[0], R2[1], U, lsum, s2, wave_u, lane_off, e);
+            if (t & 1) pipe2_slot<D, CT, 0, 0, 0, true, true, 0, true>(lds_of(t), lds_of(t - 1), L, xb, af, acc0, R2[1], R2[0], U, lsum, s2, wave_u, lane_off, e);
+            else pipe2_slot<D, CT, 0, 0, 0, true, true, 0, true>(lds_of(t), lds_of(t - 1), L, xb, af, acc0, R2[0], R2[1], U, lsum, s2, wave_u, lane_off, e);
         }
         {   // drain: the rest of the last slot's numerators, then its gradient chain
             bf16x8 pb[CT];
             pipe_fence();
-            if ((T - 1) & 1) { pipe2_drain_ops<D, CT>(R2[1], e); pipe2_pack<CT>(R2[1], pb); }
-            else { pipe2_drain_ops<D, CT>(R2[0], e); pipe2_pack<CT>(R2[0], pb); }
+            if ((T - 1) & 1) { pipe2_drain_ops<D, CT>(acc0, R2[1], e); pipe2_pack<CT>(R2[1], pb); }
+            else { pipe2_drain_ops<D, CT>(acc0, R2[0], e); pipe2_pack<CT>(R2[0], pb); }
             asm volatile("s_nop 1" ::: "memory");
             pipe2_cold_gradient<D, CT>(lds_of(T - 1), L, pb, U, lsum);
         }
