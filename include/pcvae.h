@@ -197,6 +197,26 @@ int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, const int64_t*
  * ------------------------------------------------------------------------------------------- */
 int pcvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                     float eps, int step, float grad_scale, pcvae_stream_t stream);
+/* the same with torch.optim.Adam's weight_decay (L2 term added to the gradient: g' = g * grad_scale + weight_decay * p);
+ * pretrain_env.py:59 trains the click model with it                                                                */
+int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                       float eps, int step, float grad_scale, float weight_decay, pcvae_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training the click model                       pretrain_env.py:25-139 ; env/response_model.py:76-87
+ *   scatter_add_rows    : nn.Embedding backward, dtable[idx[i], :] += g_row(i)  (g laid out like gather_rows' output)
+ *   normalize_rows_norm : F.normalize in place, row norms max(||x||, 1e-12) kept;  normalize_rows_bwd : its backward
+ *   bce_sigmoid         : nn.BCELoss()(sigmoid(x), t) per element (logs clamped at -100) and dL/dx * grad_scale
+ *   relu_bwd            : g *= (y > 0)   (F.relu backward keyed on the activated output)
+ * ------------------------------------------------------------------------------------------- */
+int pcvae_scatter_add_rows(const float* g, int64_t g_ld, int group, int D, const int64_t* idx, int64_t n_idx,
+                           float* dtable, int64_t n_rows, pcvae_stream_t stream);
+int pcvae_normalize_rows_norm(float* x, int64_t ldx, int64_t rows, int cols, float* norm, pcvae_stream_t stream);
+int pcvae_normalize_rows_bwd(const float* y, int64_t ldy, const float* norm, const float* g, int64_t ldg, float* dx,
+                             int64_t lddx, int64_t rows, int cols, pcvae_stream_t stream);
+int pcvae_bce_sigmoid(const float* x, const float* t, int64_t n, float* loss, float* dx, float grad_scale,
+                      pcvae_stream_t stream);
+int pcvae_relu_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t rows, int cols, pcvae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -243,7 +243,10 @@ def recommend(sd, cfg: Config, r, u, eps, pivot_sample=None):
 
 
 def response_mlp(sd, slates, users, no_user=False):
-    """UserResponseModel_MLP.forward: the WHOLE concatenated slate vector is normalised."""
+    """UserResponseModel_MLP.forward (env/response_model.py:76-87): the WHOLE concatenated slate vector is normalised.
+    ``F.normalize(userEmbed(users), p=2, dim=1)``: with users [B] the user rows are L2-normalised; with users [B, 1] (the
+    training batches of pretrain_env.py) the lookup is [B, 1, D] and dim=1 is its singleton axis, i.e. every component
+    becomes x / max(|x|, 1e-12) - restated as written."""
     B = slates.shape[0]
     d = F.normalize(sd["docEmbed.weight"][slates].reshape(B, -1), p=2, dim=1)
     x = d if no_user else torch.cat([d, F.normalize(sd["userEmbed.weight"][users], p=2, dim=1).reshape(B, -1)], 1)
@@ -253,6 +256,20 @@ def response_mlp(sd, slates, users, no_user=False):
         if i < n:
             x = F.relu(x)
     return x
+
+
+def response_loss_and_grads(sd, slates, users, targets, no_user=False):
+    """pretrain_env.py:82-90: BCELoss(sigmoid(logits), targets) (mean) and the gradient of every parameter."""
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    pred = response_mlp(leaf, slates, users, no_user)
+    loss = F.binary_cross_entropy(torch.sigmoid(pred.reshape(-1)), targets.reshape(-1).float())
+    loss.backward()
+    return loss.item(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+
+
+def adam_l2_step(sd, grads, state, lr, weight_decay, b1=0.9, b2=0.999, eps=1e-8):
+    """torch.optim.Adam(weight_decay=...) as pretrain_env.py:59 uses it: the L2 term joins the gradient."""
+    return adam_step(sd, {k: g + weight_decay * sd[k] for k, g in grads.items()}, state, lr, b1, b2, eps)
 
 
 # ------------------------------------------------------------------ synthetic workload

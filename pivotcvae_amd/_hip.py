@@ -51,6 +51,12 @@ SIGNATURES = {
     "pcvae_candidate_scores_bwd": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],
     "pcvae_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
+    "pcvae_adam_step_l2": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _F, _P],
+    "pcvae_scatter_add_rows": [_P, _L, _I, _I, _P, _L, _P, _L, _P],
+    "pcvae_normalize_rows_norm": [_P, _L, _L, _I, _P, _P],
+    "pcvae_normalize_rows_bwd": [_P, _L, _P, _P, _L, _P, _L, _L, _I, _P],
+    "pcvae_bce_sigmoid": [_P, _P, _L, _P, _P, _F, _P],
+    "pcvae_relu_bwd": [_P, _L, _P, _L, _L, _I, _P],
 }
 _RESTYPES = {"pcvae_last_error": _c.c_char_p, "pcvae_catalog_ws_bytes": _SZ}
 

@@ -536,9 +536,10 @@ extern "C" int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, con
 // =============================================================================================
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float one_minus_b1, float b2, float one_minus_b2,
-                            float eps, float step_size, float sqrt_bc2, float grad_scale) {
+                            float eps, float step_size, float sqrt_bc2, float grad_scale, float weight_decay) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * grad_scale;
+        float gi = g[i] * grad_scale;
+        if (weight_decay != 0.f) gi = fmaf(weight_decay, p[i], gi);  // torch.optim.Adam(weight_decay): L2 term in the gradient
         const float mi = m[i] + (gi - m[i]) * one_minus_b1;
         const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
         m[i] = mi;
@@ -550,7 +551,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 extern "C" int pcvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                                float eps, int step, float grad_scale, pcvae_stream_t stream) {
-    PCVAE_REQUIRE(p && g && m && v && n >= 0 && step >= 1, "adam_step: bad arguments");
+    return pcvae_adam_step_l2(p, g, m, v, n, lr, b1, b2, eps, step, grad_scale, 0.f, stream);
+}
+
+extern "C" int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                                  float eps, int step, float grad_scale, float weight_decay, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(p && g && m && v && n >= 0 && step >= 1 && weight_decay >= 0.f, "adam_step: bad arguments");
     if (n == 0) return PCVAE_OK;
     const double bc1 = 1.0 - pow((double)b1, step);
     const double bc2 = 1.0 - pow((double)b2, step);
@@ -559,6 +565,120 @@ extern "C" int pcvae_adam_step(float* p, const float* g, float* m, float* v, int
     const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 4096);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, g, m, v, n,
                        (float)(1.0 - (double)b1), b2, (float)(1.0 - (double)b2), eps, step_size, sqrt_bc2,
-                       grad_scale);
+                       grad_scale, weight_decay);
     return check_launch("adam_step");
+}
+
+// =============================================================================================
+// Training the click model (reference pretrain_env.py:25-139): the pieces the forward-only evaluation path did not need.
+// =============================================================================================
+// embedding backward: dtable[idx[i], :] += g_row(i), g laid out like the output of pcvae_gather_rows.  fp32 atomics: rows
+// that occur several times in a batch are summed in arrival order (the reference's index_add on the GPU is unordered too).
+__global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __restrict__ g, int64_t g_ld, int group, int D,
+                                                               const int64_t* __restrict__ idx, int64_t n_idx,
+                                                               float* __restrict__ dtable) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t i = wave; i < n_idx; i += n_waves) {
+        const float* src = g + (i / group) * g_ld + (i % group) * (int64_t)D;
+        float* dst = dtable + idx[i] * (int64_t)D;
+        for (int d = lane; d < D; d += 64) atomicAdd(dst + d, src[d]);
+    }
+}
+extern "C" int pcvae_scatter_add_rows(const float* g, int64_t g_ld, int group, int D, const int64_t* idx, int64_t n_idx,
+                                      float* dtable, int64_t n_rows, pcvae_stream_t stream) {
+    if (n_idx == 0) return PCVAE_OK;
+    PCVAE_REQUIRE(g && idx && dtable && D > 0 && group > 0 && n_rows > 0 && g_ld >= (int64_t)group * D,
+                  "scatter_add_rows: bad arguments");
+    const int64_t blocks = std::min<int64_t>(cdiv(n_idx, 4), 256 * 8);
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, g_ld, group, D,
+                       idx, n_idx, dtable);
+    return check_launch("scatter_add_rows");
+}
+
+// F.normalize with the row norms kept for the backward pass, and its backward: dx = (g - y <y, g>) / max(||x||, 1e-12)
+__global__ void __launch_bounds__(256) normalize_rows_norm_kernel(float* __restrict__ x, int64_t ldx, int64_t rows, int cols,
+                                                                  float* __restrict__ norm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float ss = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float v = x[r * ldx + c]; ss += v * v; }
+    ss = wave_sum(ss);
+    const float n = fmaxf(sqrtf(ss), 1e-12f);
+    if (lane == 0) norm[r] = n;
+    const float inv = 1.f / n;
+    for (int c = lane; c < cols; c += 64) x[r * ldx + c] *= inv;
+}
+__global__ void __launch_bounds__(256) normalize_rows_bwd_kernel(const float* __restrict__ y, int64_t ldy,
+                                                                 const float* __restrict__ norm, const float* __restrict__ g,
+                                                                 int64_t ldg, float* __restrict__ dx, int64_t lddx,
+                                                                 int64_t rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float dot = 0.f;
+    for (int c = lane; c < cols; c += 64) dot = fmaf(y[r * ldy + c], g[r * ldg + c], dot);
+    dot = wave_sum(dot);
+    const float inv = 1.f / norm[r];
+    for (int c = lane; c < cols; c += 64) dx[r * lddx + c] = (g[r * ldg + c] - y[r * ldy + c] * dot) * inv;
+}
+extern "C" int pcvae_normalize_rows_norm(float* x, int64_t ldx, int64_t rows, int cols, float* norm, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(cols > 0 && ldx >= cols && rows >= 0 && ((x && norm) || rows == 0), "normalize_rows_norm: bad arguments");
+    if (rows == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(normalize_rows_norm_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, as_stream(stream), x, ldx,
+                       rows, cols, norm);
+    return check_launch("normalize_rows_norm");
+}
+extern "C" int pcvae_normalize_rows_bwd(const float* y, int64_t ldy, const float* norm, const float* g, int64_t ldg,
+                                        float* dx, int64_t lddx, int64_t rows, int cols, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(cols > 0 && ldy >= cols && ldg >= cols && lddx >= cols && rows >= 0 && ((y && norm && g && dx) || rows == 0),
+                  "normalize_rows_bwd: bad arguments");
+    if (rows == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, as_stream(stream), y, ldy,
+                       norm, g, ldg, dx, lddx, rows, cols);
+    return check_launch("normalize_rows_bwd");
+}
+
+// nn.BCELoss()(sigmoid(x), t) per element with its gradient (pretrain_env.py:57-58,84): logs clamped at -100 as torch does,
+// dL/dx = (s - t) / max(s (1 - s), 1e-12) * s (1 - s) * grad_scale
+__global__ void bce_sigmoid_kernel(const float* __restrict__ x, const float* __restrict__ t, int64_t n,
+                                   float* __restrict__ loss, float* __restrict__ dx, float grad_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s = 1.f / (1.f + expf(-x[i]));
+        const float l1 = fmaxf(logf(s), -100.f), l0 = fmaxf(logf(1.f - s), -100.f);
+        loss[i] = -(t[i] * l1 + (1.f - t[i]) * l0);
+        if (dx) {
+            const float q = s * (1.f - s);
+            dx[i] = (s - t[i]) / fmaxf(q, 1e-12f) * q * grad_scale;
+        }
+    }
+}
+extern "C" int pcvae_bce_sigmoid(const float* x, const float* t, int64_t n, float* loss, float* dx, float grad_scale,
+                                 pcvae_stream_t stream) {
+    if (n == 0) return PCVAE_OK;
+    PCVAE_REQUIRE(x && t && loss && n > 0, "bce_sigmoid: bad arguments");
+    const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 2048);
+    hipLaunchKernelGGL(bce_sigmoid_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, t, n, loss, dx,
+                       grad_scale);
+    return check_launch("bce_sigmoid");
+}
+
+// F.relu backward keyed on the activated output: g *= (y > 0)
+__global__ void relu_bwd_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ y, int64_t ldy, int64_t rows,
+                                int cols) {
+    const int64_t n = rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cols;
+        const int c = (int)(i % cols);
+        if (!(y[r * ldy + c] > 0.f)) g[r * ldg + c] = 0.f;
+    }
+}
+extern "C" int pcvae_relu_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t rows, int cols,
+                              pcvae_stream_t stream) {
+    PCVAE_REQUIRE(g && y && cols > 0 && ldg >= cols && ldy >= cols, "relu_bwd: bad arguments");
+    if (rows == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(rows * cols, 256), 2048);
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, ldg, y, ldy, rows, cols);
+    return check_launch("relu_bwd");
 }

@@ -1,9 +1,10 @@
 """The learned click model used for in-loop evaluation (reference env/response_model.py:15-87) and the uniform user
 sampler (:10-13), forward-only on the HIP path.
 
-Only what ``train_generative.py:169-195`` touches is mirrored: ``Environment`` (owner of the RAW, un-normalised
-``docEmbed`` / ``userEmbed`` tables that the CVAE copies and normalises), ``UserResponseModel_MLP.forward`` and
-``sample_users``.  Training this model (pretrain_env.py) and the simulators' dataset generation are out of scope.
+``Environment`` (owner of the RAW, un-normalised ``docEmbed`` / ``userEmbed`` tables that the CVAE copies and
+normalises), ``UserResponseModel_MLP.forward`` (no-grad, the in-loop evaluation of ``train_generative.py:169-195``),
+``forward_train`` (the same forward with hand-written backward kernels, for ``pivotcvae_amd.pretrain_env``) and
+``sample_users``.  The simulators' dataset generation is out of scope.
 """
 import math
 
@@ -53,6 +54,27 @@ class UserResponseModel_MLP(Environment):
             nn.init.kaiming_uniform_(lin.weight)
             self.add_module("mlp_" + str(i + 1), lin)
 
+    def forward_train(self, slates, users):
+        """forward() with autograd (reference pretrain_env.py:82-83).  A quirk of the reference is reproduced: the training
+        batches carry users as [B, 1], so ``F.normalize(self.userEmbed(users), p=2, dim=1)`` (env/response_model.py:81)
+        normalises a [B, 1, D] tensor over its size-1 axis - every component becomes x / max(|x|, 1e-12) = sign(x) and
+        the user table receives a zero gradient (weight decay still moves it).  With users of shape [B] (what
+        sample_users returns) the user rows are L2-normalised as expected."""
+        B = slates.shape[0]
+        S, D = self.slateSize, self.featureSize
+        d = ops.normalize_rows(ops.embedding_rows(self.docEmbed.weight, slates, group=S))           # [B, S*D]
+        if self.noUser:
+            x = d
+        else:
+            urows = ops.embedding_rows(self.userEmbed.weight, users)                              # [B, D]
+            if users.dim() == 2:   # [B, 1]: normalisation over the singleton axis
+                uemb = ops.normalize_rows(urows.reshape(B * D, 1)).reshape(B, D)
+            else:
+                uemb = ops.normalize_rows(urows)
+            x = ops.concat([d, uemb])
+        layers = [(getattr(self, f"mlp_{i}").weight, getattr(self, f"mlp_{i}").bias) for i in range(1, self._n + 1)]
+        return ops.mlp_relu(x, layers)
+
     @torch.no_grad()
     def forward(self, slates, users):
         B = slates.shape[0]
@@ -63,8 +85,13 @@ class UserResponseModel_MLP(Environment):
         ops.gather_rows(self.docEmbed.weight, slates.reshape(-1), out=x[:, : S * D], group=S)
         ops.normalize_rows_(x[:, : S * D])
         if not self.noUser:
-            ops.gather_rows(self.userEmbed.weight, users.reshape(-1), out=x[:, S * D:])
-            ops.normalize_rows_(x[:, S * D:])
+            if users.dim() == 2:  # [B, 1] batches: the reference normalises over the singleton axis (see forward_train)
+                urows = ops.gather_rows(self.userEmbed.weight, users.reshape(-1))
+                ops.normalize_rows_(urows.reshape(B * D, 1))
+                ops.copy2d(urows, x[:, S * D:])
+            else:
+                ops.gather_rows(self.userEmbed.weight, users.reshape(-1), out=x[:, S * D:])
+                ops.normalize_rows_(x[:, S * D:])
         for i in range(1, self._n + 1):
             lin = getattr(self, f"mlp_{i}")
             x = ops.linear_fwd_raw(x, lin.weight, lin.bias, ACT_RELU if i < self._n else ACT_NONE)

@@ -582,7 +582,135 @@ def dense_ce(p, target):
 
 
 # ------------------------------------------------------------------------------------------- K8
-def adam_step_(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_step_(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0, weight_decay=0.0):
     require_device(p, g, m, v)
-    check(lib().pcvae_adam_step(ptr(p, F32), ptr(g, F32), ptr(m, F32), ptr(v, F32), p.numel(), lr, b1, b2, eps, step,
-                                grad_scale, stream()), "adam_step")
+    check(lib().pcvae_adam_step_l2(ptr(p, F32), ptr(g, F32), ptr(m, F32), ptr(v, F32), p.numel(), lr, b1, b2, eps, step,
+                                   grad_scale, weight_decay, stream()), "adam_step")
+
+
+# ------------------------------------------------------------- training the click model (pretrain_env.py:25-139)
+class _EmbeddingRows(torch.autograd.Function):
+    """table[idx] as rows of a [n_idx / group, group * D] matrix; backward = dense table gradient by scatter-add."""
+
+    @staticmethod
+    def forward(ctx, table, idx, group):
+        out = gather_rows(table, idx, group=group)
+        ctx.save_for_backward(idx)
+        ctx.group, ctx.shape = group, tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _c2d(g)
+        N, D = ctx.shape
+        dt = torch.zeros(N, D, dtype=F32, device=g.device)
+        check(lib().pcvae_scatter_add_rows(ptr(g, F32), _ld(g), ctx.group, D, ptr(idx), idx.numel(), ptr(dt, F32), N,
+                                           stream()), "scatter_add_rows")
+        return dt, None, None
+
+
+def embedding_rows(table, idx, group=1):
+    """differentiable nn.Embedding lookup: [idx.numel() / group, group * D]"""
+    return _EmbeddingRows.apply(table, idx.reshape(-1).contiguous(), group)
+
+
+class _NormalizeRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = _c2d(x).clone()
+        norm = torch.empty(y.shape[0], dtype=F32, device=y.device)
+        check(lib().pcvae_normalize_rows_norm(ptr(y, F32), _ld(y), y.shape[0], y.shape[1], ptr(norm, F32), stream()),
+              "normalize_rows_norm")
+        ctx.save_for_backward(y, norm)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, norm = ctx.saved_tensors
+        g = _c2d(g)
+        dx = torch.empty_like(y)
+        check(lib().pcvae_normalize_rows_bwd(ptr(y, F32), _ld(y), ptr(norm, F32), ptr(g, F32), _ld(g), ptr(dx, F32), _ld(dx),
+                                             y.shape[0], y.shape[1], stream()), "normalize_rows_bwd")
+        return dx
+
+
+def normalize_rows(x):
+    """F.normalize(x, p=2, dim=1) of a [rows, cols] matrix, differentiable"""
+    require_device(x)
+    return _NormalizeRows.apply(x)
+
+
+class _BCESigmoid(torch.autograd.Function):
+    """nn.BCELoss()(sigmoid(x), t), mean over all elements (pretrain_env.py:57-58,84)"""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        x, t = x.contiguous(), t.to(F32).contiguous()
+        n = x.numel()
+        le = torch.empty(n, dtype=F32, device=x.device)
+        dx = torch.empty_like(x)
+        check(lib().pcvae_bce_sigmoid(ptr(x, F32), ptr(t, F32), n, ptr(le, F32), ptr(dx, F32), 1.0 / n, stream()), "bce_sigmoid")
+        out = torch.empty((), dtype=F32, device=x.device)
+        check(lib().pcvae_sum(ptr(le, F32), n, 1.0 / n, ptr(out, F32), stream()), "sum")
+        ctx.save_for_backward(dx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        d2 = dx.reshape(1, -1)
+        out = torch.empty_like(d2)
+        check(lib().pcvae_scale_rows(ptr(d2, F32), _ld(d2), ptr(out, F32), _ld(out), 1, d2.shape[1], ptr(g.contiguous(), F32),
+                                     1.0, stream()), "scale_rows")
+        return out.reshape(dx.shape), None
+
+
+def bce_sigmoid(logits, targets):
+    require_device(logits, targets)
+    return _BCESigmoid.apply(logits, targets)
+
+
+class _MLPRelu(torch.autograd.Function):
+    """Linear -> ReLU -> ... -> Linear (the click model's stack, env/response_model.py:84-86) as one autograd node"""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        require_device(x, *params)
+        n = len(params) // 2
+        h = _c2d(x)
+        acts = [h]
+        for i in range(n):
+            h = linear_fwd_raw(h, params[2 * i], params[2 * i + 1], ACT_RELU if i < n - 1 else ACT_NONE)
+            acts.append(h)
+        ctx.n = n
+        ctx.save_for_backward(*acts, *params)
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, params = saved[: n + 1], saved[n + 1:]
+        g = _c2d(g).contiguous()
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            W, b = params[2 * i], params[2 * i + 1]
+            dW, db = torch.zeros_like(W), torch.zeros_like(b)
+            linear_bwd_weight_raw(g, acts[i], dW, db)
+            grads[2 * i], grads[2 * i + 1] = dW, db
+            if i > 0 or ctx.needs_input_grad[0]:
+                g = linear_bwd_input_raw(g, W, xact=None)
+                if i > 0:  # acts[i] is the ReLU output of layer i-1
+                    check(lib().pcvae_relu_bwd(ptr(g, F32), _ld(g), ptr(acts[i], F32), _ld(acts[i]), g.shape[0], g.shape[1],
+                                               stream()), "relu_bwd")
+            else:
+                g = None
+        return (g,) + tuple(grads)
+
+
+def mlp_relu(x, layers):
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    return _MLPRelu.apply(x, *flat)

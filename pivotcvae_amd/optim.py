@@ -13,8 +13,9 @@ from . import ops
 
 
 class FlatAdam:
-    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8):
-        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+    def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        # weight_decay: torch.optim.Adam's L2 term (pretrain_env.py:59); train_generative.py:103 passes none
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -49,4 +50,4 @@ class FlatAdam:
     def step(self, grad_scale=1.0):
         self.t += 1
         ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps,
-                       grad_scale)
+                       grad_scale, self.weight_decay)

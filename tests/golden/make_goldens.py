@@ -291,7 +291,47 @@ def make_response_model(name, N, NU, D, S, B, H, seed):
     print(f"{name}: {len(out)} arrays")
 
 
+def make_response_training(name, N, NU, D, S, B, H, seed, lr, decay, steps=3):
+    """G8: three optimisation steps of pretrain_env.train_response_model's loop body (pretrain_env.py:76-92) on one fixed
+    batch with users of shape [B, 1] (what data_loader.UserSlateResponseDataset yields): BCELoss of the sigmoid of the
+    click logits, torch.optim.Adam(lr, weight_decay) over every parameter (tables included)."""
+    torch.manual_seed(seed)
+    rm = quiet(ref_env.UserResponseModel_MLP, N - 1, NU - 1, D, S, [(S + 1) * D, H, H, S], "cpu", False)
+    g = torch.Generator().manual_seed(seed + 1)
+    s = torch.randint(0, N, (B, S), generator=g)
+    s[1] = s[0]                                   # repeated item rows: their gradients must add up
+    u = torch.randint(0, NU, (B, 1), generator=g)
+    r = (torch.rand(B, S, generator=g) < 0.4).float()
+    out = {"sd/" + k: v.numpy().copy() for k, v in rm.state_dict().items()}
+    out.update(s=s.numpy(), u=u.numpy(), r=r.numpy())
+    bce, sig = torch.nn.BCELoss(), torch.nn.Sigmoid()
+    opt = torch.optim.Adam(rm.parameters(), lr=lr, weight_decay=decay)
+    losses = []
+    for t in range(steps):
+        opt.zero_grad()
+        pred = rm.forward(s, u)
+        loss = bce(sig(pred.reshape(-1)), r.reshape(-1))
+        loss.backward()
+        if t == 0:
+            out["logits0"] = pred.detach().numpy().copy()
+            for k, p in rm.named_parameters():
+                out["grad/" + k] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+        opt.step()
+        losses.append(loss.item())
+        if t in (0, steps - 1):
+            for k, v in rm.state_dict().items():
+                out[f"after{t + 1}/" + k] = v.numpy().copy()
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["meta"] = np.array(json.dumps(dict(name=name, N=N, NU=NU, D=D, S=S, B=B, H=H, seed=seed, lr=lr, decay=decay, steps=steps,
+                                           torch=torch.__version__)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(out)} arrays, losses {losses}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "response_training":   # mint only the new case (the others stay byte-identical)
+        make_response_training("response_training", N=203, NU=11, D=16, S=5, B=12, H=24, seed=501, lr=1e-2, decay=1e-3)
+        return
     keys = list(ref_pivot.PIVOTCVAE_MODELS)
     # all 8 pivot variants, with user, S=5 D=16 (N=203: seven 32-row catalog tiles, ragged tail)
     for i, k in enumerate(keys):
@@ -306,6 +346,7 @@ def main():
     make_case("listcvae_user", "listcvae", S=5, D=16, Z=4, N=203, NU=11, B=7, H=24, HP=12, no_user=False, seed=301)
     make_case("listcvae_nouser", "listcvae", S=5, D=16, Z=4, N=203, NU=11, B=7, H=24, HP=12, no_user=True, seed=302)
     make_response_model("response_mlp", N=203, NU=11, D=16, S=5, B=9, H=24, seed=401)
+    make_response_training("response_training", N=203, NU=11, D=16, S=5, B=12, H=24, seed=501, lr=1e-2, decay=1e-3)
 
 
 if __name__ == "__main__":

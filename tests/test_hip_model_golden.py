@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from tests.gpu_util import DEV, build_from_golden, close, dev
+from oracle import pivotcvae_oracle as orc
 from tests.helpers import load, model_cases
 
 pytestmark = pytest.mark.gpu
@@ -194,6 +195,63 @@ def test_g7_response_model_and_click_stats():
     freq = torch.bincount(users, minlength=m["NU"]).float() / 20000
     assert (freq - 1.0 / m["NU"]).abs().max() < 0.01
     assert torch.equal(users, sample_users(rm, 20000, seed=3).cpu())
+
+
+def test_g8_response_model_training_steps():
+    """pivotcvae_amd.pretrain_env.ResponseTrainer (gather + scatter-add backward, whole-vector normalisation and its
+    backward, ReLU MLP, BCE of the sigmoid, Adam with weight decay over one flat buffer incl. the tables) against the
+    golden steps of the reference's loop body: logits, losses, gradients, parameters after 1 and 3 steps."""
+    from pivotcvae_amd.env.response_model import UserResponseModel_MLP
+    from pivotcvae_amd.pretrain_env import ResponseTrainer
+    g = load("response_training")
+    m = g.meta
+    rm = UserResponseModel_MLP(m["N"] - 1, m["NU"] - 1, m["D"], m["S"], [(m["S"] + 1) * m["D"], m["H"], m["H"], m["S"]],
+                               DEV, False)
+    rm.load_state_dict(g.sd)
+    rm.to(DEV)
+    s, u, r = dev(g.t("s")), dev(g.t("u")), dev(g.t("r"))
+    close(rm(s, u), g.t("logits0"), rtol=1e-5, atol=1e-5)              # the no-grad forward: same [B, 1] user quirk
+    tr = ResponseTrainer(rm, m["lr"], m["decay"])
+    tr.opt.zero_grad()
+    loss = tr.loss(s, u, r)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g.a["losses"][0], rtol=1e-5)
+    for k, p in rm.named_parameters():
+        close(p.grad, g.t("grad/" + k), rtol=2e-4, atol=2e-7)
+    assert float(rm.userEmbed.weight.grad.abs().max()) < 1e-7   # zero up to the rounding of x * (1 / |x|)
+    for t in range(m["steps"]):
+        loss = tr.step(s, u, r)
+        np.testing.assert_allclose(loss.item(), g.a["losses"][t], rtol=2e-5)
+        if t in (0, m["steps"] - 1):
+            for k, v in rm.state_dict().items():
+                # user table: its gradient is rounding noise + weight_decay * p (see tests/test_oracle_golden.py g8)
+                if k == "userEmbed.weight":
+                    close(v, g.t(f"after{t + 1}/" + k), rtol=0, atol=0.05 * m["lr"])
+                else:
+                    close(v, g.t(f"after{t + 1}/" + k), rtol=1e-4, atol=2e-6)
+
+
+def test_response_trainer_l2_users_and_validation():
+    """users of shape [B] (L2-normalised user rows, non-zero user-table gradient) against the oracle; validation loss."""
+    from pivotcvae_amd.env.response_model import UserResponseModel_MLP
+    from pivotcvae_amd.pretrain_env import ResponseTrainer
+    g = load("response_training")
+    m = g.meta
+    rm = UserResponseModel_MLP(m["N"] - 1, m["NU"] - 1, m["D"], m["S"], [(m["S"] + 1) * m["D"], m["H"], m["H"], m["S"]],
+                               DEV, False)
+    rm.load_state_dict(g.sd)
+    rm.to(DEV)
+    s, u, r = g.t("s"), g.t("u").reshape(-1), g.t("r")
+    wl, wg = orc.response_loss_and_grads(g.sd, s, u, r)
+    tr = ResponseTrainer(rm, m["lr"], m["decay"])
+    tr.opt.zero_grad()
+    loss = tr.loss(dev(s), dev(u), dev(r))
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), wl, rtol=1e-5)
+    for k, p in rm.named_parameters():
+        close(p.grad, wg[k], rtol=2e-4, atol=2e-7)
+    assert float(rm.userEmbed.weight.grad.abs().max()) > 0
+    np.testing.assert_allclose(tr.validation_loss(dev(s), dev(u), dev(r)).item(), wl, rtol=1e-5)
 
 
 def test_recommendation_test_matches_oracle_composition():

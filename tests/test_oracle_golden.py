@@ -119,6 +119,33 @@ def test_g7_response_mlp():
     close(orc.response_mlp(g.sd, g.t("s"), g.t("u")), g.t("logits"))
 
 
+def test_g8_response_training_steps():
+    """pretrain_env.py:76-92 restated: logits, BCE loss, every gradient (the user table's is exactly zero: the reference
+    normalises the [B, 1, D] user lookup over its singleton axis: zero up to rounding), parameters after 1 and 3 Adam(weight_decay) steps."""
+    g = load("response_training")
+    m = g.meta
+    s, u, r = g.t("s"), g.t("u"), g.t("r")
+    assert u.dim() == 2 and u.shape[1] == 1
+    close(orc.response_mlp(g.sd, s, u), g.t("logits0"))
+    sd, state = g.sd, {}
+    for t in range(m["steps"]):
+        loss, grads = orc.response_loss_and_grads(sd, s, u, r)
+        np.testing.assert_allclose(loss, g.a["losses"][t], rtol=2e-6)
+        if t == 0:
+            for k, v in g.sub("grad").items():
+                close(grads[k], v, rtol=2e-5, atol=1e-8)
+            assert float(g.t("grad/userEmbed.weight").abs().max()) < 1e-7   # zero up to the rounding of x * (1 / |x|)
+        sd = orc.adam_l2_step(sd, grads, state, m["lr"], m["decay"])
+        if t in (0, m["steps"] - 1):
+            for k, v in g.sub(f"after{t + 1}").items():
+                # the user table's gradient is rounding noise (~1e-9) + weight_decay * p; where |p| < 1e-4 that sum is of the
+                # order of Adam's eps and the normalised step follows the noise: those few entries agree to a few % of lr
+                if k == "userEmbed.weight":
+                    close(sd[k], v, rtol=0, atol=0.05 * m["lr"])
+                else:
+                    close(sd[k], v, rtol=2e-5, atol=2e-7)
+
+
 def test_downsample_semantics():
     """masked-out logits become 0 (not -inf) and the target column is always kept."""
     pred = torch.arange(12, dtype=torch.float32).reshape(3, 4) + 1
