@@ -218,6 +218,17 @@ int pcvae_bce_sigmoid(const float* x, const float* t, int64_t n, float* loss, fl
                       pcvae_stream_t stream);
 int pcvae_relu_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t rows, int cols, pcvae_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Offline metrics of generated slates                          analysis.py:5-30
+ *   coverage_count : number of distinct item ids among ids[0..n) (ids outside [0, N) ignored); bits = scratch of
+ *                    ceil(N / 32) words.  get_coverage = count / N.
+ *   ils            : out[b] = (sum_{i,j} <e_i, e_j> - S) / (S (S - 1)) with e_i = normalize(E[slates[b, i]])  (get_ILS)
+ * ------------------------------------------------------------------------------------------- */
+int pcvae_coverage_count(const int64_t* ids, int64_t n, int64_t N, unsigned int* bits, int64_t* count,
+                         pcvae_stream_t stream);
+int pcvae_ils(const float* E, int64_t N, int D, const int64_t* slates, int64_t B, int S, float* out,
+              pcvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

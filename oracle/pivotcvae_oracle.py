@@ -272,6 +272,19 @@ def adam_l2_step(sd, grads, state, lr, weight_decay, b1=0.9, b2=0.999, eps=1e-8)
     return adam_step(sd, {k: g + weight_decay * sd[k] for k, g in grads.items()}, state, lr, b1, b2, eps)
 
 
+def coverage(slates, N):
+    """analysis.get_coverage (analysis.py:5-12): distinct generated items / N"""
+    return len(torch.unique(slates)) * 1.0 / N
+
+
+def ils(slates, E):
+    """analysis.get_ILS (analysis.py:14-30): mean pairwise cosine similarity of the items of a slate (self pairs removed)"""
+    S = slates.shape[1]
+    emb = F.normalize(E[slates], p=2, dim=2)
+    sims = torch.bmm(emb, emb.transpose(1, 2)).reshape(slates.shape[0], -1)
+    return (sims.sum(dim=1) - S) / (S * (S - 1))
+
+
 # ------------------------------------------------------------------ synthetic workload
 def synthetic_tables(N, NU, D, seed=0):
     """E_raw, U_raw ~ U(-a, a), a = sqrt(2/D) (env/response_model.py:29-36)."""

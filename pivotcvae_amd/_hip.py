@@ -57,6 +57,8 @@ SIGNATURES = {
     "pcvae_normalize_rows_bwd": [_P, _L, _P, _P, _L, _P, _L, _L, _I, _P],
     "pcvae_bce_sigmoid": [_P, _P, _L, _P, _P, _F, _P],
     "pcvae_relu_bwd": [_P, _L, _P, _L, _L, _I, _P],
+    "pcvae_coverage_count": [_P, _L, _L, _P, _P, _P],
+    "pcvae_ils": [_P, _L, _I, _P, _L, _I, _P, _P],
 }
 _RESTYPES = {"pcvae_last_error": _c.c_char_p, "pcvae_catalog_ws_bytes": _SZ}
 

@@ -682,3 +682,71 @@ extern "C" int pcvae_relu_bwd(float* g, int64_t ldg, const float* y, int64_t ldy
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g, ldg, y, ldy, rows, cols);
     return check_launch("relu_bwd");
 }
+
+// =============================================================================================
+// Offline metrics of generated slates (reference analysis.py:5-30)
+// =============================================================================================
+// item coverage: mark every generated id in an N-bit map (atomicOr), then count the set bits
+__global__ void coverage_mark_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t N, unsigned int* __restrict__ bits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t v = ids[i];
+        if (v >= 0 && v < N) atomicOr(bits + (v >> 5), 1u << (v & 31));
+    }
+}
+__global__ void __launch_bounds__(1024) coverage_count_kernel(const unsigned int* __restrict__ bits, int64_t words,
+                                                              int64_t* __restrict__ count) {
+    __shared__ unsigned long long part[16];
+    unsigned long long c = 0;
+    for (int64_t i = threadIdx.x; i < words; i += 1024) c += __popc(bits[i]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        *count = (int64_t)t;
+    }
+}
+extern "C" int pcvae_coverage_count(const int64_t* ids, int64_t n, int64_t N, unsigned int* bits, int64_t* count,
+                                    pcvae_stream_t stream) {
+    PCVAE_REQUIRE(N > 0 && n >= 0 && bits && count && (ids || n == 0), "coverage_count: bad arguments");
+    const int64_t words = cdiv(N, 32);
+    (void)hipMemsetAsync(bits, 0, (size_t)words * 4, as_stream(stream));
+    if (n > 0) {
+        const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 2048);
+        hipLaunchKernelGGL(coverage_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), ids, n, N, bits);
+    }
+    hipLaunchKernelGGL(coverage_count_kernel, dim3(1), dim3(1024), 0, as_stream(stream), bits, words, count);
+    return check_launch("coverage_count");
+}
+
+// intra-list similarity: with e_i the L2-normalised embedding of slot i, sum_{i,j} <e_i, e_j> = ||sum_i e_i||^2, so
+// ILS = (||sum_i e_i||^2 - S) / (S (S - 1)); one wave per slate, no [S, S] matrix
+__global__ void __launch_bounds__(256) ils_kernel(const float* __restrict__ E, int D, const int64_t* __restrict__ slates,
+                                                  int64_t B, int S, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float tot = 0.f;   // ||sum_i e_i||^2 accumulated over the d slices this lane owns
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        float acc = 0.f;
+        for (int i = 0; i < S; ++i) {
+            const float* row = E + slates[b * S + i] * (int64_t)D;
+            float ss = 0.f;
+            for (int k = lane; k < D; k += 64) ss = fmaf(row[k], row[k], ss);
+            ss = wave_sum(ss);
+            if (d < D) acc += row[d] / fmaxf(sqrtf(ss), 1e-12f);
+        }
+        tot = fmaf(acc, acc, tot);
+    }
+    tot = wave_sum(tot);
+    if (lane == 0) out[b] = (tot - (float)S) / (float)(S * (S - 1));
+}
+extern "C" int pcvae_ils(const float* E, int64_t N, int D, const int64_t* slates, int64_t B, int S, float* out,
+                         pcvae_stream_t stream) {
+    PCVAE_REQUIRE(E && N > 0 && D > 0 && S > 1 && B >= 0 && ((slates && out) || B == 0), "ils: bad arguments");
+    if (B == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(ils_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), E, D, slates, B, S, out);
+    return check_launch("ils");
+}

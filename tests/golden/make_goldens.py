@@ -328,7 +328,27 @@ def make_response_training(name, N, NU, D, S, B, H, seed, lr, decay, steps=3):
     print(f"{name}: {len(out)} arrays, losses {losses}")
 
 
+def make_analysis(name="response_analysis"):
+    """G9: analysis.get_coverage / get_ILS (analysis.py:5-30) on slates with repeated items."""
+    import analysis as ref_analysis
+    torch.manual_seed(7)
+    N, D, B, S = 300, 24, 40, 5
+    emb = torch.nn.Embedding(N, D)
+    g = torch.Generator().manual_seed(8)
+    slates = torch.randint(0, 60, (B, S), generator=g)      # few distinct ids: coverage < 1, repeated items inside slates
+    slates[3] = slates[3, 0]                                  # a slate of one repeated item: ILS = 1
+    cov = ref_analysis.get_coverage(slates, N)
+    ils = ref_analysis.get_ILS(slates, emb)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), E=emb.weight.detach().numpy(), slates=slates.numpy(),
+                        coverage=np.array(cov), ils=ils.detach().numpy(),
+                        meta=np.array(json.dumps(dict(name=name, N=N, D=D, B=B, S=S))))
+    print(f"{name}: coverage {cov}")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "response_analysis":
+        make_analysis()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "response_training":   # mint only the new case (the others stay byte-identical)
         make_response_training("response_training", N=203, NU=11, D=16, S=5, B=12, H=24, seed=501, lr=1e-2, decay=1e-3)
         return
@@ -347,6 +367,7 @@ def main():
     make_case("listcvae_nouser", "listcvae", S=5, D=16, Z=4, N=203, NU=11, B=7, H=24, HP=12, no_user=True, seed=302)
     make_response_model("response_mlp", N=203, NU=11, D=16, S=5, B=9, H=24, seed=401)
     make_response_training("response_training", N=203, NU=11, D=16, S=5, B=12, H=24, seed=501, lr=1e-2, decay=1e-3)
+    make_analysis()
 
 
 if __name__ == "__main__":

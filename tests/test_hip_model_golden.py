@@ -254,6 +254,20 @@ def test_response_trainer_l2_users_and_validation():
     np.testing.assert_allclose(tr.validation_loss(dev(s), dev(u), dev(r)).item(), wl, rtol=1e-5)
 
 
+def test_g9_offline_metrics_on_device():
+    """analysis.get_coverage / get_ILS (analysis.py:5-30) against the reference's values; S != 5 against the oracle."""
+    from pivotcvae_amd import analysis
+    g = load("response_analysis")
+    sl, E = dev(g.t("slates")), dev(g.t("E"))
+    assert analysis.get_coverage(sl, g.meta["N"]) == float(g.a["coverage"])
+    close(analysis.get_ILS(sl, torch.nn.Embedding.from_pretrained(E)), g.t("ils"), rtol=1e-5, atol=2e-6)
+    gen = torch.Generator().manual_seed(5)
+    E2 = torch.randn(5000, 128, generator=gen)
+    s2 = torch.randint(0, 5000, (300, 10), generator=gen)
+    close(analysis.get_ILS(dev(s2), dev(E2)), orc.ils(s2, E2), rtol=1e-5, atol=2e-6)
+    assert analysis.get_coverage(dev(s2), 5000) == orc.coverage(s2, 5000)
+
+
 def test_recommendation_test_matches_oracle_composition():
     """The device-side in-loop evaluation == oracle recommend + oracle response model on the same users and eps."""
     from oracle import pivotcvae_oracle as orc

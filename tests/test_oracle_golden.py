@@ -146,6 +146,12 @@ def test_g8_response_training_steps():
                     close(sd[k], v, rtol=2e-5, atol=2e-7)
 
 
+def test_g9_offline_metrics():
+    g = load("response_analysis")
+    assert orc.coverage(g.t("slates"), g.meta["N"]) == float(g.a["coverage"])
+    close(orc.ils(g.t("slates"), g.t("E")), g.t("ils"), rtol=1e-5, atol=1e-6)
+
+
 def test_downsample_semantics():
     """masked-out logits become 0 (not -inf) and the target column is always kept."""
     pred = torch.arange(12, dtype=torch.float32).reshape(3, 4) + 1
