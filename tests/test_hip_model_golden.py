@@ -254,6 +254,40 @@ def test_response_trainer_l2_users_and_validation():
     np.testing.assert_allclose(tr.validation_loss(dev(s), dev(u), dev(r)).item(), wl, rtol=1e-5)
 
 
+def test_train_response_model_loop(tmp_path):
+    """pretrain_env.train_response_model end to end on a small synthetic click log: same arguments as the reference function,
+    the loss falls, the best model is pickled and loads back with the reference's state_dict keys."""
+    from pivotcvae_amd.pretrain_env import train_response_model
+
+    class Log:
+        def __init__(self): self.lines = []
+        def log(self, s): self.lines.append(s)
+
+    class Clicks(torch.utils.data.Dataset):      # the fields of data_loader.UserSlateResponseDataset the function reads
+        def __init__(self, n, seed):
+            gen = torch.Generator().manual_seed(seed)
+            self.slates = torch.randint(0, 50, (n, 5), generator=gen).numpy()
+            self.users = torch.randint(0, 7, (n, 1), generator=gen).numpy()
+            self.resp = (torch.from_numpy(self.slates) % 3 == 0).float().numpy()   # learnable: a click iff item id % 3 == 0
+            self.max_iid, self.max_uid, self.noUser = 49, 6, False
+        def __len__(self): return len(self.slates)
+        def __getitem__(self, i): return {"slates": self.slates[i], "users": self.users[i], "responses": self.resp[i]}
+
+    path = str(tmp_path / "resp_model")
+    log = Log()
+    torch.manual_seed(0)
+    model, th, vh = train_response_model(Clicks(2048, 1), Clicks(256, 2), 8, 5, [48, 32, 5], 128, 6, 1e-2, 1e-5, DEV, path, log)
+    assert th[-1] < 0.6 * th[0] and vh[-1] < vh[0]
+    assert any("Save best model" in l for l in log.lines)
+    back = torch.load(open(path, "rb"), weights_only=False)
+    assert sorted(back.state_dict()) == ["docEmbed.weight", "mlp_1.bias", "mlp_1.weight", "mlp_2.bias", "mlp_2.weight",
+                                         "userEmbed.weight"]
+    s = torch.from_numpy(Clicks(64, 3).slates).to(DEV)
+    u = torch.zeros(64, dtype=torch.long, device=DEV)
+    pred = torch.sigmoid(back.to(DEV)(s, u)) > 0.5
+    assert (pred.cpu() == (s.cpu() % 3 == 0)).float().mean() > 0.9
+
+
 def test_g9_offline_metrics_on_device():
     """analysis.get_coverage / get_ILS (analysis.py:5-30) against the reference's values; S != 5 against the oracle."""
     from pivotcvae_amd import analysis

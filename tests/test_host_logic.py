@@ -172,3 +172,23 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
         for loop in loops:
             bad = [l for l in loop if l.startswith(mod.FORBIDDEN)]
             assert not bad, (name, bad[:5])
+
+
+def test_catalog_kernel_choice_and_range_alignment(monkeypatch):
+    """pcvae_catalog_ce_variant mirrors the launch logic (host only): f32 -> 0; bf16 D = 256 -> pipelined always; D = 128 /
+    64 -> pipelined on long ranges only, PCVAE_PIPE_MIN_TILES overrides; unsupported shapes -> -1."""
+    L = _hip.lib()
+    monkeypatch.delenv("PCVAE_PIPE_MIN_TILES", raising=False)
+    assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_F32) == 0
+    assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_BF16) == 2      # config 4 on one GPU: 7 8xx tiles per range
+    assert L.pcvae_catalog_ce_variant(10240, 1_000_000, 128, _hip.PREC_BF16) == 1      # one 8-GPU shard: 980 tiles per range
+    assert L.pcvae_catalog_ce_variant(40960, 100_000, 64, _hip.PREC_BF16) == 1         # config 3
+    assert L.pcvae_catalog_ce_variant(163840, 10_000_000, 256, _hip.PREC_BF16) == 2    # config 5
+    assert L.pcvae_catalog_ce_variant(64, 1000, 256, _hip.PREC_BF16) == 2
+    assert L.pcvae_catalog_ce_variant(64, 1000, 32, _hip.PREC_BF16) == -1
+    assert L.pcvae_catalog_ce_variant(0, 1000, 128, _hip.PREC_BF16) == -1
+    monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1")
+    assert L.pcvae_catalog_ce_variant(10240, 1_000_000, 128, _hip.PREC_BF16) == 2
+    monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1000000000")
+    assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_BF16) == 1
+    assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 256, _hip.PREC_BF16) == 2
