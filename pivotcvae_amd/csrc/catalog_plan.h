@@ -31,17 +31,13 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     const int64_t slots = 256 * (f32 ? 2 : 1);
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
     const int64_t nblk = (!f32 && D == 256) ? cdiv(R, 128) : p.nrb;
-    const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
+    int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
+    // bf16 D = 128: the pipelined kernel and the kernel that takes the rest of every range each write a partial per range
+    // and the merge kernel gives every partial a lane of one wave: at most 32 ranges
+    if (!f32 && D == 128) cap = std::min<int64_t>(cap, 32);
     int64_t best_cost = -1;
     for (int64_t ns = 1; ns <= cap; ++ns) {
-        int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;
-        // software-pipelined bf16 kernels: their steady-state trip is 12 slots (D = 128: 6 ring chunks x 2 subtiles) resp. 6
-        // (D = 256) after one fill slot; what is left over runs fenced.  A range of 12k+4 (resp. 12k+8) tiles leaves 3
-        // (resp. 1) such slots instead of up to 11 (5).
-        if (!f32 && (D == 128 || D == 256) && tps >= 64) {
-            const int64_t want = D == 128 ? 4 : 8;
-            tps += ((want - tps % 12) + 12) % 12;
-        }
+        const int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;
         const int64_t ns_eff = cdiv(p.ntiles, tps);
         const int64_t rounds = cdiv(nblk * ns_eff, slots);
         const int64_t cost = rounds * tps;
@@ -50,6 +46,15 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
             p.tiles_per_split = (int)tps;
             p.nsplit = (int)ns_eff;
         }
+    }
+    // software-pipelined bf16 kernel for D = 256: its steady-state trip is 6 slots after one fill slot, what is left over
+    // runs fenced; a range of 12k+8 tiles leaves 1 such slot instead of up to 5.  (Applied after the choice above, so that
+    // the few extra tiles do not bias it; D = 128 hands the rest of a range to the other kernel, D = 64 runs it at speed.)
+    if (!f32 && D == 256 && p.tiles_per_split >= 64) {
+        int64_t tps = p.tiles_per_split;
+        tps += ((8 - tps % 12) + 12) % 12;
+        p.tiles_per_split = (int)tps;
+        p.nsplit = (int)cdiv(p.ntiles, tps);
     }
     return p;
 }
@@ -60,7 +65,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
 static inline bool catalog_bf16_pipelined(int D, int tiles_per_split) {
     if (D == 256) return true;
     const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
-    return tiles_per_split >= (env_min ? atoi(env_min) : (D == 128 ? 2048 : 512));
+    return tiles_per_split >= (env_min ? atoi(env_min) : 512);
 }
 
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,

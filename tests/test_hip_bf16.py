@@ -124,13 +124,17 @@ def test_bf16_ce_masks(ops, R, N, D):
     assert (dx.cpu() - wd).abs().max() < 4e-3 * wd.abs().max()
 
 
+@pytest.mark.parametrize("pipelined", [False, True])
 @pytest.mark.parametrize("D", [64, 128, 256])
-def test_bf16_ce_peaked_rows_both_kernels(ops, D):
+def test_bf16_ce_peaked_rows_both_kernels(ops, D, pipelined, monkeypatch):
     """rows whose softmax is dominated by one item, late / early / very negative logits.  With |rx| = 60 the logit bound
     (60 * log2 e = 86.6 <= 90) still admits the max-free fast kernel: exp2 spans 2^+-86 and everything stays normal
     fp32; scaled by 1.2 the bound fails and the row block runs the lazy running-max kernel (its raise branches)."""
     from pivotcvae_amd._hip import PREC_BF16
-    R, N = 256, 8192
+    # pipelined: at D = 128 every range is split between two kernels; for a row block that the lazy-max kernel owns the
+    # second one must still hand the merge kernel a neutral partial (second half of the rows below, scale 1.2)
+    monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1" if pipelined else "1000000000")
+    R, N = 512, 8192
     E = orc.normalize_rows(rnd(N, D, seed=2))
     rx = rnd(R, D, seed=1, scale=0.1)
     rx[3] = E[N - 5] * 60.0
@@ -146,6 +150,14 @@ def test_bf16_ce_peaked_rows_both_kernels(ops, D):
         torch.testing.assert_close(lse.cpu(), wl, rtol=3e-5, atol=3e-5)
         torch.testing.assert_close(nll.cpu(), wn, rtol=3e-5, atol=1e-4)
         assert (dx.cpu() - wd).abs().max() < 4e-3 * wd.abs().max()
+    # mixed: the first 256-row block stays within the bound (max-free kernels), the second is scaled past it (lazy-max)
+    x = rx.clone()
+    x[256:] = rx[:256] * 1.2
+    nll, lse, dx = ops.catalog_ce_raw(x.to(DEV), E.to(DEV), tgt.to(DEV), prec=PREC_BF16)
+    wn0, wl0, wd0 = emulate_fast(x[:256], E, tgt[:256])
+    wn1, wl1, wd1 = emulate(x[256:], E, tgt[256:])
+    torch.testing.assert_close(lse.cpu(), torch.cat([wl0, wl1]), rtol=3e-5, atol=3e-5)
+    assert (dx.cpu() - torch.cat([wd0, wd1])).abs().max() < 4e-3 * wd0.abs().max()
 
 
 def test_bf16_vs_fp32_reference_arithmetic(ops):
