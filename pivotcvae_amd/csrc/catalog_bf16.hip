@@ -1439,6 +1439,8 @@ struct ScreenParams {
     float* eps2;                     // [R] 2 eps
     unsigned long long* best_key;    // [R]
     float e_max_norm;
+    unsigned int* overflow;          // set by the pipelined pass B when a workgroup's candidate list is full
+    int only_if_overflow;            // this launch is the exact redo of pass B: it returns at once unless *overflow != 0
 };
 
 __device__ __forceinline__ unsigned int ordered_bits(float f) {
@@ -1539,6 +1541,7 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_kernel(ScreenParam
     n_full = max(n_full, 0);
     const int64_t rw = (int64_t)rb * ROWS_WG + wave * 32;
     if (PASS == 1) {
+        if (p.only_if_overflow && *p.overflow == 0u) return;   // the pipelined pass B parked everything: nothing to redo
         if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(smem + SCREEN_RING + SCREEN_CAND_CAP * 8) = 0u;
         __syncthreads();
     }
@@ -1618,6 +1621,260 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_kernel(ScreenParam
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The screening passes on the software-pipelined logits chain (one wave per SIMD, CT column tiles of 16 rows per wave, every
+// MFMA / LDS read an inline-asm statement in schedule order - see catalog_ce_bf16_pipe_kernel).  Slot t = logits chain L(t)
+// into accumulator set t & 1, while the VALU looks at the logits of subtile t-1 (maxima / threshold tests, plain C++ that
+// hipcc schedules between the MFMAs; an empty asm on the previous accumulators a few MFMAs into the slot keeps those reads
+// behind the MFMAs that wrote them).  Ring and seams as in the CE kernel; the seam sits at the end of a chunk's last slot.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SCREEN_PIPE_CAP = 3072;   // 16-byte entries: (row, first item of the lane's eight, bit per item, -)
+
+template <int CT>
+struct ScreenAcc { f32x4 acc[2][CT]; };
+
+template <int CT>
+struct ScreenState {        // per lane: rows 16 ct + c of the wave
+    float m[CT], thr[CT], eps2[CT];
+    int64_t row[CT];
+};
+
+template <int D, int CT, int PASS, bool CHECK_N>
+__device__ __forceinline__ void screen_look(const ScreenParams& p, char* cand, ScreenAcc<CT>& a, const int64_t n0,
+                                            ScreenState<CT>& st, const int g, const int ct) {
+    if (CHECK_N) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (n0 + 16 * rt + 4 * g + i >= p.N) a.acc[rt][ct][i] = -INFINITY;
+    }
+    float v = fmaxf(fmaxf(a.acc[0][ct][0], a.acc[0][ct][1]), fmaxf(a.acc[0][ct][2], a.acc[0][ct][3]));
+    v = fmaxf(v, fmaxf(fmaxf(a.acc[1][ct][0], a.acc[1][ct][1]), fmaxf(a.acc[1][ct][2], a.acc[1][ct][3])));
+    if (PASS == 0) {
+        st.m[ct] = fmaxf(st.m[ct], v);
+    } else if (v >= st.thr[ct]) {
+        // park the lane's eight items (n0 + 16 rt + 4 g + i) as ONE entry with a bit per item that passed (branch-free to
+        // build); the final phase rescores the marked items exactly.  A full list raises the overflow flag: the (slow, exact)
+        // two-waves kernel then redoes pass B.
+        unsigned int* cnt = reinterpret_cast<unsigned int*>(cand + SCREEN_PIPE_CAP * 16);
+        uint4* list = reinterpret_cast<uint4*>(cand);
+        unsigned int mask = 0;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mask |= (a.acc[rt][ct][i] >= st.thr[ct] ? 1u : 0u) << (4 * rt + i);
+        const unsigned int slot = atomicAdd(cnt, 1u);
+        if (slot < (unsigned)SCREEN_PIPE_CAP) list[slot] = make_uint4((unsigned int)st.row[ct], (unsigned int)(n0 + 4 * g), mask, 0u);
+        else *p.overflow = 1u;
+        st.thr[ct] = fmaxf(st.thr[ct], v - st.eps2[ct]);
+    }
+}
+
+struct ScreenSeam {          // all wave-uniform
+    const uint16_t* E;
+    bool do_seam;            // this slot ends a ring chunk (runtime form, fenced slots only)
+    int64_t n_stage;         // first item of the chunk to request
+    char* stage_buf;
+    unsigned next_lbase;     // LDS address (minus the immediate) of the NEXT slot's subtile
+};
+
+// L(t) with the look at subtile t-1 spread over it: column tile ct of the previous accumulators is released to the VALU
+// after step (ct + 1) * NI / CT - 1 of this chain (>= 2 CT MFMAs after the MFMAs that wrote them).  In the middle of the
+// chain: the seam (if this slot ends a ring chunk) and the first A fragments of the NEXT slot, so no slot starts on a cold
+// LDS read.
+template <int D, int CT, int PASS, int OFF, int OFFN, int I, bool SEAM, int VM, bool HAS_PREV, bool COLD>
+__device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* cand, const unsigned lbase, const int a0,
+                                                   bf16x8 (&af)[2 * FastGeo<D>::KS],
+                                                   const bf16x8 (&xb)[CT][FastGeo<D>::KS], ScreenAcc<CT>& cur,
+                                                   ScreenAcc<CT>& prev, const int64_t n_prev, ScreenState<CT>& st, const int g,
+                                                   const ScreenSeam& sm, const int wave_u, const int (&lane_off)[4]) {
+    constexpr int NI = 2 * FastGeo<D>::KS, MID = NI / 2;
+    if constexpr (I < NI) {
+        if constexpr (I == MID) {
+            if constexpr (SEAM) {
+                if constexpr (COLD) {
+                    pipe_fence();
+                    if (sm.do_seam) {
+                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                        fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                    }
+                    pipe_fence();
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+                    fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                }
+            }
+            static_assert(PIPE_AD <= MID, "af[0 .. PIPE_AD) must be consumed before the next slot's fragments land in them");
+            pipe_a_prologue<D, OFFN, PIPE_AD>(sm.next_lbase, a0, af);   // first fragments of the next slot
+        }
+        // fragments younger than A(I) still in flight: the ones requested after it, and the next slot's first fragments if they
+        // were requested while A(I) was already in flight
+        constexpr int extra = (I >= MID && I < MID + PIPE_AD) ? PIPE_AD : 0;
+        if constexpr (I + PIPE_AD < NI) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
+        lgkm_wait<(I + PIPE_AD < NI ? PIPE_AD : NI - 1 - I) + extra>();
+        constexpr int s = I >> 1, rt = I & 1;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if constexpr (s == 0) mfma_v0<COLD>(cur.acc[rt][ct], af[I], xb[ct][s]);
+            else mfma_v<COLD>(cur.acc[rt][ct], af[I], xb[ct][s]);
+        }
+        if constexpr (HAS_PREV && (I + 1) % (NI / CT) == 0) {
+            constexpr int ct = (I + 1) / (NI / CT) - 1;
+            asm volatile("" : "+v"(prev.acc[0][ct]), "+v"(prev.acc[1][ct]));   // not before this point of the chain
+            screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);
+        }
+        screen_pipe_logits<D, CT, PASS, OFF, OFFN, I + 1, SEAM, VM, HAS_PREV, COLD>(p, cand, lbase, a0, af, xb, cur, prev,
+                                                                                  n_prev, st, g, sm, wave_u, lane_off);
+    }
+}
+
+template <int D, int CT, int PASS>
+__global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParams p) {
+    using G = FastGeo<D>;
+    using PG = PipeGeo<D, CT>;
+    constexpr int CB = 16384, NW = 4, ROWS = PG::ROWS, SUB = G::SUB, TR = PG::TR, NB = PG::NB, PF = PG::PF;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    char* cand = smem + NB * CB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int nrb = (int)((p.R + ROWS - 1) / ROWS);
+    const int split = logical / nrb, rb = logical % nrb;
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int64_t nbase = (int64_t)t_beg * 32;
+    int Cn = (int)min((int64_t)((t_end - t_beg) / SUB), (p.N - nbase) / G::BNF);
+    Cn = max(Cn, 0);
+    const int T = Cn * SUB;
+    const int64_t rw = (int64_t)rb * ROWS + wave * 16 * CT;
+    if (PASS == 1) {
+        if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(cand + SCREEN_PIPE_CAP * 16) = 0u;
+        __syncthreads();
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int lane_off[4];
+    fast_lane_off<D, NW>(lane, wave, lane_off);
+    for (int c0 = 0; c0 <= PF; ++c0)   // requests beyond the last chunk repeat it (constant number of chunks in flight)
+        if (Cn > 0) fast_stage<D, NW>(p.Eb, nbase + (int64_t)min(c0, Cn - 1) * G::BNF, smem + c0 * CB, wave_u, lane_off);
+
+    bf16x8 xb[CT][G::KS];
+    ScreenState<CT> st;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int64_t r = rw + 16 * ct + c;
+        st.row[ct] = r < p.R ? r : p.R - 1;
+        st.m[ct] = -INFINITY; st.thr[ct] = INFINITY; st.eps2[ct] = 0.f;
+        if (PASS == 1 && r < p.R) { st.thr[ct] = p.thr[r]; st.eps2[ct] = p.eps2[r]; }  // padding rows: never a candidate
+#pragma unroll
+        for (int s = 0; s < G::KS; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p.x + st.row[ct] * D + 8 * fchunk<D>(s, g));
+            const float4 v1 = *reinterpret_cast<const float4*>(p.x + st.row[ct] * D + 8 * fchunk<D>(s, g) + 4);
+            xb[ct][s][0] = (__bf16)v0.x; xb[ct][s][1] = (__bf16)v0.y; xb[ct][s][2] = (__bf16)v0.z; xb[ct][s][3] = (__bf16)v0.w;
+            xb[ct][s][4] = (__bf16)v1.x; xb[ct][s][5] = (__bf16)v1.y; xb[ct][s][6] = (__bf16)v1.z; xb[ct][s][7] = (__bf16)v1.w;
+        }
+    }
+    const FastLane L = fast_lane<D>(lane);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    ScreenAcc<CT> A2[2];
+    bf16x8 af[2 * G::KS];
+    auto lds_of = [&](int t) { return lds0 + (unsigned)(((t / SUB) % NB) * CB + (t % SUB) * G::ST); };
+    // the seam a slot carries in the middle of its chain (runtime form)
+    auto seam_of = [&](int t) {
+        ScreenSeam sm;
+        sm.E = p.Eb;
+        sm.do_seam = (t % SUB) == SUB - 1;
+        const int cs = t / SUB + 1 + PF;   // beyond the last chunk: request the last one again (never read)
+        sm.n_stage = nbase + (int64_t)min(cs, Cn - 1) * G::BNF;
+        sm.stage_buf = smem + (cs % NB) * CB;
+        sm.next_lbase = lds0;
+        return sm;
+    };
+
+    if (T > 0) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PF * 4) : "memory");
+        pipe_a_prologue<D, 0, PIPE_AD>(lds0, L.a0, af);
+        {   // slot 0: nothing to look at yet
+            ScreenSeam sm = seam_of(0);
+            sm.next_lbase = lds_of(T > 1 ? 1 : 0);
+            pipe_fence();
+            screen_pipe_logits<D, CT, PASS, 0, 0, 0, true, 0, false, true>(p, cand, lds0, L.a0, af, xb, A2[0], A2[1], 0, st, g, sm,
+                                                                         wave_u, lane_off);
+            pipe_fence();
+        }
+        int t = 1;
+        for (; t + TR <= T; t += TR) {   // steady state: every LDS offset an immediate
+#define PCVAE_SP(UU)                                                                                                      \
+            if constexpr (UU < TR) {                                                                                      \
+                constexpr int TL = 1 + UU, TN = 2 + UU;                                                                   \
+                constexpr int OL = ((TL / SUB) % NB) * CB + (TL % SUB) * G::ST;                                           \
+                constexpr int ON = ((TN / SUB) % NB) * CB + (TN % SUB) * G::ST;                                           \
+                constexpr bool SEAM = (TL % SUB) == SUB - 1;                                                              \
+                const ScreenSeam s2 = seam_of(t + UU);                                                                    \
+                screen_pipe_logits<D, CT, PASS, OL, ON, 0, SEAM, (PF - 1) * 4, true, false>(                              \
+                    p, cand, lds0, L.a0, af, xb, A2[TL & 1], A2[UU & 1], nbase + (int64_t)(t + UU - 1) * 32, st, g, s2,   \
+                    wave_u, lane_off);                                                                                    \
+            }
+            PCVAE_SP(0) PCVAE_SP(1) PCVAE_SP(2) PCVAE_SP(3) PCVAE_SP(4) PCVAE_SP(5) PCVAE_SP(6) PCVAE_SP(7)
+            PCVAE_SP(8) PCVAE_SP(9) PCVAE_SP(10) PCVAE_SP(11) PCVAE_SP(12) PCVAE_SP(13) PCVAE_SP(14) PCVAE_SP(15)
+#undef PCVAE_SP
+            pipe_fence();  // latch
+        }
+        for (; t < T; ++t) {   // the last slots: runtime ring offsets, fenced MFMAs
+            ScreenSeam s2 = seam_of(t);
+            s2.next_lbase = lds_of(t + 1 < T ? t + 1 : t);
+            pipe_fence();
+            if (t & 1) screen_pipe_logits<D, CT, PASS, 0, 0, 0, true, 0, true, true>(p, cand, lds_of(t), L.a0, af, xb, A2[1], A2[0], nbase + (int64_t)(t - 1) * 32, st, g, s2, wave_u, lane_off);
+            else screen_pipe_logits<D, CT, PASS, 0, 0, 0, true, 0, true, true>(p, cand, lds_of(t), L.a0, af, xb, A2[0], A2[1], nbase + (int64_t)(t - 1) * 32, st, g, s2, wave_u, lane_off);
+            pipe_fence();
+        }
+        pipe_fence();
+        lgkm_wait<0>();
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {   // drain: the look at the last subtile
+            if ((T - 1) & 1) screen_look<D, CT, PASS, false>(p, cand, A2[1], nbase + (int64_t)(T - 1) * 32, st, g, ct);
+            else screen_look<D, CT, PASS, false>(p, cand, A2[0], nbase + (int64_t)(T - 1) * 32, st, g, ct);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- tail: short / ragged chunks, staged synchronously with clamped addresses, one subtile at a time
+    for (int tt = t_beg + T; tt < t_end; tt += 4) {
+        __syncthreads();
+        fast_stage_tail<D, NW>(p.Eb, p.N, (int64_t)tt * 32, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nsub = min(4, t_end - tt);
+        for (int sb = 0; sb < nsub; ++sb) {
+            ScreenAcc<CT> a;
+            pipe_fence();
+            pipe2_cold_logits<D, CT>(lds0 + sb * G::ST, L.a0, af, xb, a.acc);
+            pipe_fence();
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) screen_look<D, CT, PASS, true>(p, cand, a, (int64_t)(tt + sb) * 32, st, g, ct);
+        }
+    }
+    if (PASS == 1) {  // rescore the parked candidates, one per thread
+        __syncthreads();
+        const unsigned int cnt = min(*reinterpret_cast<const unsigned int*>(cand + SCREEN_PIPE_CAP * 16), (unsigned)SCREEN_PIPE_CAP);
+        const uint4* list = reinterpret_cast<const uint4*>(cand);
+        for (unsigned int j = threadIdx.x; j < 8 * cnt; j += 256) {   // entry j / 8, item (j % 8) of its lane
+            const uint4 en = list[j >> 3];
+            const int64_t n = (int64_t)en.y + 16 * ((j >> 2) & 1) + (j & 3);
+            if (((en.z >> (j & 7)) & 1u) && n < p.N) screen_rescore<D>(p, (int64_t)en.x, n);
+        }
+    }
+    if (PASS == 0) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            float v = st.m[ct];
+            v = fmaxf(v, __shfl_xor(v, 16, 64));
+            v = fmaxf(v, __shfl_xor(v, 32, 64));
+            const int64_t r = rw + 16 * ct + c;
+            if (g == 0 && r < p.R) p.pm[(int64_t)split * p.R + r] = v;
+        }
+    }
+}
+
 // after pass A: thr[r] = max_j pm[j][r] - 2 eps_r ; best_key[r] = 0.  pass A may have seen only a PREFIX of the catalog:
 // any lower bound of the full approximate maximum m~ is a valid threshold base (more candidates, same answer).
 __global__ void catalog_screen_threshold_kernel(ScreenParams p, int D) {
@@ -1632,6 +1889,7 @@ __global__ void catalog_screen_threshold_kernel(ScreenParams p, int D) {
     p.thr[r] = mm - 2.f * eps - 1e-30f;
     p.eps2[r] = 2.f * eps + 1e-30f;
     p.best_key[r] = 0ull;
+    if (r == 0) *p.overflow = 0u;
 }
 
 __global__ void catalog_screen_decode_kernel(ScreenParams p, int64_t* __restrict__ idx, float* __restrict__ best) {
@@ -1693,10 +1951,33 @@ static int launch_screened(ScreenParams p, const CatalogPlan& pa, const CatalogP
         attr_set = true;
     }
     const dim3 block(512);
+    // long ranges: the software-pipelined screening kernels (one wave per SIMD, 64 rows per wave for D <= 128)
+    constexpr int CT = D == 256 ? 2 : 4;
+    using PG = PipeGeo<D, CT>;
+    constexpr int lds_pipe = PG::NB * 16384 + SCREEN_PIPE_CAP * 16 + 16;
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
+        attr_set2 = true;
+    }
+    const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
+    const int pipe_min = env_min ? atoi(env_min) : 512;
     p.N = Ns; p.nrb = pa.nrb; p.nsplit = pa.nsplit; p.tiles_per_split = pa.tiles_per_split; p.ntiles = pa.ntiles;
-    hipLaunchKernelGGL((catalog_screen_bf16_kernel<D, 0>), dim3((unsigned)(pa.nrb * pa.nsplit)), block, lds, st, p);
+    if (pa.tiles_per_split >= pipe_min)
+        hipLaunchKernelGGL((catalog_screen_pipe_kernel<D, CT, 0>), dim3((unsigned)(cdiv(p.R, PG::ROWS) * pa.nsplit)), dim3(256),
+                           lds_pipe, st, p);
+    else
+        hipLaunchKernelGGL((catalog_screen_bf16_kernel<D, 0>), dim3((unsigned)(pa.nrb * pa.nsplit)), block, lds, st, p);
     hipLaunchKernelGGL(catalog_screen_threshold_kernel, dim3((unsigned)cdiv(p.R, 256)), dim3(256), 0, st, p, D);
     p.N = N; p.nrb = pb.nrb; p.nsplit = pb.nsplit; p.tiles_per_split = pb.tiles_per_split; p.ntiles = pb.ntiles;
+    if (pb.tiles_per_split >= pipe_min) {
+        hipLaunchKernelGGL((catalog_screen_pipe_kernel<D, CT, 1>), dim3((unsigned)(cdiv(p.R, PG::ROWS) * pb.nsplit)), dim3(256),
+                           lds_pipe, st, p);
+        p.only_if_overflow = 1;   // exact redo, a no-op unless a candidate list overflowed
+    }
     hipLaunchKernelGGL((catalog_screen_bf16_kernel<D, 1>), dim3((unsigned)(pb.nrb * pb.nsplit)), block, lds, st, p);
     hipLaunchKernelGGL(catalog_screen_decode_kernel, dim3((unsigned)cdiv(p.R, 256)), dim3(256), 0, st, p, idx, best);
     return check_launch("catalog_argmax_screened");
@@ -1716,6 +1997,7 @@ int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const
     p.thr = reinterpret_cast<float*>(p.best_key + R);
     p.eps2 = p.thr + R;
     p.pm = p.eps2 + R;   // [nsplit(A) <= 64][R]
+    p.overflow = reinterpret_cast<unsigned int*>(p.pm + 64 * R);   // (pcvae_catalog_ws_bytes reserves 64 bytes behind pm)
     switch (D) {
         case 64: return launch_screened<64>(p, pa, pb, Ns, N, idx, best, st);
         case 128: return launch_screened<128>(p, pa, pb, Ns, N, idx, best, st);

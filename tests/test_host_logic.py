@@ -166,11 +166,11 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels = mod.hot_loops()
-    assert len(kernels) >= 3, "pipelined kernels not found in the generated ISA"
+    assert len(kernels) >= 9, "pipelined kernels not found in the generated ISA"   # 3 CE + 6 screening instantiations
     for name, loops in kernels.items():
         assert loops, f"{name}: no steady-state loop found"
         for loop in loops:
-            bad = [l for l in loop if l.startswith(mod.FORBIDDEN)]
+            bad = mod.forbidden_in(loop)
             assert not bad, (name, bad[:5])
 
 

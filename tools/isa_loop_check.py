@@ -15,6 +15,44 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FORBIDDEN = ("v_accvgpr_", "v_mov_b", "scratch_", "buffer_store", "v_readlane", "v_writelane")
 
 
+def _regs(tok):
+    """'v[10:13]' / 'v7' -> ('v', {10, 11, 12, 13})"""
+    tok = tok.strip()
+    m = re.match(r"([va])\[(\d+):(\d+)\]", tok)
+    if m:
+        return m.group(1), set(range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.match(r"([va])(\d+)$", tok)
+    if m:
+        return m.group(1), {int(m.group(2))}
+    return None, set()
+
+
+def forbidden_in(loop):
+    """register copies / spills hipcc placed in an unfenced loop that could read an MFMA result too early: any v_accvgpr_*,
+    any scratch access, and a v_mov whose SOURCE is a register some MFMA of the loop writes.  (A v_mov from an SGPR, a literal
+    or a VALU-produced register - the rare candidate path of the screening kernels builds its list entries that way - moves
+    no MFMA result.)"""
+    mfma_dst = {"v": set(), "a": set()}
+    for l in loop:
+        if l.startswith("v_mfma"):
+            k, r = _regs(l.split(None, 1)[1].split(",")[0])
+            if k:
+                mfma_dst[k] |= r
+    bad = []
+    for l in loop:
+        if l.startswith(("v_accvgpr_", "scratch_", "buffer_store", "v_readlane", "v_writelane")):
+            bad.append(l)
+        elif l.startswith("v_mov_b"):
+            k, r = _regs(l.split(",")[-1])
+            if k and (r & mfma_dst[k]):
+                bad.append(l)
+    return bad
+
+
+def forbidden(line):   # kept for callers that test single lines: the conservative form
+    return line.startswith(FORBIDDEN)
+
+
 def hot_loops(pattern="pipe"):
     """-> {kernel name: [loop bodies]} for every loop with >= 60 MFMAs of which at least one is NOT fenced (followed by
     `s_nop 15`): those are the loops whose correctness depends on hipcc placing no register copy / spill inside."""
@@ -54,7 +92,7 @@ def main():
         ok = ok and bool(loops)
         for loop in loops:
             c = collections.Counter(l.split()[0] for l in loop)
-            bad = [l for l in loop if l.startswith(FORBIDDEN)]
+            bad = forbidden_in(loop)
             print(f"{name[:70]}: unfenced loop of {len(loop)} instructions, {c['v_mfma_f32_16x16x32_bf16']} MFMA, {len(bad)} forbidden")
             for b in bad[:10]:
                 print("   ", b)
