@@ -11,8 +11,7 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
     size_t need = 0;
     for (int prec : {PCVAE_PREC_F32, PCVAE_PREC_BF16}) {  // one answer valid for every precision mode
         const CatalogPlan pl = catalog_plan(R, N, D, prec);
-        // bf16, D = 128: the pipelined kernel and the kernel that takes the rest of every range each write a partial
-        const size_t rows = (size_t)pl.nsplit * (size_t)R * ((prec == PCVAE_PREC_BF16 && D == 128) ? 2 : 1);
+        const size_t rows = (size_t)pl.nsplit * (size_t)R;
         const size_t ce = rows * 2 * sizeof(float) + (want_dx ? rows * (size_t)D * sizeof(float) : 0);
         const size_t am = (rows + 1) * sizeof(float) + rows * sizeof(int64_t) + 16;
         need = std::max(need, std::max(ce, am) + (size_t)pl.nrb + 64);

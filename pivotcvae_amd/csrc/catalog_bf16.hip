@@ -65,7 +65,8 @@ struct CatParamsB {
     const uint8_t* safe_flags;  // [nrb] or null: 1 = this row block needs the lazy-max kernel (large |rx|)
     int run_if_flag;        // this launch handles the row blocks whose flag equals this value
     int rem_mode;           // fast kernel only: 1 = handle what the pipelined kernel of this shape leaves over of every range
-                            // (its last tiles, see pipe_slots_of) and write the partials at split index nsplit + split
+                            // (its last tiles, see pipe_slots_of) and ADD the result into that kernel's partial (both are
+                            // max-free: pm = 0, so the partials of one range simply add up)
 };
 
 template <int D>
@@ -603,10 +604,7 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
     const int nrb = p.nrb * (ROWS_WG / G::ROWS);
     const int split = logical / nrb, rb = logical % nrb;
     if ((int64_t)rb * G::ROWS >= p.R) return;
-    // large |rx| in this row block: the lazy-max kernel handles it (in rem_mode this kernel still owes the merge kernel a
-    // neutral partial for its extra split index)
-    const bool flagged = p.safe_flags[rb / (ROWS_WG / G::ROWS)] != 0;
-    if (flagged && !p.rem_mode) return;
+    if (p.safe_flags[rb / (ROWS_WG / G::ROWS)] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
     int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
     if (p.rem_mode) {   // skip the tiles the pipelined kernel takes
@@ -616,8 +614,7 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
     const int64_t nbase = (int64_t)t_beg * 32;
     // ring chunks of this range that exist in full (no per-element bound checks in their bodies)
     int n_full = (int)min((int64_t)((t_end - t_beg) / G::SUB), (p.N - nbase) / G::BNF);
-    n_full = flagged ? 0 : max(n_full, 0);
-    const int out_split = p.rem_mode ? p.nsplit + split : split;
+    n_full = max(n_full, 0);
 
     const int64_t rw = (int64_t)rb * G::ROWS + wave * 32;  // first row of this wave
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -684,7 +681,7 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
         fast_chunk<D, 0>(smem, (cc & 3) * CB, nA, p.N, xb, U, lsum, L);
     }
     // ---- tail: short / ragged chunks (at most a few subtiles), staged synchronously with clamped addresses
-    for (int t = t_beg + G::SUB * n_full; t < t_end && !flagged; t += 4) {
+    for (int t = t_beg + G::SUB * n_full; t < t_end; t += 4) {
         __syncthreads();
         fast_stage_tail<D, G::NW>(p.E, p.N, (int64_t)t * 32, smem);
         __syncthreads();
@@ -698,13 +695,22 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
         const float l = lsum[ct][0];
         const int64_t r = rw + 16 * ct + c;
         if (r < p.R) {
-            const int64_t o = (int64_t)out_split * p.R + r;
-            // (a flagged block in rem_mode: the neutral partial - weight exp2(-inf - M) = 0 in the merge)
-            if (g == 0) { p.pm[o] = flagged ? -INFINITY : 0.f; p.pl[o] = l; }
+            const int64_t o = (int64_t)split * p.R + r;
+            if (p.rem_mode) {   // add into the partial the pipelined kernel wrote for this range (it ran before this launch)
+                if (g == 0) p.pl[o] += l;
 #pragma unroll
-            for (int dt = 0; dt < G::NDT; ++dt)  // U[dt][ct][reg] = U^T[d = 16 dt + 4 g + reg][r]
-                *reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g) =
-                    make_float4(U[dt][ct][0], U[dt][ct][1], U[dt][ct][2], U[dt][ct][3]);
+                for (int dt = 0; dt < G::NDT; ++dt) {
+                    float4* q = reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g);
+                    const float4 old = *q;
+                    *q = make_float4(old.x + U[dt][ct][0], old.y + U[dt][ct][1], old.z + U[dt][ct][2], old.w + U[dt][ct][3]);
+                }
+            } else {
+                if (g == 0) { p.pm[o] = 0.f; p.pl[o] = l; }
+#pragma unroll
+                for (int dt = 0; dt < G::NDT; ++dt)  // U[dt][ct][reg] = U^T[d = 16 dt + 4 g + reg][r]
+                    *reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g) =
+                        make_float4(U[dt][ct][0], U[dt][ct][1], U[dt][ct][2], U[dt][ct][3]);
+            }
         }
     }
 }
@@ -837,8 +843,8 @@ struct PipeGeo {
 };
 
 // D = 128 (CT = 4) splits every catalog range: the pipelined kernel takes the fill slot and the whole steady-state trips,
-// the two-waves-per-SIMD kernel takes the rest (last tiles, ragged tail) as one more partial per range for the merge
-// kernel.  That keeps the fenced paths of the pipelined kernel to a fill slot and a drain - at 256 VGPRs it has no room
+// the two-waves-per-SIMD kernel, launched right behind it, takes the rest (last tiles, ragged tail) and adds its result into
+// the same partial.  That keeps the fenced paths of the pipelined kernel to a fill slot and a drain - at 256 VGPRs it has no room
 // for remainder loops - and lets short ranges (the 8-GPU shards) use it.  Cn = full ring chunks of the range.
 template <int D, int CT>
 __host__ __device__ constexpr bool pipe_splits_range() { return D == 128 && CT == 4; }
@@ -1322,9 +1328,8 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_bf16_kernel(CatParamsB p
 
 template <int D>
 int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uint8_t* flags, float* nll, float* lse,
-                float* dx, bool split_rem, hipStream_t st) {
+                float* dx, hipStream_t st) {
     using G = GeoB<D>;
-    int merge_splits = p.nsplit;
     const size_t lds = 2 * G::CHUNK_BYTES;
     const dim3 grid((unsigned)(p.nrb * p.nsplit)), block(512);
     p.safe_flags = nullptr;
@@ -1344,8 +1349,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
             // threshold: the tests force the pipelined kernels onto small shapes with it.
             constexpr bool ALWAYS_PIPE = D == 256;
             constexpr int CT = D == 256 ? 2 : 4;
-            // (D = 128 splits every range between the two kernels: needs a second partial per range, see catalog_ce_bf16)
-            if (catalog_bf16_pipelined(D, p.tiles_per_split) && (!pipe_splits_range<D, CT>() || split_rem)) {
+            if (catalog_bf16_pipelined(D, p.tiles_per_split)) {
                 constexpr int lds_pipe = PipeGeo<D, CT>::NB * 16384;
                 static bool attr_set3 = false;
                 if (!attr_set3) {
@@ -1355,7 +1359,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
                 }
                 const dim3 g2((unsigned)(cdiv(p.R, PipeGeo<D, CT>::ROWS) * p.nsplit));
                 hipLaunchKernelGGL((catalog_ce_bf16_pipe_kernel<D, CT>), g2, dim3(256), lds_pipe, st, p);
-                if constexpr (pipe_splits_range<D, CT>()) {   // the rest of every range: one more partial per range
+                if constexpr (pipe_splits_range<D, CT>()) {   // the rest of every range, added into the same partial
                     constexpr int lds_fast = 65536;
                     static bool attr_set4 = false;
                     if (!attr_set4) {
@@ -1366,7 +1370,6 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
                     CatParamsB pr = p;
                     pr.rem_mode = 1;
                     hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), grid, block, lds_fast, st, pr);
-                    merge_splits = 2 * p.nsplit;
                 }
             } else if constexpr (!ALWAYS_PIPE) {
                 constexpr int lds_fast = 65536;  // ring of four 16 KB chunks (also holds the <= 64 KB synchronous tail image)
@@ -1404,7 +1407,6 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
 #undef PCVAE_CEB
     int rc = check_launch("catalog_ce_bf16");
     if (rc != PCVAE_OK) return rc;
-    p.nsplit = merge_splits;
     hipLaunchKernelGGL((catalog_ce_merge_bf16_kernel<D>), dim3((unsigned)cdiv(p.R, 4)), dim3(256), 0, st, p, nll, lse,
                        want_dx ? dx : nullptr);
     return check_launch("catalog_ce_merge_bf16");
@@ -1912,11 +1914,7 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
     p.rx = rx; p.E = E; p.target = target; p.keep = keep_mask;
     p.seed = seed; p.row_offset = row_offset; p.R = R; p.N = N;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
-    // D = 128 training calls on long ranges: two partials per range (pipelined kernel + the kernel that takes the rest of the
-    // range); the merge kernel gives every partial a lane, so this needs 2 * nsplit <= 64
-    const bool split_rem = D == 128 && dx && !keep_mask && !(keep_prob < 1.0f) && 2 * pl.nsplit <= 64 &&
-                           catalog_bf16_pipelined(D, pl.tiles_per_split);
-    const int64_t nsplit_ws = split_rem ? 2 * pl.nsplit : pl.nsplit;
+    const int64_t nsplit_ws = pl.nsplit;
     p.pm = reinterpret_cast<float*>(ws);
     p.pl = p.pm + nsplit_ws * R;
     p.pU = p.pl + nsplit_ws * R;
@@ -1930,9 +1928,9 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
         p.keep_thresh = th <= 0.0 ? 0u : (th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th);
     }
     switch (D) {
-        case 64: return launch_ce_b<64>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, split_rem, st);
-        case 128: return launch_ce_b<128>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, split_rem, st);
-        case 256: return launch_ce_b<256>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, split_rem, st);
+        case 64: return launch_ce_b<64>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
+        case 128: return launch_ce_b<128>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
+        case 256: return launch_ce_b<256>(p, mask_mode, dx != nullptr, e_max_norm, flags, nll, lse, dx, st);
     }
     set_error("catalog_ce(bf16): unsupported D=%d (64, 128, 256; smaller tables use the f32 kernel)", D);
     return PCVAE_EINVAL;

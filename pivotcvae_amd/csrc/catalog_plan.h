@@ -31,10 +31,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     const int64_t slots = 256 * (f32 ? 2 : 1);
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
     const int64_t nblk = (!f32 && D == 256) ? cdiv(R, 128) : p.nrb;
-    int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
-    // bf16 D = 128: the pipelined kernel and the kernel that takes the rest of every range each write a partial per range
-    // and the merge kernel gives every partial a lane of one wave: at most 32 ranges
-    if (!f32 && D == 128) cap = std::min<int64_t>(cap, 32);
+    const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
     int64_t best_cost = -1;
     for (int64_t ns = 1; ns <= cap; ++ns) {
         const int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;

@@ -231,3 +231,27 @@ def test_model_recommend_screened_ids_identical(ops, monkeypatch):
             monkeypatch.undo()
         assert items_s.dtype == torch.int64 and items_s.numel() == B * S
         assert torch.equal(items_s, items_f), name
+
+
+def test_bf16_ce_random_shapes_every_kernel_choice(ops, monkeypatch):
+    """Range bookkeeping under stress: random (R, N, D) with catalogs that are not multiples of anything, with the pipelined
+    kernels forced on (fill slot / steady trips / fenced last slots / drain / ragged tail / the D = 128 range split between
+    two kernels) and forced off, against the emulation of the kernels' arithmetic; and the two choices against each other."""
+    from pivotcvae_amd._hip import PREC_BF16
+    rng = np.random.default_rng(20261003)
+    for case in range(18):
+        D = int(rng.choice([64, 128, 256]))
+        R = int(rng.integers(1, 700))
+        N = int(rng.choice([rng.integers(1, 200), rng.integers(200, 6000), rng.integers(6000, 60000)]))
+        rx, E = rnd(R, D, seed=100 + case, scale=2.0 * (128.0 / D) ** 0.5), orc.normalize_rows(rnd(N, D, seed=200 + case))
+        tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(300 + case))
+        wn, wl, wd = emulate_fast(rx, E, tgt)
+        outs = []
+        for min_tiles in ("1", "1000000000"):
+            monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", min_tiles)
+            nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), prec=PREC_BF16)
+            msg = f"case {case}: R={R} N={N} D={D} min_tiles={min_tiles}"
+            torch.testing.assert_close(lse.cpu(), wl, rtol=3e-5, atol=5e-5, msg=lambda m: msg + "\n" + m)
+            assert (dx.cpu() - wd).abs().max() < 1e-3 * wd.abs().max() + 1e-6, msg
+            outs.append((lse, dx))
+        torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-5, atol=3e-5)
