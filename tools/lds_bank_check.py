@@ -93,8 +93,46 @@ def check16(D=128, chunk_of=lambda s, g: 4 * g + s):
     return worst_row == 1 and worst_tr == 1
 
 
+# ---- the fast / pipelined kernels' image for all three widths (fswz<D>, fchunk<D> of catalog_bf16.hip) ---------------------
+def fswz(D, row, c):
+    if D >= 128:
+        return (c & ~15) | ((c & 15) ^ (((row & 3) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1)))
+    return c ^ ((((row >> 1) & 3) << 1) | ((row >> 3) & 1))
+
+
+def fchunk(D, s, g):
+    return 2 * g + s if D == 64 else (4 * g + s if D == 128 else 16 * (s >> 2) + 4 * g + (s & 3))
+
+
+def check_fast(D):
+    """row reads: lane (c, g) reads chunk fchunk(s, g) of row nb + 16 rt + c; transposed reads: rows nb + 16 lohi + 4 g + q,
+    cols 16 dt + 4 pp; LDS-DMA: lane-linear destination, swizzle on the source."""
+    off = lambda row, col: row * 2 * D + (fswz(D, row & 15, col >> 3) << 4) + ((col & 7) << 1)
+    worst_row, worst_tr = 1, 1
+    for nb in (0, 32):
+        for rt in range(2):
+            for s in range(D // 32):
+                addr = {l: off(nb + 16 * rt + (l & 15), 8 * fchunk(D, s, l >> 4)) for l in range(64)}
+                for grp in B128_GROUPS:
+                    worst_row = max(worst_row, conflicts([addr[l] for l in grp], 16))
+        for dt in range(D // 16):
+            for lohi in range(2):
+                addr = {}
+                for l in range(64):
+                    c, g = l & 15, l >> 4
+                    addr[l] = off(nb + 16 * lohi + 4 * g + (c >> 2), 16 * dt + 4 * (c & 3))
+                for half in (range(32), range(32, 64)):
+                    worst_tr = max(worst_tr, conflicts([addr[l] for l in half], 8))
+    for row in range(16):
+        for c in range(D // 8):
+            assert fswz(D, row, fswz(D, row, c)) == c and 0 <= fswz(D, row, c) < D // 8
+    print(f"fast image, D={D}: b128 row read worst {worst_row}-way, tr_b16 read worst {worst_tr}-way, swizzle involution OK")
+    return worst_row == 1 and worst_tr == 1
+
+
 if __name__ == "__main__":
+    ok_fast = all([check_fast(D) for D in (64, 128, 256)])
     ok = all([check(D) for D in (64, 128, 256)])
     check16(128, lambda s, g: 4 * s + g)            # natural chunk order: 2-way conflicts on the row reads
     ok = check16(128, lambda s, g: 4 * g + s) and ok  # lane group g walks chunks 4g..4g+3: conflict-free
-    sys.exit(0 if ok else 1)
+    sys.exit(0 if (ok and ok_fast) else 1)
