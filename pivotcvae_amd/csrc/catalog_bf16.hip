@@ -778,6 +778,12 @@ __device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 1
 #ifndef PIPE_AD
 #define PIPE_AD 2            // logits chain: A fragments requested ahead (the first PIPE_AD are issued at the previous seam)
 #endif
+// Timing probes (tools/build_variant.sh ... -DPIPE_PROBE=<mask>; results are garbage, only the time means something): drop from the
+// steady-state slots 1: the numerator VALU ops, 2: the A-fragment reads, 4: the transposed reads, 8: the seam (wait + barrier +
+// refill), 16: the LDS waits, 32: the row-sum MFMAs, 64: only the refill of the seam
+#ifndef PIPE_PROBE
+#define PIPE_PROBE 0
+#endif
 
 template <int D, int OFF, int I>
 __device__ __forceinline__ void pipe_a_issue(const unsigned lbase, const int a0, bf16x8& a) {
@@ -837,9 +843,28 @@ struct PipeGeo {
     // chunks early, nothing is requested past the end) - tools/isa_loop_check.py is the judge.
     static constexpr bool DUMMY = !(D == 128 && CT == 4);
     static constexpr int TR = NB * G::SUB;          // slots per steady-state trip
-    static constexpr int first_op(int m) { return (m * VOPS + MPOS - 1) / MPOS; }
-    // the last exponential of a row-tile-0 pair is op 3 (2 CT - 1): it must sit behind a gradient-chain MFMA
-    static_assert(3 * (2 * CT - 1) < (MG * VOPS + MPOS - 1) / MPOS, "row tile 0 numerators must finish in their own slot");
+    // ---- where the numerator ops sit.  Vector issue is the scarce resource of a slot (an MFMA holds it for 8 of its 16 cycles,
+    // a v_exp_f32 for 8, a conversion, an LDS read or a wait for 4-5; MI355X_MICROARCH.md, issue-cost row): the gap behind every
+    // CT-th MFMA already carries the LDS reads and the wait of the next group (and the seam), so the WEIGHTED schedule leaves
+    // those gaps alone and gives every other gap at most one op, spread evenly.  Where a slot has fewer such gaps than ops
+    // (D = 64) the ops are spread uniformly by count over all gaps.  (-DPIPE_UNIFORM_OPS: the uniform spread everywhere, for A/B.)
+    static constexpr int FREE = MPOS - MPOS / CT;
+#ifdef PIPE_UNIFORM_OPS
+    static constexpr bool WEIGHTED = false;
+#else
+    static constexpr bool WEIGHTED = CT > 1 && VOPS <= FREE;
+#endif
+    static constexpr int first_op(int m) {              // ops in gap m: [first_op(m), first_op(m + 1))
+        if (!WEIGHTED) return (m * VOPS + MPOS - 1) / MPOS;
+        int n = 0;
+        for (int v = 0; v < VOPS; ++v) {
+            const int f = v * FREE / VOPS;              // op v sits in the f-th free gap; CT - 1 of them per group of CT
+            n += f + f / (CT - 1) < m;
+        }
+        return n;
+    }
+    // the last exponential of a row-tile-0 pair must sit behind a gradient-chain MFMA (its accumulators are not double-buffered)
+    static constexpr int LAST_RT0_EXP = 3 * (2 * CT - 1);
 };
 
 // D = 128 (CT = 4) splits every catalog range: the pipelined kernel takes the fill slot and the whole steady-state trips,
@@ -886,7 +911,7 @@ __device__ __forceinline__ void pipe2_ops(const f32x4 (&acc0)[CT], const PipeReg
                                           float (&e)[4 * CT][2]) {
     using PG = PipeGeo<D, CT>;
     if constexpr (M < PG::MPOS && V < PG::first_op(M + 1) && V < PG::VOPS) {
-        pipe2_op<CT, V>(acc0, src, dst, e);
+        if constexpr (!(PIPE_PROBE & 1)) pipe2_op<CT, V>(acc0, src, dst, e);
         pipe2_ops<D, CT, M, V + 1>(acc0, src, dst, e);
     }
 }
@@ -915,8 +940,8 @@ __device__ __forceinline__ void pipe2_logits(const unsigned lbase, const int a0,
                                              PipeRegs<CT>& prev, float (&e)[4 * CT][2]) {
     using PG = PipeGeo<D, CT>;
     if constexpr (I < PG::NI) {
-        if constexpr (I + PIPE_AD < PG::NI) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
-        lgkm_wait<(I + PIPE_AD < PG::NI ? PIPE_AD : PG::NI - 1 - I)>();
+        if constexpr (I + PIPE_AD < PG::NI && !(!COLD && (PIPE_PROBE & 2))) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
+        if constexpr (COLD || !(PIPE_PROBE & (2 | 16))) lgkm_wait<(I + PIPE_AD < PG::NI ? PIPE_AD : PG::NI - 1 - I)>();
         constexpr int s = I >> 1, rt = I & 1;
 #define PCVAE_L_MFMA(CTI)                                                                                  \
         if constexpr (CTI < CT) {                                                                          \
@@ -951,17 +976,22 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
                         if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
                     }
                     pipe_fence();
-                } else {
-                    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
-                    if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                } else if constexpr (!(PIPE_PROBE & 8)) {
+                    if constexpr (PIPE_PROBE & 64) asm volatile("s_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+                    if constexpr (!(PIPE_PROBE & 64))
+                        if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
                 }
             }
-            pipe_a_prologue<D, OFFL_NEXT, PIPE_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
+            if constexpr (COLD || !(PIPE_PROBE & 2))
+                pipe_a_prologue<D, OFFL_NEXT, PIPE_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
         }
         if constexpr (HAS_G) {
             constexpr int extra = (DT >= SEAM_AT && DT < SEAM_AT + PIPE_TD) ? PIPE_AD : 0;
-            if constexpr (DT + PIPE_TD < NDT) tr_issue<D, OFFG, DT + PIPE_TD>(lbase_g, t0, tl[DT + PIPE_TD], th[DT + PIPE_TD]);
-            lgkm_wait<2 * ((DT + PIPE_TD < NDT ? DT + PIPE_TD : NDT - 1) - DT) + extra>();
+            if constexpr (DT + PIPE_TD < NDT && !(!COLD && (PIPE_PROBE & 4)))
+                tr_issue<D, OFFG, DT + PIPE_TD>(lbase_g, t0, tl[DT + PIPE_TD], th[DT + PIPE_TD]);
+            if constexpr (COLD || !(PIPE_PROBE & (2 | 4 | 16)))
+                lgkm_wait<2 * ((DT + PIPE_TD < NDT ? DT + PIPE_TD : NDT - 1) - DT) + extra>();
         }
         const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
@@ -992,11 +1022,11 @@ __device__ __forceinline__ void pipe2_slot(const unsigned lbase_l, const unsigne
     pipe2_pack<CT>(prev, pb_prev);
     s16x4 tl[G::NDT], th[G::NDT];
     if constexpr (HAS_G) {
-        pipe_tr_prologue<D, OFFG, PIPE_TD>(lbase_g, L.t0, tl, th);
+        if constexpr (COLD || !(PIPE_PROBE & 4)) pipe_tr_prologue<D, OFFG, PIPE_TD>(lbase_g, L.t0, tl, th);
 #define PCVAE_ONES(CTI)                                                                                    \
         if constexpr (CTI < CT) {                                                                          \
             if constexpr (COLD) mfma_a<true>(lsum[CTI], L.ones, pb_prev[CTI]);                             \
-            else mfma_agpr_guarded(lsum[CTI], L.ones, pb_prev[CTI]);                                       \
+            else if constexpr (!(PIPE_PROBE & 32)) mfma_agpr_guarded(lsum[CTI], L.ones, pb_prev[CTI]);     \
             pipe2_ops<D, CT, CTI>(acc0, cur, cur, e);                                                      \
         }
         PCVAE_ONES(0) PCVAE_ONES(1) PCVAE_ONES(2) PCVAE_ONES(3)
@@ -1096,6 +1126,8 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
     using PG = PipeGeo<D, CT>;
     constexpr int CB = 16384, NW = 4, ROWS = PG::ROWS, SUB = G::SUB, TR = PG::TR;
     static_assert(TR % 2 == 0, "the accumulator parity must repeat every trip");
+    static_assert(PG::LAST_RT0_EXP < PG::first_op(PG::MG), "row tile 0 numerators must finish in their own slot");
+    static_assert(PG::first_op(PG::MPOS) == PG::VOPS, "every numerator op has a gap");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -57,8 +57,9 @@ def hot_loops(pattern="pipe"):
     """-> {kernel name: [loop bodies]} for every loop with >= 60 MFMAs of which at least one is NOT fenced (followed by
     `s_nop 15`): those are the loops whose correctness depends on hipcc placing no register copy / spill inside."""
     src = os.path.join(ROOT, "pivotcvae_amd", "csrc", "catalog_bf16.hip")
+    extra = os.environ.get("PCVAE_ISA_FLAGS", "").split()   # e.g. -DPIPE_OPS_MODE=0 when judging a variant
     asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
-                          src, "-o", "-"], capture_output=True, text=True, check=True).stdout
+                          *extra, src, "-o", "-"], capture_output=True, text=True, check=True).stdout
     out = {}
     for m in re.finditer(r"^(_Z\S+):\s*; @", asm, re.M):
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()

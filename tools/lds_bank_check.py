@@ -69,7 +69,7 @@ def check(D):
 
 
 
-# ---- 16x16x32 MFMA variant of the fast kernel (catalog_ce_bf16_d128_fast16_kernel) --------------------------------
+# ---- 16x16x32 MFMA layout at D = 128 with an arbitrary chunk order (shows why fchunk is not the natural order) ----
 def check16(D=128, chunk_of=lambda s, g: 4 * g + s):
     """lane l: c = l & 15, g = l >> 4.  Row reads: row nb + 16*rt + c, 16-B chunk chunk_of(s, g).  Transposed reads:
     rows nb + 16*lohi + 4*g + q, cols 16*dt + 4*pp (q = c >> 2, pp = c & 3)."""
