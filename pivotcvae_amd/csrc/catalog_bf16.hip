@@ -564,6 +564,27 @@ __device__ __forceinline__ void fast_stage(const uint16_t* __restrict__ E, int64
     }
 }
 
+// The same four pieces of a wave (NW = 4) as ONE asm statement for the steady-state seams of the pipelined kernels: scalar base
+// + 32-bit lane offset addressing, the piece stride as the instruction's immediate (it is added to both the global and the LDS
+// address), M0 written once.  hipcc's own lowering of the builtin spends a 64-bit VALU add, an M0 update and two or three SALU
+// instructions on every piece - in a seam all of that sits in ONE MFMA gap.  Invisible to hipcc's vmcnt bookkeeping: the
+// callers wait with counted vmcnt by hand (they already do).
+template <int D>
+__device__ __forceinline__ void pipe_stage(const uint16_t* __restrict__ E, int64_t n0, unsigned lds_dst, const int wave_u,
+                                           const int (&lane_off)[4]) {
+    using G = FastGeo<D>;
+    static_assert(G::RPP * G::RB == 1024, "a piece is 1 KiB of whole rows");
+    const char* base = reinterpret_cast<const char*>(E) + (n0 + (int64_t)wave_u * 4 * G::RPP) * G::RB;
+    const unsigned m0v = lds_dst + (unsigned)wave_u * 4096u;
+    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %4\n\t"
+                 "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %3, %4 offset:3072"
+                 ::"v"(lane_off[0]), "v"(lane_off[1]), "v"(lane_off[2]), "v"(lane_off[3]), "s"(base), "s"(m0v)
+                 : "memory", "m0");
+}
+
 // ragged tail: up to 128 items staged synchronously with clamped addresses (same image: row * RB, fswz)
 template <int D, int NW>
 __device__ __forceinline__ void fast_stage_tail(const uint16_t* __restrict__ E, int64_t N, int64_t n0, char* buf) {
@@ -930,6 +951,7 @@ struct Pipe2Seam {          // all wave-uniform
     bool do_seam;           // this slot ends a ring chunk: wait for the next chunk + barrier (+ request one more)
     int64_t n_stage;        // first item of the chunk to request, < 0: nothing to request
     char* stage_buf;
+    unsigned stage_lds;     // the same ring buffer as an LDS byte address (steady-state seams: pipe_stage)
     unsigned next_lbase;    // LDS address (minus the immediate) of the NEXT slot's subtile
 };
 
@@ -980,7 +1002,7 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
                     if constexpr (PIPE_PROBE & 64) asm volatile("s_barrier" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
                     if constexpr (!(PIPE_PROBE & 64))
-                        if (sm.n_stage >= 0) fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                        if (sm.n_stage >= 0) pipe_stage<D>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
                 }
             }
             if constexpr (COLD || !(PIPE_PROBE & 2))
@@ -1208,6 +1230,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
         if constexpr (PG::DUMMY) sm.n_stage = sm.do_seam ? nbase + (int64_t)min(cs, Cn - 1) * G::BNF : -1;
         else sm.n_stage = (sm.do_seam && cs < Cn) ? nbase + (int64_t)cs * G::BNF : -1;
         sm.stage_buf = smem + (cs % PG::NB) * CB;
+        sm.stage_lds = lds0 + (unsigned)((cs % PG::NB) * CB);
         sm.next_lbase = lds0;
         return sm;
     };
@@ -1232,7 +1255,8 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
                 constexpr int OG = ((TG / SUB) % PG::NB) * CB + (TG % SUB) * G::ST;                                      \
                 constexpr int ON = ((TN / SUB) % PG::NB) * CB + (TN % SUB) * G::ST;                                      \
                 constexpr bool SEAM = (TL % SUB) == SUB - 1;                                                              \
-                const Pipe2Seam s2 = seam_of(t + UU);                                                                     \
+                Pipe2Seam s2 = seam_of(t + UU);                                                                           \
+                s2.stage_lds = lds0 + (((1 + UU) / SUB + 1 + PG::PF) % PG::NB) * CB;   /* t = 1 (mod TR): a constant */      \
                 pipe2_slot<D, CT, OL, OG, ON, SEAM, true, (PG::PF - 1) * 4, false>(lds0, lds0, L, xb, af, acc0, R2[TL & 1], R2[TG & 1], U, \
                                                                         lsum, s2, wave_u, lane_off, e);                   \
             }
