@@ -778,10 +778,6 @@ __device__ __forceinline__ void mfma_a(f32x4& acc, const bf16x8& a, const bf16x8
     if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+a"(acc) : "v"(a), "v"(b));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
-// first consumer of operands hipcc may have just copied into place (a VALU result needs 2 wait states before an MFMA)
-__device__ __forceinline__ void mfma_agpr_guarded(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
 template <int N>
 __device__ __forceinline__ void lgkm_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
@@ -1048,7 +1044,7 @@ __device__ __forceinline__ void pipe2_slot(const unsigned lbase_l, const unsigne
 #define PCVAE_ONES(CTI)                                                                                    \
         if constexpr (CTI < CT) {                                                                          \
             if constexpr (COLD) mfma_a<true>(lsum[CTI], L.ones, pb_prev[CTI]);                             \
-            else if constexpr (!(PIPE_PROBE & 32)) mfma_agpr_guarded(lsum[CTI], L.ones, pb_prev[CTI]);     \
+            else if constexpr (!(PIPE_PROBE & 32)) mfma_a<false>(lsum[CTI], L.ones, pb_prev[CTI]);         \
             pipe2_ops<D, CT, CTI>(acc0, cur, cur, e);                                                      \
         }
         PCVAE_ONES(0) PCVAE_ONES(1) PCVAE_ONES(2) PCVAE_ONES(3)
@@ -1734,6 +1730,7 @@ struct ScreenSeam {          // all wave-uniform
     bool do_seam;            // this slot ends a ring chunk (runtime form, fenced slots only)
     int64_t n_stage;         // first item of the chunk to request
     char* stage_buf;
+    unsigned stage_lds;      // the same ring buffer as an LDS byte address (steady-state seams: pipe_stage)
     unsigned next_lbase;     // LDS address (minus the immediate) of the NEXT slot's subtile
 };
 
@@ -1760,7 +1757,7 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
                     pipe_fence();
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
-                    fast_stage<D, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                    pipe_stage<D>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
                 }
             }
             static_assert(PIPE_AD <= MID, "af[0 .. PIPE_AD) must be consumed before the next slot's fragments land in them");
@@ -1845,6 +1842,7 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
         const int cs = t / SUB + 1 + PF;   // beyond the last chunk: request the last one again (never read)
         sm.n_stage = nbase + (int64_t)min(cs, Cn - 1) * G::BNF;
         sm.stage_buf = smem + (cs % NB) * CB;
+        sm.stage_lds = lds0 + (unsigned)((cs % NB) * CB);
         sm.next_lbase = lds0;
         return sm;
     };
@@ -1868,7 +1866,8 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
                 constexpr int OL = ((TL / SUB) % NB) * CB + (TL % SUB) * G::ST;                                           \
                 constexpr int ON = ((TN / SUB) % NB) * CB + (TN % SUB) * G::ST;                                           \
                 constexpr bool SEAM = (TL % SUB) == SUB - 1;                                                              \
-                const ScreenSeam s2 = seam_of(t + UU);                                                                    \
+                ScreenSeam s2 = seam_of(t + UU);                                                                          \
+                s2.stage_lds = lds0 + (((1 + UU) / SUB + 1 + PF) % NB) * CB;   /* t = 1 (mod TR): a constant */              \
                 screen_pipe_logits<D, CT, PASS, OL, ON, 0, SEAM, (PF - 1) * 4, true, false>(                              \
                     p, cand, lds0, L.a0, af, xb, A2[TL & 1], A2[UU & 1], nbase + (int64_t)(t + UU - 1) * 32, st, g, s2,   \
                     wave_u, lane_off);                                                                                    \

@@ -170,7 +170,7 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
     for name, loops in kernels.items():
         assert loops, f"{name}: no steady-state loop found"
         for loop in loops:
-            bad = mod.forbidden_in(loop)
+            bad = mod.forbidden_in(loop, no_mov="catalog_ce_" in name)
             assert not bad, (name, bad[:5])
 
 
