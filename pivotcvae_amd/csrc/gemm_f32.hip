@@ -16,6 +16,7 @@
 //    input grad   dX[M,K] = dY[M,N] . W[N,K]      A k-contiguous, B row-contiguous
 //    weight grad  dW[N,K] = dY[M,N]^T . X[M,K]    A row-contiguous, B row-contiguous, split over M
 #include "common.h"
+#include <cstdint>
 
 using namespace pcvae;
 
@@ -68,6 +69,39 @@ __device__ __forceinline__ void store_tile(float* S, const float (&v)[TPT]) {
     }
 }
 
+// Interior tiles (all 64 rows and all 64 k inside the operand): 16-byte global loads, a quarter of the load instructions and of
+// the address arithmetic of the scalar form.  Register j of load i holds the element (row, k) below; row starts need only be
+// 4-byte aligned (K = 1419: ld is odd), which global_load_dwordx4 accepts.
+//   KC:  a wave-load covers 4 rows x 64 k:   row = 16 i + (t >> 4),  k = 4 (t & 15) + j
+//   !KC: a wave-load covers 4 k x 64 rows:   k = 16 i + (t >> 4),    row = 4 (t & 15) + j
+// LDS stores stay scalar into the K-major image (stride 65): bank = k + row (mod 64), distinct across the lanes of a store.
+template <bool KC>
+__device__ __forceinline__ void load_tile_v4(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t k0, float (&v)[TPT]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < TPT / 4; ++i) {
+        const int major = 16 * i + (t >> 4), minor = 4 * (t & 15);
+        const float* src = KC ? P + (row0 + major) * ld + (k0 + minor) : P + (k0 + major) * ld + (row0 + minor);
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f32x4u q = *reinterpret_cast<const f32x4u*>(src);
+        v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile_v4(float* S, const float (&v)[TPT]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < TPT / 4; ++i) {
+        const int major = 16 * i + (t >> 4), minor = 4 * (t & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (KC) S[(minor + j) * LDT + major] = v[4 * i + j];
+            else S[major * LDT + minor + j] = v[4 * i + j];
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
     __shared__ float As[BK * LDT];
@@ -93,22 +127,41 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
     const bool do_bias = (EPI == EPI_DW) && p.bias_grad != nullptr && blockIdx.x == 0 && threadIdx.x < BM;
     float bsum = 0.f;
 
+    // whole rows of both operands inside (workgroup-uniform): every k chunk but a ragged last one takes the 16-byte path
+    const bool rows_in = m0 + BM <= p.M && n0 + BN <= p.N;
     float va[TPT], vb[TPT];
-    load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, va);
-    load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, vb);
+    bool vec = rows_in && kbeg + BK <= kend;   // layout of the tile held in va / vb
+    if (vec) {
+        load_tile_v4<A_KC>(p.A, p.lda, m0, kbeg, va);
+        load_tile_v4<B_KC>(p.B, p.ldb, n0, kbeg, vb);
+    } else {
+        load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, va);
+        load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, vb);
+    }
 
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();  // previous tile fully consumed
-        store_tile<A_KC>(As, va);
-        store_tile<B_KC>(Bs, vb);
+        if (vec) {
+            store_tile_v4<A_KC>(As, va);
+            store_tile_v4<B_KC>(Bs, vb);
+        } else {
+            store_tile<A_KC>(As, va);
+            store_tile<B_KC>(Bs, vb);
+        }
         __syncthreads();
         if (do_bias) {
 #pragma unroll
             for (int k = 0; k < BK; ++k) bsum += As[k * LDT + threadIdx.x];
         }
         if (k0 + BK < kend) {  // prefetch the next tile while this one is multiplied
-            load_tile<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, kend, va);
-            load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, vb);
+            vec = rows_in && k0 + 2 * BK <= kend;
+            if (vec) {
+                load_tile_v4<A_KC>(p.A, p.lda, m0, k0 + BK, va);
+                load_tile_v4<B_KC>(p.B, p.ldb, n0, k0 + BK, vb);
+            } else {
+                load_tile<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, kend, va);
+                load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, vb);
+            }
         }
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
@@ -176,6 +229,35 @@ __device__ __forceinline__ void store_tile_s(float* S, const float (&v)[STPT]) {
     }
 }
 
+// 16-byte loads for interior tiles (see load_tile_v4):  KC: row = 16 i + (t >> 4), k = 4 (t & 15) + j;
+// !KC: k = 32 i + (t >> 3), row = 4 (t & 7) + j
+template <bool KC>
+__device__ __forceinline__ void load_tile_s_v4(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t k0, float (&v)[STPT]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < STPT / 4; ++i) {
+        const int major = KC ? 16 * i + (t >> 4) : 32 * i + (t >> 3), minor = KC ? 4 * (t & 15) : 4 * (t & 7);
+        const float* src = KC ? P + (row0 + major) * ld + (k0 + minor) : P + (k0 + major) * ld + (row0 + minor);
+        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const f32x4u q = *reinterpret_cast<const f32x4u*>(src);
+        v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile_s_v4(float* S, const float (&v)[STPT]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < STPT / 4; ++i) {
+        const int major = KC ? 16 * i + (t >> 4) : 32 * i + (t >> 3), minor = KC ? 4 * (t & 15) : 4 * (t & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (KC) S[(minor + j) * SLD + major] = v[4 * i + j];
+            else S[major * SLD + minor + j] = v[4 * i + j];
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
     static_assert(EPI == EPI_FWD || EPI == EPI_DX, "the weight-gradient GEMM is already split over workgroups");
@@ -191,17 +273,35 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
+    const bool rows_in = m0 + SM <= p.M && n0 + SM <= p.N;   // workgroup-uniform
     float va[STPT], vb[STPT];
-    load_tile_s<A_KC>(p.A, p.lda, m0, p.M, 0, p.K, va);
-    load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, 0, p.K, vb);
+    bool vec = rows_in && BK <= p.K;
+    if (vec) {
+        load_tile_s_v4<A_KC>(p.A, p.lda, m0, 0, va);
+        load_tile_s_v4<B_KC>(p.B, p.ldb, n0, 0, vb);
+    } else {
+        load_tile_s<A_KC>(p.A, p.lda, m0, p.M, 0, p.K, va);
+        load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, 0, p.K, vb);
+    }
     for (int64_t k0 = 0; k0 < p.K; k0 += BK) {
         __syncthreads();
-        store_tile_s<A_KC>(As, va);
-        store_tile_s<B_KC>(Bs, vb);
+        if (vec) {
+            store_tile_s_v4<A_KC>(As, va);
+            store_tile_s_v4<B_KC>(Bs, vb);
+        } else {
+            store_tile_s<A_KC>(As, va);
+            store_tile_s<B_KC>(Bs, vb);
+        }
         __syncthreads();
         if (k0 + BK < p.K) {
-            load_tile_s<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, p.K, va);
-            load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, p.K, vb);
+            vec = rows_in && k0 + 2 * BK <= p.K;
+            if (vec) {
+                load_tile_s_v4<A_KC>(p.A, p.lda, m0, k0 + BK, va);
+                load_tile_s_v4<B_KC>(p.B, p.ldb, n0, k0 + BK, vb);
+            } else {
+                load_tile_s<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, p.K, va);
+                load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, p.K, vb);
+            }
         }
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
@@ -281,10 +381,16 @@ extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const floa
     // C(n, kk) = sum_m dY[m, n] * X[m, kk]: both operands row-contiguous, reduction over M split
     // across blockIdx.z so that a [256 x 1419] gradient still fills the chip; partials land with
     // fp32 atomics in the (pre-zeroed, accumulating) gradient buffer.
-    const int64_t tiles = cdiv(N, BM) * cdiv(K, BN);
-    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), cdiv(M, BK)));
-    splits = std::min<int64_t>(splits, 64);
-    int64_t kps = cdiv(cdiv(M, splits), BK) * BK;
+    // The split count minimises (waves of workgroups) x (K rounds per workgroup): 512 workgroups are resident at once (two
+    // per CU at this kernel's register count), so 1104 workgroups of 11 rounds take three waves where 1012 of 12 take two.
+    const int64_t tiles = cdiv(N, BM) * cdiv(K, BN), rounds_total = cdiv(M, BK);
+    int64_t splits = 1, best = INT64_MAX;
+    for (int64_t sp = 1; sp <= std::min<int64_t>(64, rounds_total); ++sp) {
+        const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
+        const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp;              // +1: prologue / epilogue of a workgroup
+        if (cost < best) { best = cost; splits = nsp; }
+    }
+    const int64_t kps = cdiv(rounds_total, splits) * BK;
     splits = cdiv(M, kps);
     GemmParams p{dY, lddy, X, ldx, dW, lddw, N, K, M, nullptr, db, nullptr, 0, 0, kps};
     hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_DW>),
