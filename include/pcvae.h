@@ -126,6 +126,14 @@ int pcvae_kld_bwd(const float* mu, const float* lv, const float* pmu, const floa
                   const float* scale_dev, float scale_host, float* dmu, float* dlv, float* dpmu, float* dplv,
                   pcvae_stream_t stream);
 
+/* K4 + K7 backward fused (the posterior's mu / logvar get a gradient from both): WRITES
+ *   dmu = dz + s dKLD/dmu, dlv = dz eps exp(lv/2)/2 + s dKLD/dlv, dpmu = s dKLD/dpmu, dplv = s dKLD/dplv,
+ * s = dkld_host * (dkld_dev ? *dkld_dev : 1): replaces reparam_bwd + kld_bwd + their zero-fills + autograd's adds
+ * (models/cvae.py:79-83 and train_generative.py:61 under loss.backward()). */
+int pcvae_latent_bwd(const float* dz, int64_t lddz, const float* eps, const float* mu, const float* lv, const float* pmu,
+                     const float* plv, const float* dkld_dev, float dkld_host, float* dmu, float* dlv, float* dpmu,
+                     float* dplv, int64_t B, int Z, pcvae_stream_t stream);
+
 /* deterministic reduction: *out = scale * sum(x[0..n))   (CrossEntropyLoss 'mean', train_generative.py:59) */
 int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t stream);
 

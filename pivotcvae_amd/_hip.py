@@ -40,6 +40,7 @@ SIGNATURES = {
     "pcvae_reparam_bwd": [_P, _L, _P, _P, _P, _P, _L, _I, _P],
     "pcvae_kld_fwd": [_P, _P, _P, _P, _L, _P, _P],
     "pcvae_kld_bwd": [_P, _P, _P, _P, _L, _P, _F, _P, _P, _P, _P, _P],
+    "pcvae_latent_bwd": [_P, _L, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _L, _I, _P],
     "pcvae_sum": [_P, _L, _F, _P, _P],
     "pcvae_catalog_ws_bytes": [_L, _L, _I, _I],
     "pcvae_catalog_ce_variant": [_L, _L, _I, _I],

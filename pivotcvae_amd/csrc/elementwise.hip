@@ -327,6 +327,41 @@ extern "C" int pcvae_kld_bwd(const float* mu, const float* lv, const float* pmu,
     return check_launch("kld_bwd");
 }
 
+// K4 + K7 backward in one launch: the posterior's (mu, logvar) receive a gradient from the reparameterisation and from the KL
+// term; this kernel WRITES the four gradients (no zero-fill, no accumulation, no autograd add afterwards).
+//   dmu   = dz + s d / exp(plv)                 dlv  = dz eps exp(lv / 2) / 2 - s (1 - exp(lv) / exp(plv)) / 2
+//   dpmu  = -s d / exp(plv)                     dplv = -s (-1 + (exp(lv) + d^2) / exp(plv)) / 2        d = mu - pmu
+__global__ void latent_bwd_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ eps,
+                                  const float* __restrict__ mu, const float* __restrict__ lv, const float* __restrict__ pmu,
+                                  const float* __restrict__ plv, const float* __restrict__ dkld_dev, float dkld_host,
+                                  float* __restrict__ dmu, float* __restrict__ dlv, float* __restrict__ dpmu,
+                                  float* __restrict__ dplv, int64_t B, int Z) {
+    const float sc = dkld_host * (dkld_dev ? dkld_dev[0] : 1.f);
+    const int64_t n = B * Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float g = dz[(i / Z) * lddz + (i % Z)];
+        const float ip = expf(-plv[i]);
+        const float d = mu[i] - pmu[i];
+        const float ev = expf(lv[i]);
+        dmu[i] = g + sc * d * ip;
+        dlv[i] = g * eps[i] * 0.5f * expf(0.5f * lv[i]) + sc * (-0.5f) * (1.f - ev * ip);
+        dpmu[i] = sc * (-d * ip);
+        dplv[i] = sc * (-0.5f) * (-1.f + (ev + d * d) * ip);
+    }
+}
+
+extern "C" int pcvae_latent_bwd(const float* dz, int64_t lddz, const float* eps, const float* mu, const float* lv,
+                                const float* pmu, const float* plv, const float* dkld_dev, float dkld_host, float* dmu,
+                                float* dlv, float* dpmu, float* dplv, int64_t B, int Z, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(dz && eps && mu && lv && pmu && plv && dmu && dlv && dpmu && dplv && Z > 0 && lddz >= Z && B >= 0,
+                  "latent_bwd: bad arguments");
+    if (B == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(B * Z, 256), 2048);
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dz, lddz, eps, mu, lv, pmu,
+                       plv, dkld_dev, dkld_host, dmu, dlv, dpmu, dplv, B, Z);
+    return check_launch("latent_bwd");
+}
+
 __global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ x, int64_t n, float scale,
                                                    float* __restrict__ out) {
     float acc = 0.f;

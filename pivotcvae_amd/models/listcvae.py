@@ -70,7 +70,7 @@ class UserListCVAEWithPrior(BaseCVAE):
         return p, rx, z, emb, z_mu, z_logvar
 
     def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
-             eps_offset=None):
+             eps_offset=None, terms_only=False):
         """Fused counterpart of train_generative.get_gen_loss for the mask-train path: the [R, N] logits are
         never materialised.  -> (loss, recLoss, KLD)."""
         B = s.shape[0]
@@ -82,16 +82,17 @@ class UserListCVAEWithPrior(BaseCVAE):
         z_mu, z_logvar = self.encode(emb, cond, u_emb)
         if eps is None:
             off = self._next_offset(B * self.latent_size) if eps_offset is None else int(eps_offset)
-            z, self._last_eps = ops.reparam(z_mu, z_logvar, None, seed=self.rng_seed, offset=off)
+            z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, None, seed=self.rng_seed, offset=off)
         else:
-            z = self.reparametrize(z_mu, z_logvar, eps)
+            z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, eps)
         rx = self.decode(z, cond, u_emb)
         keep_prob = 1.0 if n_neg is None else float(n_neg) / N
         if keep_prob > 1.0:
             raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
         rec = ops.catalog_ce(rx.reshape(-1, self.feature_size), self.catalog_table(), s.reshape(-1), keep_prob,
                              mask_seed, row_offset * s.shape[1], keep_mask, self.catalog_precision, inv_count)
-        k = ops.kld(z_mu, z_logvar, pmu, plv)
+        if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
+            return None, rec, k
         return rec + beta * k, rec, k
 
     def recommend(self, r, u=None, return_item=False, eps=None):

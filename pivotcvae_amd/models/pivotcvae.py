@@ -121,7 +121,7 @@ class UserPivotCVAE(BaseCVAE):
         return p, rx, z, emb, z_mu, z_logvar
 
     def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
-             eps_offset=None):
+             eps_offset=None, terms_only=False):
         """Fused counterpart of train_generative.get_gen_loss (mask-train path) -> (loss, recLoss, KLD).
 
         The [B*S, N] logits never exist: the full-catalog softmax CE (with the reference's downsample
@@ -139,11 +139,12 @@ class UserPivotCVAE(BaseCVAE):
         u_emb = self._user_rows(u, B)
         pmu, plv = self._prior_from(cond, u_emb)
         z_mu, z_logvar = self.encode(emb, cond, u_emb)
+        # reparametrize + KLD as one autograd node (their backward is one kernel); values as ops.reparam / ops.kld
         if eps is None:  # in-kernel Philox; a data-parallel caller pins the stream position explicitly
             off = self._next_offset(B * self.latent_size) if eps_offset is None else int(eps_offset)
-            z, self._last_eps = ops.reparam(z_mu, z_logvar, None, seed=self.rng_seed, offset=off)
+            z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, None, seed=self.rng_seed, offset=off)
         else:
-            z = self.reparametrize(z_mu, z_logvar, eps)
+            z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, eps)
         true_pivot = s[:, 0].contiguous()
         if self.TRAIN_RULE == "gt":
             self.last_pivot = true_pivot
@@ -156,7 +157,8 @@ class UserPivotCVAE(BaseCVAE):
             raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
         rec = ops.catalog_ce(rx.reshape(-1, self.feature_size), self.catalog_table(), s.reshape(-1), keep_prob,
                              mask_seed, row_offset * S, keep_mask, self.catalog_precision, inv_count)
-        k = ops.kld(z_mu, z_logvar, pmu, plv)
+        if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
+            return None, rec, k
         return rec + beta * k, rec, k
 
     def recommend(self, r, u=None, return_item=False, random_pivot=False, eps=None):

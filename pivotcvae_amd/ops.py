@@ -316,6 +316,50 @@ def kld(mu, logvar, pmu, plogvar):
     return _KLD.apply(mu, logvar, pmu, plogvar)
 
 
+class _Latent(torch.autograd.Function):
+    """reparam() and kld() of one posterior as ONE autograd node: the posterior's (mu, logvar) feed both, so separate nodes
+    cost two backward kernels, six zero-fills and two gradient adds per step; here the backward is one kernel that writes
+    all four gradients (pcvae_latent_bwd).  Forward values are those of reparam() / kld() (same kernels)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, pmu, plogvar, eps, seed, offset):
+        require_device(mu, logvar, pmu, plogvar)
+        mu, logvar, pmu, plogvar = (_c2d(t).contiguous() for t in (mu, logvar, pmu, plogvar))
+        B, Z = mu.shape
+        z = torch.empty(B, Z, dtype=F32, device=mu.device)
+        eps_used = torch.empty(B, Z, dtype=F32, device=mu.device)
+        if eps is not None:
+            eps = eps.to(F32).contiguous()
+        check(lib().pcvae_reparam_fwd(ptr(mu, F32), ptr(logvar, F32), ptr(eps, F32) if eps is not None else None,
+                                      seed, offset, ptr(z, F32), Z, ptr(eps_used, F32), B, Z, stream()), "reparam_fwd")
+        k = torch.empty((), dtype=F32, device=mu.device)
+        check(lib().pcvae_kld_fwd(ptr(mu, F32), ptr(logvar, F32), ptr(pmu, F32), ptr(plogvar, F32), mu.numel(), ptr(k, F32),
+                                  stream()), "kld_fwd")
+        ctx.save_for_backward(eps_used, mu, logvar, pmu, plogvar)
+        ctx.mark_non_differentiable(eps_used)
+        ctx.set_materialize_grads(False)   # an unused output arrives as None, not as a zero-filled tensor (a launch)
+        return z, eps_used, k
+
+    @staticmethod
+    def backward(ctx, gz, _geps, gk):
+        eps, mu, lv, pmu, plv = ctx.saved_tensors
+        B, Z = eps.shape
+        if gz is None:
+            gz = torch.zeros_like(eps)
+        gz = _c2d(gz)
+        outs = [torch.empty_like(eps) for _ in range(4)]
+        gk_ptr, gk_host = (ptr(gk.contiguous(), F32), 1.0) if gk is not None else (None, 0.0)
+        check(lib().pcvae_latent_bwd(ptr(gz, F32), _ld(gz), ptr(eps, F32), ptr(mu, F32), ptr(lv, F32), ptr(pmu, F32),
+                                     ptr(plv, F32), gk_ptr, gk_host, *(ptr(o, F32) for o in outs), B, Z, stream()),
+              "latent_bwd")
+        return outs[0], outs[1], outs[2], outs[3], None, None, None
+
+
+def latent(mu, logvar, pmu, plogvar, eps=None, seed=0, offset=0):
+    """-> (z, eps_used, kld): reparam(mu, logvar, eps, seed, offset) and kld(mu, logvar, pmu, plogvar) with a fused backward."""
+    return _Latent.apply(mu, logvar, pmu, plogvar, eps, int(seed), int(offset))
+
+
 # -------------------------------------------------------------------------------------- K5 / K6
 class CatalogTable:
     """The frozen item table E[N, D] plus (lazily) its bf16 hi / lo copies for the MFMA bf16 modes."""

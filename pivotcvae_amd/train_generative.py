@@ -95,7 +95,9 @@ class Trainer:
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
         self.rank = self.dist.get_rank(process_group) if self.dist else 0
         self.opt = optimizer if optimizer is not None else FlatAdam(model, lr)
+        self._own_loss = loss_fn is None
         self.loss_fn = loss_fn or (lambda m, s, r, u, **kw: m.loss(s, r, u, **kw))
+        self._seed = None   # (1, beta) as device scalars: backward is seeded with them instead of forming rec + beta * KLD first
         self.global_step = 0
         # hipGraph capture of zero-grad + forward + backward (the ~90 small launches of a step become one graph
         # launch; matters when a rank only holds B/8 slates).  eps is drawn OUTSIDE the graph into a static buffer
@@ -118,9 +120,21 @@ class Trainer:
         """zero-grad + local loss + backward (this rank's shard)."""
         B, S = s.shape
         self.opt.zero_grad()
-        loss, rec, kld = self.loss_fn(self.model, s, r, u, beta=self.beta, n_neg=self.n_neg, eps=eps,
-                                      row_offset=row_offset, inv_count=1.0 / (B * S * self.world),
-                                      eps_offset=eps_offset, mask_seed=self.global_step)
+        kw = dict(beta=self.beta, n_neg=self.n_neg, eps=eps, row_offset=row_offset, inv_count=1.0 / (B * S * self.world),
+                  eps_offset=eps_offset, mask_seed=self.global_step)
+        if self._own_loss:
+            # d(rec + beta KLD) = 1 d rec + beta d KLD: seeding backward with the two constants saves the mul / add / fill / mul
+            # launches of forming the sum and differentiating it (the logged loss is formed in step(), one launch)
+            if self._seed is None:
+                self._seed = (torch.ones((), dtype=torch.float32, device=s.device),
+                              torch.full((), float(self.beta), dtype=torch.float32, device=s.device), float(self.beta))
+            elif self._seed[2] != float(self.beta):   # beta changed (annealing): in place, a captured graph keeps the address
+                self._seed[1].fill_(float(self.beta))
+                self._seed = (self._seed[0], self._seed[1], float(self.beta))
+            _, rec, kld = self.model.loss(s, r, u, terms_only=True, **kw)
+            torch.autograd.backward([rec, kld], [self._seed[0], self._seed[1]])
+            return None, rec.detach(), kld.detach()
+        loss, rec, kld = self.loss_fn(self.model, s, r, u, **kw)
         loss.backward()
         return loss.detach(), rec.detach(), kld.detach()
 
@@ -175,9 +189,11 @@ class Trainer:
             loss, rec, kld = self._local(s, r, u, eps, row_offset, eps_offset)
         if self.dist is not None:  # also with a 1-rank group: the collective path is then the one that is exercised
             self.dist.all_reduce(self.opt.grad, group=self.pg)  # SUM: one collective per step
-            stats = torch.stack([loss, rec, kld])
+            stats = torch.stack([rec, kld] if loss is None else [loss, rec, kld])
             self.dist.all_reduce(stats, group=self.pg)
-            loss, rec, kld = stats[0], stats[1], stats[2]
+            loss, rec, kld = (None, stats[0], stats[1]) if loss is None else (stats[0], stats[1], stats[2])
+        if loss is None:
+            loss = torch.add(rec, kld, alpha=float(self.beta))
         self.opt.step()
         self.global_step += 1
         return loss, rec, kld

@@ -184,6 +184,39 @@ def test_kld_forward_backward(ops):
         torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-5, atol=1e-6)
 
 
+def test_latent_is_reparam_plus_kld_with_one_backward(ops):
+    """ops.latent (one autograd node, fused backward kernel) against the oracle's reparametrize + KLD under autograd, with both
+    outputs used the way the loss uses them (z through a linear map, beta * KLD added)."""
+    B, Z = 300, 16
+    ts = [rnd(B, Z, seed=i) for i in range(4)]
+    eps = torch.randn(B, Z, generator=torch.Generator().manual_seed(9))
+    w = rnd(B, Z, seed=7)
+    ref = [t.clone().requires_grad_(True) for t in ts]
+    zr = orc.reparametrize(ref[0], ref[1], eps)
+    kr = orc.kld(*ref)
+    ((zr * w).sum() + 0.37 * kr).backward()
+    dv = [t.to(DEV).requires_grad_(True) for t in ts]
+    z, used, k = ops.latent(*dv, eps.to(DEV))
+    ((z * w.to(DEV)).sum() + 0.37 * k).backward()
+    torch.testing.assert_close(z.cpu(), zr.detach(), rtol=1e-6, atol=1e-6)
+    assert torch.equal(used.cpu(), eps)
+    np.testing.assert_allclose(k.item(), kr.item(), rtol=2e-6)
+    for a, b in zip(dv, ref):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-5, atol=1e-6)
+    # only the KL term used (z dropped): the reparameterisation contributes nothing
+    dv2 = [t.to(DEV).requires_grad_(True) for t in ts]
+    _, _, k2 = ops.latent(*dv2, eps.to(DEV))
+    (0.37 * k2).backward()
+    ref2 = [t.clone().requires_grad_(True) for t in ts]
+    (0.37 * orc.kld(*ref2)).backward()
+    for a, b in zip(dv2, ref2):
+        torch.testing.assert_close(a.grad.cpu(), b.grad, rtol=1e-5, atol=1e-6)
+    # Philox path: the same stream as ops.reparam
+    z3, e3, _ = ops.latent(*[t.to(DEV) for t in ts], None, seed=5, offset=32)
+    z4, e4 = ops.reparam(ts[0].to(DEV), ts[1].to(DEV), None, seed=5, offset=32)
+    assert torch.equal(e3, e4) and torch.equal(z3, z4)
+
+
 # --------------------------------------------------------------------------------------------- K8
 def test_adam_matches_oracle(ops):
     n = 5000
