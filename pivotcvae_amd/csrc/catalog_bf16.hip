@@ -64,9 +64,11 @@ struct CatParamsB {
     float* pU;              // [nsplit][R][D]
     const uint8_t* safe_flags;  // [nrb] or null: 1 = this row block needs the lazy-max kernel (large |rx|)
     int run_if_flag;        // this launch handles the row blocks whose flag equals this value
-    int rem_mode;           // fast kernel only: 1 = handle what the pipelined kernel of this shape leaves over of every range
-                            // (its last tiles, see pipe_slots_of) and ADD the result into that kernel's partial (both are
-                            // max-free: pm = 0, so the partials of one range simply add up)
+    int rem_mode;           // fast kernel only: G > 0 = handle what the pipelined kernel of this shape leaves over of every range
+                            // (its last tiles, see pipe_slots_of) and ADD the result into that kernel's partials (both are
+                            // max-free: pm = 0, so partials simply add up).  The grid is then nrb x G: a workgroup walks the
+                            // ranges g, g + G, ... of its row block and adds the sum into the partial of range g - the
+                            // leftovers are a few tiles per range, far less than a workgroup's fixed cost
 };
 
 template <int D>
@@ -623,27 +625,35 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     // p.nrb counts 256-row blocks (the lazy-max kernel's, and the flags'); this kernel's blocks are G::ROWS rows
     const int nrb = p.nrb * (ROWS_WG / G::ROWS);
-    const int split = logical / nrb, rb = logical % nrb;
+    const int split0 = logical / nrb, rb = logical % nrb;
     if ((int64_t)rb * G::ROWS >= p.R) return;
     if (p.safe_flags[rb / (ROWS_WG / G::ROWS)] != 0) return;  // large |rx| in this row block: the lazy-max kernel handles it
-    int t_beg = split * p.tiles_per_split;
-    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
-    if (p.rem_mode) {   // skip the tiles the pipelined kernel takes
-        const int Cn = max((int)min((int64_t)((t_end - t_beg) / G::SUB), (p.N - (int64_t)t_beg * 32) / G::BNF), 0);
-        t_beg += pipe_slots_of<D, 4>(Cn);
-    }
-    const int64_t nbase = (int64_t)t_beg * 32;
-    // ring chunks of this range that exist in full (no per-element bound checks in their bodies)
-    int n_full = (int)min((int64_t)((t_end - t_beg) / G::SUB), (p.N - nbase) / G::BNF);
-    n_full = max(n_full, 0);
+    const int split_step = p.rem_mode ? p.rem_mode : p.nsplit;    // normal launches: one range per workgroup
+    int t_beg, t_end, n_full;   // the current range: tiles [t_beg, t_end), n_full ring chunks that exist in full
+    int64_t nbase;
+    auto set_range = [&](int split) {
+        t_beg = split * p.tiles_per_split;
+        t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+        if (p.rem_mode) {   // skip the tiles the pipelined kernel takes
+            const int Cn = max((int)min((int64_t)((t_end - t_beg) / G::SUB), (p.N - (int64_t)t_beg * 32) / G::BNF), 0);
+            t_beg += pipe_slots_of<D, 4>(Cn);
+        }
+        nbase = (int64_t)t_beg * 32;
+        // (no per-element bound checks in the bodies of full chunks)
+        n_full = max((int)min((int64_t)((t_end - t_beg) / G::SUB), (p.N - nbase) / G::BNF), 0);
+    };
+    set_range(split0);
 
     const int64_t rw = (int64_t)rb * G::ROWS + wave * 32;  // first row of this wave
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int lane_off[G::PPW];
     fast_lane_off<D, G::NW>(lane, wave, lane_off);
+    auto stage_prologue = [&]() {
 #pragma unroll
-    for (int c0 = 0; c0 < 3; ++c0)  // prologue: chunks 0..2 in flight
-        if (c0 < n_full) fast_stage<D, G::NW>(p.E, nbase + (int64_t)c0 * G::BNF, smem + c0 * CB, wave_u, lane_off);
+        for (int c0 = 0; c0 < 3; ++c0)  // chunks 0..2 in flight
+            if (c0 < n_full) fast_stage<D, G::NW>(p.E, nbase + (int64_t)c0 * G::BNF, smem + c0 * CB, wave_u, lane_off);
+    };
+    stage_prologue();
 
     // B operand of the logits chain: column tile ct, k-step s: rx[row 16 ct + c][8 fchunk(s, g) .. + 7] * log2 e
     bf16x8 xb[2][G::KS];
@@ -676,6 +686,7 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
         for (int i = 0; i < 4; ++i) lsum[ct][i] = 0.f;
     const FastLane L = fast_lane<D>(lane);
 
+    for (int split = split0;;) {
     int cc = 0;
     const int n_pipe = n_full >= 3 ? n_full - 2 : 0;   // chunks consumed with two younger chunks in flight
     for (; cc + 4 <= n_pipe; cc += 4) {
@@ -710,13 +721,19 @@ __global__ void __launch_bounds__(FastGeo<D>::NW * 64, 1) catalog_ce_bf16_fast_k
         for (int st = 0; st < nsub; ++st)
             fast_subtile<D, true, 0>(smem, st * G::ST, (int64_t)(t + st) * 32, p.N, xb, U, lsum, L);
     }
+    split += split_step;
+    if (split >= p.nsplit) break;
+    __syncthreads();          // rest-of-range launches: the next range of this row block reuses the ring (all loads have landed)
+    set_range(split);
+    stage_prologue();
+    }
 
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
         const float l = lsum[ct][0];
         const int64_t r = rw + 16 * ct + c;
         if (r < p.R) {
-            const int64_t o = (int64_t)split * p.R + r;
+            const int64_t o = (int64_t)split0 * p.R + r;
             if (p.rem_mode) {   // add into the partial the pipelined kernel wrote for this range (it ran before this launch)
                 if (g == 0) p.pl[o] += l;
 #pragma unroll
@@ -1420,8 +1437,9 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
                         attr_set4 = true;
                     }
                     CatParamsB pr = p;
-                    pr.rem_mode = 1;
-                    hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), grid, block, lds_fast, st, pr);
+                    const int64_t nblk = (int64_t)grid.x / p.nsplit;   // row blocks of this kernel
+                    pr.rem_mode = (int)std::max<int64_t>(1, std::min<int64_t>(p.nsplit, 256 / std::max<int64_t>(nblk, 1)));
+                    hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), dim3((unsigned)(nblk * pr.rem_mode)), block, lds_fast, st, pr);
                 }
             } else if constexpr (!ALWAYS_PIPE) {
                 constexpr int lds_fast = 65536;  // ring of four 16 KB chunks (also holds the <= 64 KB synchronous tail image)
