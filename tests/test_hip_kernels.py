@@ -120,6 +120,22 @@ def test_mlp_forward_backward(ops, M, K, N, last_linear):
         torch.testing.assert_close(b.grad.cpu(), rb.grad, rtol=1e-3, atol=10 * tol)
 
 
+def test_linear_large_shapes_take_the_64x64_kernel_and_its_16_byte_loads(ops):
+    """>= 256 output tiles of 64 x 64: gemm_f32_kernel with 16-byte loads on interior tiles; K = 283 makes every row start
+    4-byte but not 16-byte aligned and leaves a ragged last k chunk; M and N leave ragged edge tiles (scalar path)."""
+    M, K, N = 2100, 283, 650
+    x, W, b, g = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3), rnd(M, N, seed=4)
+    xd, Wd, bd, gd = x.to(DEV), W.to(DEV), b.to(DEV), g.to(DEV)
+    y = ops.linear_fwd_raw(xd, Wd, bd, 0)
+    torch.testing.assert_close(y.cpu(), (x.double() @ W.double().t() + b.double()).float(), rtol=1e-4, atol=1e-4)
+    dx = ops.linear_bwd_input_raw(gd, Wd)
+    torch.testing.assert_close(dx.cpu(), (g.double() @ W.double()).float(), rtol=1e-4, atol=2e-4)
+    dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    ops.linear_bwd_weight_raw(gd, xd, dW, db)
+    torch.testing.assert_close(dW.cpu(), (g.double().t() @ x.double()).float(), rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(db.cpu(), g.double().sum(0).float(), rtol=1e-4, atol=5e-4)
+
+
 def test_linear_on_column_windows(ops):
     """inputs / outputs may be column windows of wider buffers (ld > width)."""
     big = rnd(33, 50, seed=1).to(DEV)
