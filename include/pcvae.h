@@ -67,6 +67,11 @@ int pcvae_condition(const float* r, int64_t B, int ncols, int S, float* out, int
 /* strided 2-D copy (the torch.cat of models/pivotcvae.py:167,203,213,236 becomes column windows) */
 int pcvae_copy2d(const float* src, int64_t src_ld, float* dst, int64_t dst_ld, int64_t rows, int cols,
                  pcvae_stream_t stream);
+/* torch.cat(parts, 1) of up to four column blocks in one launch (models/pivotcvae.py:167,205,232: the inputs of the
+ * encoder / prior / slate-completion stacks).  Part i is [rows, c_i] with leading dimension ld_i; unused trailing parts: c_i = 0. */
+int pcvae_concat(const float* s0, int64_t ld0, int c0, const float* s1, int64_t ld1, int c1, const float* s2, int64_t ld2,
+                 int c2, const float* s3, int64_t ld3, int c3, float* dst, int64_t dst_ld, int64_t rows,
+                 pcvae_stream_t stream);
 
 /* out[r, c] = x[r, c] * scale_host * (scale_dev ? *scale_dev : 1)   (chain rule through 'mean') */
 int pcvae_scale_rows(const float* x, int64_t ldx, float* out, int64_t ldo, int64_t rows, int cols,

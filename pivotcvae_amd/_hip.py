@@ -27,6 +27,7 @@ SIGNATURES = {
     "pcvae_gather_rows": [_P, _L, _I, _P, _L, _I, _P, _L, _P],
     "pcvae_condition": [_P, _L, _I, _I, _P, _L, _P],
     "pcvae_copy2d": [_P, _L, _P, _L, _L, _I, _P],
+    "pcvae_concat": [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _L, _P],
     "pcvae_scale_rows": [_P, _L, _P, _L, _L, _I, _P, _F, _P],
     "pcvae_normalize_rows": [_P, _L, _L, _I, _P],
     "pcvae_click_stats": [_P, _L, _I, _P, _P, _P],

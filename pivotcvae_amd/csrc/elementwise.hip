@@ -142,6 +142,43 @@ extern "C" int pcvae_copy2d(const float* src, int64_t src_ld, float* dst, int64_
     return check_launch("copy2d");
 }
 
+// torch.cat(parts, 1) of up to four column blocks in ONE launch (a concat of k parts was k copy2d launches; at B/8 slates
+// per rank every launch is ~4.6 us of floor).  Part i is [rows, cols[i]] with leading dimension ld[i]; unused parts: cols = 0.
+struct ConcatParams {
+    const float* src[4];
+    int64_t ld[4];
+    int cols[4];
+};
+
+__global__ void concat_kernel(ConcatParams p, float* __restrict__ dst, int64_t dst_ld, int64_t rows, int total) {
+    const int64_t n = rows * total;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / total;
+        int c = (int)(i % total);
+        const int c_out = c;
+        int part = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (part == k && c >= p.cols[k]) { c -= p.cols[k]; part = k + 1; }
+        dst[r * dst_ld + c_out] = p.src[part][r * p.ld[part] + c];
+    }
+}
+
+extern "C" int pcvae_concat(const float* s0, int64_t ld0, int c0, const float* s1, int64_t ld1, int c1, const float* s2,
+                            int64_t ld2, int c2, const float* s3, int64_t ld3, int c3, float* dst, int64_t dst_ld,
+                            int64_t rows, pcvae_stream_t stream) {
+    const int total = c0 + c1 + c2 + c3;
+    PCVAE_REQUIRE(dst && c0 > 0 && c1 >= 0 && c2 >= 0 && c3 >= 0 && dst_ld >= total, "concat: bad arguments");
+    PCVAE_REQUIRE(s0 && ld0 >= c0 && (c1 == 0 || (s1 && ld1 >= c1)) && (c2 == 0 || (s2 && ld2 >= c2)) &&
+                  (c3 == 0 || (s3 && ld3 >= c3)), "concat: bad part");
+    PCVAE_REQUIRE((c2 == 0 || c1 > 0) && (c3 == 0 || c2 > 0), "concat: parts must be packed from the front");
+    if (rows == 0) return PCVAE_OK;
+    ConcatParams p{{s0, s1 ? s1 : s0, s2 ? s2 : s0, s3 ? s3 : s0}, {ld0, ld1, ld2, ld3}, {c0, c1, c2, c3}};
+    const int64_t blocks = std::min<int64_t>(cdiv(rows * total, 256), 4096);
+    hipLaunchKernelGGL(concat_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), p, dst, dst_ld, rows, total);
+    return check_launch("concat");
+}
+
 __global__ void scale_rows_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t ldo,
                                   int64_t rows, int cols, const float* __restrict__ scale_dev, float scale_host) {
     const float sc = scale_host * (scale_dev ? scale_dev[0] : 1.f);

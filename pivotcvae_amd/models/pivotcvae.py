@@ -145,13 +145,13 @@ class UserPivotCVAE(BaseCVAE):
             z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, None, seed=self.rng_seed, offset=off)
         else:
             z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, eps)
-        true_pivot = s[:, 0].contiguous()
         if self.TRAIN_RULE == "gt":
-            self.last_pivot = true_pivot
-            pivot_emb = ops.gather_rows(self.docEmbed.weight, true_pivot)
+            self.last_pivot = s[:, 0]
+            # the ground-truth pivot's row is the first D columns of the slate's gathered rows: no second gather
+            pivot_emb = emb[:, : self.feature_size]
             rx = self._complete(z, cond, u_emb, pivot_emb)
         else:
-            rx = self.decode(z, cond, u_emb=u_emb, true_pivot=true_pivot)
+            rx = self.decode(z, cond, u_emb=u_emb, true_pivot=s[:, 0].contiguous())
         keep_prob = 1.0 if n_neg is None else float(n_neg) / N
         if keep_prob > 1.0:
             raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")

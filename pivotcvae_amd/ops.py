@@ -83,8 +83,14 @@ class _Concat(torch.autograd.Function):
         widths = [p.shape[1] for p in parts]
         out = torch.empty(B, sum(widths), dtype=F32, device=parts[0].device)
         c = 0
-        for p, w in zip(parts, widths):
-            copy2d(p, out[:, c:c + w])
+        for i in range(0, len(parts), 4):   # up to four parts per launch
+            grp = [_c2d(p) for p in parts[i:i + 4]]
+            args = []
+            for k in range(4):
+                args += [ptr(grp[k], F32), _ld(grp[k]), grp[k].shape[1]] if k < len(grp) else [None, 0, 0]
+            w = sum(g.shape[1] for g in grp)
+            dst = out[:, c:c + w]
+            check(lib().pcvae_concat(*args, ptr(dst, F32), _ld(dst), B, stream()), "concat")
             c += w
         ctx.widths = widths
         return out

@@ -82,6 +82,13 @@ def test_concat_and_backward(ops):
     w = rnd(9, 26, seed=4)
     (out * w.to(DEV)).sum().backward()
     assert torch.equal(ad.grad.cpu(), w[:, :4])
+    # five parts (two launches of the four-part kernel), one of them a column window of a wider buffer
+    parts = [rnd(33, wd, seed=10 + i) for i, wd in enumerate((3, 1, 17, 8, 5))]
+    wide = rnd(33, 40, seed=20)
+    dev_parts = [q.to(DEV) for q in parts]
+    dev_parts[2] = wide.to(DEV)[:, 7:24]
+    parts[2] = wide[:, 7:24]
+    assert torch.equal(ops.concat(dev_parts).cpu(), torch.cat(parts, 1))
 
 
 # --------------------------------------------------------------------------------------------- K3
