@@ -570,7 +570,9 @@ __device__ __forceinline__ void fast_stage(const uint16_t* __restrict__ E, int64
 // + 32-bit lane offset addressing, the piece stride as the instruction's immediate (it is added to both the global and the LDS
 // address), M0 written once.  hipcc's own lowering of the builtin spends a 64-bit VALU add, an M0 update and two or three SALU
 // instructions on every piece - in a seam all of that sits in ONE MFMA gap.  Invisible to hipcc's vmcnt bookkeeping: the
-// callers wait with counted vmcnt by hand (they already do).
+// callers wait with counted vmcnt by hand (they already do).  (hipcc warns that m0 on a clobber list is a reserved register: it
+// never keeps a value in M0 across statements - its own LDS-DMA lowering rewrites M0 in front of every use - and the clobber
+// stays so that this is stated, not assumed.)
 template <int D>
 __device__ __forceinline__ void pipe_stage(const uint16_t* __restrict__ E, int64_t n0, unsigned lds_dst, const int wave_u,
                                            const int (&lane_off)[4]) {
@@ -1459,7 +1461,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
     do {                                                                                                         \
         static bool attr_set = false;                                                                            \
         if (!attr_set) {                                                                                         \
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_kernel<D, MASKV, DXV>),          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_kernel<D, MASKV, DXV>),          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
             attr_set = true;                                                                                     \
         }                                                                                                        \
