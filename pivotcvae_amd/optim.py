@@ -13,6 +13,8 @@ from . import ops
 
 
 class FlatAdam:
+    TAIL = 4
+
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         # weight_decay: torch.optim.Adam's L2 term (pretrain_env.py:59); train_generative.py:103 passes none
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
@@ -22,7 +24,11 @@ class FlatAdam:
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        # the gradient buffer carries a short tail behind the parameters' gradients: a data-parallel trainer puts the step's
+        # logged scalars there, so that ONE all-reduce per step moves gradients and statistics (Adam never sees the tail)
+        self.grad_ext = torch.zeros(total + self.TAIL, dtype=torch.float32, device=dev)
+        self.grad = self.grad_ext[:total]
+        self.tail = self.grad_ext[total:]
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
@@ -35,7 +41,7 @@ class FlatAdam:
         self.t = 0
 
     def zero_grad(self):
-        self.grad.zero_()
+        self.grad_ext.zero_()
         for p, g in zip(self.params, self._grad_views()):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g  # someone set it to None / replaced it: re-attach the flat view

@@ -188,9 +188,17 @@ class Trainer:
         else:
             loss, rec, kld = self._local(s, r, u, eps, row_offset, eps_offset)
         if self.dist is not None:  # also with a 1-rank group: the collective path is then the one that is exercised
-            self.dist.all_reduce(self.opt.grad, group=self.pg)  # SUM: one collective per step
-            stats = torch.stack([rec, kld] if loss is None else [loss, rec, kld])
-            self.dist.all_reduce(stats, group=self.pg)
+            terms = [rec, kld] if loss is None else [loss, rec, kld]
+            tail = getattr(self.opt, "tail", None)
+            if tail is not None and tail.numel() >= len(terms):
+                # ONE collective per step: the logged scalars ride in the tail of the flat gradient buffer
+                torch.stack(terms, out=tail[:len(terms)])
+                self.dist.all_reduce(self.opt.grad_ext, group=self.pg)  # SUM
+                stats = tail[:len(terms)].clone()   # the tail is zeroed with the gradients at the next step
+            else:   # an optimiser without the tail: gradients, then the scalars
+                self.dist.all_reduce(self.opt.grad, group=self.pg)
+                stats = torch.stack(terms)
+                self.dist.all_reduce(stats, group=self.pg)
             loss, rec, kld = (None, stats[0], stats[1]) if loss is None else (stats[0], stats[1], stats[2])
         if loss is None:
             loss = torch.add(rec, kld, alpha=float(self.beta))
