@@ -1711,7 +1711,39 @@ template <int CT>
 struct ScreenState {        // per lane: rows 16 ct + c of the wave
     float m[CT], thr[CT], eps2[CT];
     int64_t row[CT];
+    uint64_t mk[CT];     // steady-state slots of pass B: lanes of column tile ct that saw a logit over their threshold (SGPR pair)
 };
+
+// Largest of a lane's eight logits as ONE asm statement (three v_max3_f32 + one more): fmaxf() on values that come out of asm
+// MFMAs costs a canonicalising v_max x, x per input (11 VALU ops instead of 4), and hipcc puts an s_nop 0 in front of every asm
+// statement that reads the result of another one (its hazard recogniser does not count asm as wait states) - one statement,
+// one nop.  Vector issue, not the MFMA pipe, is what bounds a screening slot.
+__device__ __forceinline__ float vmax8(const f32x4& lo, const f32x4& hi) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8"
+        : "=&v"(r)
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+    return r;
+}
+__device__ __forceinline__ void vmax8_into(float& m, const f32x4& lo, const f32x4& hi) {   // m = max(m, the eight)
+    float t;
+    asm("v_max3_f32 %1, %2, %3, %4\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max3_f32 %1, %1, %7, %8\n\tv_max3_f32 %0, %0, %1, %9"
+        : "+v"(m), "=&v"(t)
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+}
+
+// Pass B, steady state: the eight-way maximum AND the threshold test in one statement, the outcome as a wave mask in SGPRs.
+// The four masks of a slot are OR-ed and tested ONCE at the end of the slot (one scalar branch per slot instead of four
+// exec-mask branches); a slot that has a candidate anywhere then runs screen_look() per column tile.
+__device__ __forceinline__ uint64_t screen_peek(const f32x4& lo, const f32x4& hi, const float thr) {
+    float t;
+    uint64_t mask;
+    asm("v_max3_f32 %1, %2, %3, %4\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max3_f32 %1, %1, %7, %8\n\tv_max_f32 %1, %1, %9\n\t"
+        "v_cmp_ge_f32 %0, %1, %10"
+        : "=s"(mask), "=&v"(t)
+        : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(thr));
+    return mask;
+}
 
 template <int D, int CT, int PASS, bool CHECK_N>
 __device__ __forceinline__ void screen_look(const ScreenParams& p, char* cand, ScreenAcc<CT>& a, const int64_t n0,
@@ -1723,11 +1755,10 @@ __device__ __forceinline__ void screen_look(const ScreenParams& p, char* cand, S
             for (int i = 0; i < 4; ++i)
                 if (n0 + 16 * rt + 4 * g + i >= p.N) a.acc[rt][ct][i] = -INFINITY;
     }
-    float v = fmaxf(fmaxf(a.acc[0][ct][0], a.acc[0][ct][1]), fmaxf(a.acc[0][ct][2], a.acc[0][ct][3]));
-    v = fmaxf(v, fmaxf(fmaxf(a.acc[1][ct][0], a.acc[1][ct][1]), fmaxf(a.acc[1][ct][2], a.acc[1][ct][3])));
+    float v = 0.f;
     if (PASS == 0) {
-        st.m[ct] = fmaxf(st.m[ct], v);
-    } else if (v >= st.thr[ct]) {
+        vmax8_into(st.m[ct], a.acc[0][ct], a.acc[1][ct]);
+    } else if ((v = vmax8(a.acc[0][ct], a.acc[1][ct])) >= st.thr[ct]) {
         // park the lane's eight items (n0 + 16 rt + 4 g + i) as ONE entry with a bit per item that passed (branch-free to
         // build); the final phase rescores the marked items exactly.  A full list raises the overflow flag: the (slow, exact)
         // two-waves kernel then redoes pass B.
@@ -1797,10 +1828,19 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
         if constexpr (HAS_PREV && (I + 1) % (NI / CT) == 0) {
             constexpr int ct = (I + 1) / (NI / CT) - 1;
             asm volatile("" : "+v"(prev.acc[0][ct]), "+v"(prev.acc[1][ct]));   // not before this point of the chain
-            screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);
+            if constexpr (PASS == 1 && !COLD) st.mk[ct] = screen_peek(prev.acc[0][ct], prev.acc[1][ct], st.thr[ct]);
+            else screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);
         }
         screen_pipe_logits<D, CT, PASS, OFF, OFFN, I + 1, SEAM, VM, HAS_PREV, COLD>(p, cand, lbase, a0, af, xb, cur, prev,
                                                                                   n_prev, st, g, sm, wave_u, lane_off);
+    } else if constexpr (HAS_PREV && PASS == 1 && !COLD) {
+        uint64_t any = st.mk[0];
+#pragma unroll
+        for (int ct = 1; ct < CT; ++ct) any |= st.mk[ct];
+        if (any != 0) {   // rare: some lane of the wave has a candidate in the previous subtile
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);
+        }
     }
 }
 
