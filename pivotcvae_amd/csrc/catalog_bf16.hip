@@ -1839,7 +1839,8 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
         for (int ct = 1; ct < CT; ++ct) any |= st.mk[ct];
         if (any != 0) {   // rare: some lane of the wave has a candidate in the previous subtile
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);
+            for (int ct = 0; ct < CT; ++ct)
+                if (st.mk[ct] != 0) screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);   // scalar test again
         }
     }
 }
