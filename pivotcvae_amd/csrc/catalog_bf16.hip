@@ -1712,6 +1712,7 @@ struct ScreenState {        // per lane: rows 16 ct + c of the wave
     float m[CT], thr[CT], eps2[CT];
     int64_t row[CT];
     uint64_t mk[CT];     // steady-state slots of pass B: lanes of column tile ct that saw a logit over their threshold (SGPR pair)
+    unsigned int cnt;    // pass B: entries this WAVE has parked in its own quarter of the candidate list (wave-uniform)
 };
 
 // Largest of a lane's eight logits as ONE asm statement (three v_max3_f32 + one more): fmaxf() on values that come out of asm
@@ -1755,24 +1756,34 @@ __device__ __forceinline__ void screen_look(const ScreenParams& p, char* cand, S
             for (int i = 0; i < 4; ++i)
                 if (n0 + 16 * rt + 4 * g + i >= p.N) a.acc[rt][ct][i] = -INFINITY;
     }
-    float v = 0.f;
     if (PASS == 0) {
         vmax8_into(st.m[ct], a.acc[0][ct], a.acc[1][ct]);
-    } else if ((v = vmax8(a.acc[0][ct], a.acc[1][ct])) >= st.thr[ct]) {
-        // park the lane's eight items (n0 + 16 rt + 4 g + i) as ONE entry with a bit per item that passed (branch-free to
-        // build); the final phase rescores the marked items exactly.  A full list raises the overflow flag: the (slow, exact)
-        // two-waves kernel then redoes pass B.
-        unsigned int* cnt = reinterpret_cast<unsigned int*>(cand + SCREEN_PIPE_CAP * 16);
-        uint4* list = reinterpret_cast<uint4*>(cand);
-        unsigned int mask = 0;
+    } else {
+        // Every caller reaches this point with all 64 lanes active.  A lane whose best logit passes its threshold parks its
+        // eight items (n0 + 16 rt + 4 g + i) as ONE entry with a bit per item that passed; the final phase rescores the marked
+        // items exactly.  Each wave owns a quarter of the list and counts its entries in a register: an entry costs a ballot,
+        // an mbcnt and one ds_write - no LDS atomic, no wait that would also drain the A fragments in flight.  A full quarter
+        // raises the overflow flag: the (slow, exact) two-waves kernel then redoes pass B.
+        const float v = vmax8(a.acc[0][ct], a.acc[1][ct]);
+        const bool hit = v >= st.thr[ct];
+        const uint64_t act = __ballot(hit);
+        if (act != 0) {
+            if (hit) {
+                const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u));
+                const unsigned int slot = st.cnt + rank;
+                unsigned int mask = 0;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+                for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mask |= (a.acc[rt][ct][i] >= st.thr[ct] ? 1u : 0u) << (4 * rt + i);
-        const unsigned int slot = atomicAdd(cnt, 1u);
-        if (slot < (unsigned)SCREEN_PIPE_CAP) list[slot] = make_uint4((unsigned int)st.row[ct], (unsigned int)(n0 + 4 * g), mask, 0u);
-        else *p.overflow = 1u;
-        st.thr[ct] = fmaxf(st.thr[ct], v - st.eps2[ct]);
+                    for (int i = 0; i < 4; ++i) mask |= (a.acc[rt][ct][i] >= st.thr[ct] ? 1u : 0u) << (4 * rt + i);
+                uint4* list = reinterpret_cast<uint4*>(cand) + (threadIdx.x >> 6) * (SCREEN_PIPE_CAP / 4);
+                if (slot < (unsigned)(SCREEN_PIPE_CAP / 4)) list[slot] = make_uint4((unsigned int)st.row[ct], (unsigned int)(n0 + 4 * g), mask, 0u);
+                else *p.overflow = 1u;
+                // everything this lane meets later only matters if it comes within 2 eps of what it has already seen
+                st.thr[ct] = fmaxf(st.thr[ct], v - st.eps2[ct]);
+            }
+            st.cnt += (unsigned int)__popcll(act);
+        }
     }
 }
 
@@ -1864,10 +1875,6 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
     Cn = max(Cn, 0);
     const int T = Cn * SUB;
     const int64_t rw = (int64_t)rb * ROWS + wave * 16 * CT;
-    if (PASS == 1) {
-        if (threadIdx.x == 0) *reinterpret_cast<unsigned int*>(cand + SCREEN_PIPE_CAP * 16) = 0u;
-        __syncthreads();
-    }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int lane_off[4];
     fast_lane_off<D, NW>(lane, wave, lane_off);
@@ -1876,6 +1883,7 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
 
     bf16x8 xb[CT][G::KS];
     ScreenState<CT> st;
+    st.cnt = 0u;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int64_t r = rw + 16 * ct + c;
@@ -1971,14 +1979,18 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
             for (int ct = 0; ct < CT; ++ct) screen_look<D, CT, PASS, true>(p, cand, a, (int64_t)(tt + sb) * 32, st, g, ct);
         }
     }
-    if (PASS == 1) {  // rescore the parked candidates, one per thread
+    if (PASS == 1) {  // rescore the parked candidates of the four waves' lists, one item per thread
+        unsigned int* counts = reinterpret_cast<unsigned int*>(cand + SCREEN_PIPE_CAP * 16);
+        if (lane == 0) counts[wave] = min(st.cnt, (unsigned)(SCREEN_PIPE_CAP / 4));
         __syncthreads();
-        const unsigned int cnt = min(*reinterpret_cast<const unsigned int*>(cand + SCREEN_PIPE_CAP * 16), (unsigned)SCREEN_PIPE_CAP);
-        const uint4* list = reinterpret_cast<const uint4*>(cand);
-        for (unsigned int j = threadIdx.x; j < 8 * cnt; j += 256) {   // entry j / 8, item (j % 8) of its lane
-            const uint4 en = list[j >> 3];
-            const int64_t n = (int64_t)en.y + 16 * ((j >> 2) & 1) + (j & 3);
-            if (((en.z >> (j & 7)) & 1u) && n < p.N) screen_rescore<D>(p, (int64_t)en.x, n);
+        for (int w = 0; w < 4; ++w) {
+            const unsigned int cnt = counts[w];
+            const uint4* list = reinterpret_cast<const uint4*>(cand) + w * (SCREEN_PIPE_CAP / 4);
+            for (unsigned int j = threadIdx.x; j < 8 * cnt; j += 256) {   // entry j / 8, item (j % 8) of its lane
+                const uint4 en = list[j >> 3];
+                const int64_t n = (int64_t)en.y + 16 * ((j >> 2) & 1) + (j & 3);
+                if (((en.z >> (j & 7)) & 1u) && n < p.N) screen_rescore<D>(p, (int64_t)en.x, n);
+            }
         }
     }
     if (PASS == 0) {
