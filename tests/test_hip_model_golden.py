@@ -174,6 +174,38 @@ def test_graph_captured_step_equals_eager_step():
         close(outs[1][1][k], outs[0][1][k], rtol=1e-4, atol=2e-6)
 
 
+def test_trainer_with_a_one_rank_rccl_group_equals_the_plain_trainer():
+    """The data-parallel path of Trainer.step on the GPU (one all-reduce over the flat gradient buffer, whose tail carries the
+    logged ELBO terms) with a 1-rank RCCL group: bitwise the same parameters and statistics as the trainer without a group."""
+    import socket
+    import torch.distributed as dist
+    from pivotcvae_amd.train_generative import Trainer
+    g = load("pivotcvae_gt_pi_s10")
+    s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
+
+    def run():
+        m = build_from_golden(g)
+        m.rng_seed = 77
+        tr = Trainer(m, lr=1e-3, beta=g.meta["beta"])
+        stats = [[float(x) for x in tr.step(s, r, u)] for _ in range(3)]
+        return tr, stats, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    _, plain_stats, plain_sd = run()
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        tr, dp_stats, dp_sd = run()
+        assert tr.dist is not None and tr.world == 1
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_allclose(dp_stats, plain_stats, rtol=2e-5)   # weight-gradient GEMMs use fp32 atomics
+    for k in plain_sd:
+        close(dp_sd[k], plain_sd[k], rtol=1e-4, atol=2e-6)
+
+
 def test_g7_response_model_and_click_stats():
     """UserResponseModel_MLP.forward against the golden logits of the reference; sigmoid-sum statistics."""
     from pivotcvae_amd import ops
