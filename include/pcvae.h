@@ -98,6 +98,10 @@ int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, c
 int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
                            int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
                            pcvae_stream_t stream);
+/* dX = (dX + dY . W) * LeakyReLU'(Xact): the second of two Linear layers fed by the same activated input (the mu / logvar
+ * heads, models/pivotcvae.py:214-220,236-239): their input gradients are summed and masked in the GEMM epilogue. */
+int pcvae_linear_bwd_input_acc(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact, int64_t ldxa,
+                               float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K, pcvae_stream_t stream);
 int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
                             float* db, int64_t M, int64_t N, int64_t K, pcvae_stream_t stream);
 /* in place: g *= (y > 0 ? 1 : 0.01)  - LeakyReLU backward keyed on the activated output */

@@ -34,6 +34,7 @@ SIGNATURES = {
     "pcvae_philox_randint": [_P, _L, _L, _U64, _U64, _P],
     "pcvae_linear_fwd": [_P, _L, _P, _L, _P, _P, _L, _L, _L, _L, _I, _P],
     "pcvae_linear_bwd_input": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P],
+    "pcvae_linear_bwd_input_acc": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P],
     "pcvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _P],
     "pcvae_leaky_bwd": [_P, _L, _P, _L, _L, _I, _P],
     "pcvae_reparam_fwd": [_P, _P, _P, _U64, _U64, _P, _L, _P, _L, _I, _P],

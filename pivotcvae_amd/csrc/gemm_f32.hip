@@ -38,6 +38,7 @@ struct GemmParams {
     const float* aux; int64_t ldaux;  // EPI_DX: activated input [M,N] or null
     int act;
     int64_t k_per_split;           // EPI_DW: reduction range per blockIdx.z
+    int accumulate;                // EPI_DX: C = (C + A.B) * act'(aux) - the second of two layers that share an input
 };
 
 // Load a 64 x 64 (rows x k) tile of a logical operand P(row, k) into 16 registers per thread; a wave reads 64
@@ -188,6 +189,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
             else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
             p.C[m * p.ldc + n] = v;
         } else if (EPI == EPI_DX) {
+            if (p.accumulate) v += p.C[m * p.ldc + n];
             if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
             p.C[m * p.ldc + n] = v;
         } else {
@@ -324,6 +326,7 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
             if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
             else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
         } else {
+            if (p.accumulate) v += p.C[m * p.ldc + n];
             if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
         }
         p.C[m * p.ldc + n] = v;
@@ -343,7 +346,7 @@ extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int
     PCVAE_REQUIRE(act == PCVAE_ACT_NONE || act == PCVAE_ACT_LEAKY || act == PCVAE_ACT_RELU, "linear_fwd: unknown activation %d", act);
     if (M == 0) return PCVAE_OK;
     PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_fwd: M too large");
-    GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, nullptr, 0, act, 0};
+    GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, nullptr, 0, act, 0, 0};
     if (use_small_tiles(M, N))
         hipLaunchKernelGGL((gemm_f32_small_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, SM), (unsigned)cdiv(M, SM)),
                            dim3(256), 0, as_stream(stream), p);
@@ -353,16 +356,15 @@ extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int
     return check_launch("linear_fwd");
 }
 
-extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
-                                      int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
-                                      pcvae_stream_t stream) {
+static int linear_bwd_input_impl(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact, int64_t ldxa,
+                                 float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K, int accumulate, pcvae_stream_t stream) {
     PCVAE_REQUIRE(dY && W && dX, "linear_bwd_input: null pointer");
     PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K && (!Xact || ldxa >= K),
                   "linear_bwd_input: bad shape");
     if (M == 0) return PCVAE_OK;
     PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_bwd_input: M too large");
     // C(m, kk) = sum_n dY[m, n] * W[n, kk]:  A = dY (reduction index contiguous), B(kk, n) = W[n * ldw + kk]
-    GemmParams p{dY, lddy, W, ldw, dX, lddx, M, K, N, nullptr, nullptr, Xact, ldxa, 0, 0};
+    GemmParams p{dY, lddy, W, ldw, dX, lddx, M, K, N, nullptr, nullptr, Xact, ldxa, 0, 0, accumulate};
     if (use_small_tiles(M, K))
         hipLaunchKernelGGL((gemm_f32_small_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, SM), (unsigned)cdiv(M, SM)),
                            dim3(256), 0, as_stream(stream), p);
@@ -370,6 +372,20 @@ extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float
         hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(M, BM)),
                            dim3(256), 0, as_stream(stream), p);
     return check_launch("linear_bwd_input");
+}
+
+extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
+                                      int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
+                                      pcvae_stream_t stream) {
+    return linear_bwd_input_impl(dY, lddy, W, ldw, Xact, ldxa, dX, lddx, M, N, K, 0, stream);
+}
+
+// dX = (dX + dY . W) * LeakyReLU'(Xact): the second of two layers fed by the same activated input (the mu / logvar heads of
+// the encoder and of the prior) - replaces a GEMM into a temporary, autograd's add, a copy and a separate LeakyReLU' kernel
+extern "C" int pcvae_linear_bwd_input_acc(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
+                                          int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
+                                          pcvae_stream_t stream) {
+    return linear_bwd_input_impl(dY, lddy, W, ldw, Xact, ldxa, dX, lddx, M, N, K, 1, stream);
 }
 
 extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
@@ -392,7 +408,7 @@ extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const floa
     }
     const int64_t kps = cdiv(rounds_total, splits) * BK;
     splits = cdiv(M, kps);
-    GemmParams p{dY, lddy, X, ldx, dW, lddw, N, K, M, nullptr, db, nullptr, 0, 0, kps};
+    GemmParams p{dY, lddy, X, ldx, dW, lddw, N, K, M, nullptr, db, nullptr, 0, 0, kps, 0};
     hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_DW>),
                        dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(N, BM), (unsigned)splits), dim3(256), 0,
                        as_stream(stream), p);

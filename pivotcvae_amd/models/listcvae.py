@@ -39,8 +39,7 @@ class UserListCVAEWithPrior(BaseCVAE):
 
     def encode(self, emb, c, u_emb=None):
         x = ops.concat([emb, c] if self.noUser else [emb, c, u_emb])
-        h = ops.mlp(x, self._mlp_layers("enc", self._n_enc), last_linear=False)
-        return ops.mlp(h, self._head("encmu"), True), ops.mlp(h, self._head("enclogvar"), True)
+        return ops.mlp_heads(x, self._mlp_layers("enc", self._n_enc), self._head("encmu")[0], self._head("enclogvar")[0])
 
     def decode(self, z, c, u_emb=None):
         x = ops.concat([z, c] if self.noUser else [z, c, u_emb])
@@ -48,8 +47,7 @@ class UserListCVAEWithPrior(BaseCVAE):
 
     def _prior_from(self, cond, u_emb):
         x = cond if self.noUser else ops.concat([cond, u_emb])
-        h = ops.mlp(x, self._mlp_layers("prior", self._n_prior), last_linear=False)
-        return ops.mlp(h, self._head("priorMu"), True), ops.mlp(h, self._head("priorLogvar"), True)
+        return ops.mlp_heads(x, self._mlp_layers("prior", self._n_prior), self._head("priorMu")[0], self._head("priorLogvar")[0])
 
     def get_prior(self, r, u=None):
         return self._prior_from(self.get_condition(r), self._user_rows(u, r.shape[0]))

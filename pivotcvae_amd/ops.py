@@ -226,6 +226,90 @@ class _MLP(torch.autograd.Function):
         return (g, None) + tuple(grads)
 
 
+def linear_bwd_input_acc_raw(gy, W, xact, out):
+    """out = (out + gy @ W) * LeakyReLU'(xact)   (xact may be None: no mask)."""
+    gy = _c2d(gy)
+    M, N = gy.shape
+    K = W.shape[1]
+    _timed_gemm(2.0 * M * N * K, lambda: check(
+        lib().pcvae_linear_bwd_input_acc(ptr(gy, F32), _ld(gy), ptr(W, F32), _ld(W),
+                                         ptr(xact, F32) if xact is not None else None,
+                                         _ld(xact) if xact is not None else 0, ptr(out, F32), _ld(out), M, N, K,
+                                         stream()), "linear_bwd_input_acc"))
+    return out
+
+
+class _MLPHeads(torch.autograd.Function):
+    """A LeakyReLU trunk followed by TWO linear heads on its output (encoder -> mu / logvar, prior -> mu / logvar;
+    models/pivotcvae.py:205-220,232-239) as one autograd node.  As separate nodes the two heads hand autograd two input
+    gradients to add, and the trunk then copies the sum and masks it with LeakyReLU' - three launches that the second head's
+    input-gradient GEMM absorbs here (pcvae_linear_bwd_input_acc: accumulate + mask in the epilogue)."""
+
+    @staticmethod
+    def forward(ctx, x, n_trunk, *params):
+        require_device(x, *params)
+        x = _c2d(x)
+        acts = [x]
+        h = x
+        for i in range(n_trunk):
+            h = linear_fwd_raw(h, params[2 * i], params[2 * i + 1], ACT_LEAKY)
+            acts.append(h)
+        Wa, ba, Wb, bb = params[2 * n_trunk:2 * n_trunk + 4]
+        ya = linear_fwd_raw(h, Wa, ba, ACT_NONE)
+        yb = linear_fwd_raw(h, Wb, bb, ACT_NONE)
+        ctx.n = n_trunk
+        ctx.direct = [p.grad if (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_cuda
+                                 and p.grad.shape == p.shape and p.grad.is_contiguous()) else None for p in params]
+        ctx.save_for_backward(*acts, *params)
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, params = saved[: n + 1], saved[n + 1:]
+        grads = [None] * len(params)
+        h = acts[n]
+
+        def weight_grad(k, g, a):   # parameter pair k (weight 2k, bias 2k + 1) from output gradient g and layer input a
+            if not (ctx.needs_input_grad[2 + 2 * k] or ctx.needs_input_grad[3 + 2 * k]):
+                return
+            dW, db = ctx.direct[2 * k], ctx.direct[2 * k + 1]
+            if dW is not None and db is not None:
+                linear_bwd_weight_raw(g, a, dW, db)   # accumulated in place: nothing to hand to autograd
+            else:
+                dW, db = torch.zeros_like(params[2 * k]), torch.zeros_like(params[2 * k + 1])
+                linear_bwd_weight_raw(g, a, dW, db)
+                grads[2 * k], grads[2 * k + 1] = dW, db
+
+        ga, gb = _c2d(ga), _c2d(gb)
+        weight_grad(n, ga, h)
+        weight_grad(n + 1, gb, h)
+        if n == 0 and not ctx.needs_input_grad[0]:
+            return (None, None) + tuple(grads)
+        # d h = ga Wa + gb Wb, masked with the trunk's top LeakyReLU' in the second GEMM's epilogue
+        g = linear_bwd_input_raw(ga, params[2 * n], xact=None)
+        g = linear_bwd_input_acc_raw(gb, params[2 * n + 2], h if n > 0 else None, g)
+        for i in range(n - 1, -1, -1):
+            weight_grad(i, g, acts[i])
+            if i > 0:
+                g = linear_bwd_input_raw(g, params[2 * i], xact=acts[i])
+            elif ctx.needs_input_grad[0]:
+                g = linear_bwd_input_raw(g, params[0], xact=None)
+            else:
+                g = None
+        return (g, None) + tuple(grads)
+
+
+def mlp_heads(x, trunk, head_a, head_b):
+    """trunk: list of (weight, bias) with LeakyReLU after every layer; head_a / head_b: (weight, bias), linear.
+    -> (head_a(trunk(x)), head_b(trunk(x)))"""
+    flat = []
+    for W, b in list(trunk) + [head_a, head_b]:
+        flat += [W, b]
+    return _MLPHeads.apply(x, len(trunk), *flat)
+
+
 def mlp(x, layers, last_linear):
     """layers: list of (weight [out,in], bias [out])."""
     flat = []

@@ -127,6 +127,37 @@ def test_mlp_forward_backward(ops, M, K, N, last_linear):
         torch.testing.assert_close(b.grad.cpu(), rb.grad, rtol=1e-3, atol=10 * tol)
 
 
+@pytest.mark.parametrize("M,K,H,Z,n_trunk,x_grad", [(300, 139, 48, 16, 2, False), (1100, 70, 256, 16, 1, True), (37, 20, 8, 3, 0, True)])
+def test_trunk_with_two_heads_is_one_node(ops, M, K, H, Z, n_trunk, x_grad):
+    """ops.mlp_heads (trunk + two linear heads, the heads' input gradients summed and masked in a GEMM epilogue) against
+    torch autograd on the CPU, values and every gradient."""
+    x = rnd(M, K, seed=1)
+    dims = [K] + [H] * n_trunk
+    trunk = [(rnd(dims[i + 1], dims[i], seed=10 + i, scale=0.3), rnd(dims[i + 1], seed=20 + i)) for i in range(n_trunk)]
+    heads = [(rnd(Z, dims[-1], seed=30 + j, scale=0.3), rnd(Z, seed=40 + j)) for j in range(2)]
+    ga, gb = rnd(M, Z, seed=50), rnd(M, Z, seed=51)
+
+    xr = x.clone().requires_grad_(x_grad)
+    pr = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in trunk + heads]
+    h = xr
+    for w, b in pr[:n_trunk]:
+        h = torch.nn.functional.leaky_relu(h @ w.t() + b, 0.01)
+    ya, yb = h @ pr[n_trunk][0].t() + pr[n_trunk][1], h @ pr[n_trunk + 1][0].t() + pr[n_trunk + 1][1]
+    ((ya * ga).sum() + (yb * gb).sum()).backward()
+
+    xd = x.to(DEV).requires_grad_(x_grad)
+    pd = [(w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)) for w, b in trunk + heads]
+    da, db = ops.mlp_heads(xd, pd[:n_trunk], pd[n_trunk], pd[n_trunk + 1])
+    ((da * ga.to(DEV)).sum() + (db * gb.to(DEV)).sum()).backward()
+    torch.testing.assert_close(da.cpu(), ya.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), yb.detach(), rtol=1e-4, atol=1e-4)
+    for (wd, bd), (wr, br) in zip(pd, pr):
+        torch.testing.assert_close(wd.grad.cpu(), wr.grad, rtol=1e-4, atol=2e-4)
+        torch.testing.assert_close(bd.grad.cpu(), br.grad, rtol=1e-4, atol=2e-4)
+    if x_grad:
+        torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=2e-4)
+
+
 def test_linear_large_shapes_take_the_64x64_kernel_and_its_16_byte_loads(ops):
     """>= 256 output tiles of 64 x 64: gemm_f32_kernel with 16-byte loads on interior tiles; K = 283 makes every row start
     4-byte but not 16-byte aligned and leaves a ragged last k chunk; M and N leave ragged edge tiles (scalar path)."""
