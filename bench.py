@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: PivotCVAE train step (fwd + bwd + Adam [+ gradient all-reduce]) on synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched as one rank per GPU by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+environment), or started plainly - then this process spawns `python -m torch.distributed.run --nproc-per-node N`
+on itself BEFORE it touches the GPU, passes the ranks' output through and exits with their code.
 
 Metric (BASELINE.json): slates/sec (+ the ELBO terms) at catalog N=1M, slate K=10, emb D=128, global batch
 B=8192, variant pivotcvae_gt_pi, full-catalog softmax (n_neg = N), Z=16, hidden 256/256, prior 128/128.
@@ -77,7 +81,7 @@ def kernel_name(R, N, D, dtype):
     from pivotcvae_amd import _hip
     v = _hip.lib().pcvae_catalog_ce_variant(R, N, D, _hip.PREC_NAMES[dtype])
     return {0: f"catalog_ce_f32_kernel<{D}>", 1: f"catalog_ce_bf16_fast_kernel<{D}>",
-            2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>"}.get(v, "?")
+            2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>", 3: f"catalog_ce_x3_pipe_kernel<{D}, 2>"}.get(v, "?")
 
 
 def gather_roofline(model, cfg, device, tables=4):
@@ -109,13 +113,13 @@ def gather_roofline(model, cfg, device, tables=4):
             if it >= 3:
                 ts.append(e0.elapsed_time(e1) / k)
         ms[mode] = sum(ts) / len(ts)
-    t = ms["back_to_back"]
-    return {"kernel": "gather_rows_vec4_kernel", "bound": "hbm", "achieved": nbytes / (t * 1e-3) / 1e9, "peak": 8000.0,
-            "unit": "GB/s", "frac": nbytes / (t * 1e-3) / 8e12, "bytes_per_launch": nbytes, "us_per_launch": t * 1e3,
-            "rows": n_idx, "timed_over": f"{tables} back-to-back launches on {tables} distinct cold tables between one event pair",
-            "single_launch": {"us_per_launch": ms["single"] * 1e3, "achieved": nbytes / (ms["single"] * 1e-3) / 1e9,
-                              "frac": nbytes / (ms["single"] * 1e-3) / 8e12,
-                              "note": "one launch per event pair: includes the pair's own ~2.4 us"},
+    t1, tb = ms["single"], ms["back_to_back"]
+    # headline = ONE launch between one event pair (it carries the pair's own ~2.4 us on a ~20 us kernel: a lower bound)
+    return {"kernel": "gather_rows_vec4_kernel", "bound": "hbm", "achieved": nbytes / (t1 * 1e-3) / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "frac": nbytes / (t1 * 1e-3) / 8e12, "bytes_per_launch": nbytes, "us_per_launch": t1 * 1e3,
+            "rows": n_idx, "timed_over": "one launch per HIP event pair (includes the pair's own ~2.4 us)",
+            "back_to_back": {"us_per_launch": tb * 1e3, "achieved": nbytes / (tb * 1e-3) / 1e9, "frac": nbytes / (tb * 1e-3) / 8e12,
+                             "note": f"{tables} launches on {tables} distinct cold tables between one event pair"},
             "cache": "cold (512 MB written before every measurement)"}
 
 
@@ -218,6 +222,16 @@ def generate_throughput(model, cfg, device, iters=3):
             "f32_kernel": res["f32"], "ids_identical_to_f32_kernel": bool(torch.equal(ids["screened"], ids["f32"]))}
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline_and_parity(model, st, cfg, dtype):
     """Oracle train step on the host cores on a bounded sample + HIP-vs-oracle ELBO on that same sample."""
     from oracle import pivotcvae_oracle as orc
@@ -254,7 +268,8 @@ def cpu_baseline_and_parity(model, st, cfg, dtype):
     with torch.no_grad():
         hl, hrec, hkld = model.loss(s, r, u, BETA, eps=eps.to(dev))
     rel = lambda a, b: abs(a - b) / max(abs(b), 1e-30)
-    base = {"value": Bs / dt, "unit": "slates/s", "cores": torch.get_num_threads(), "kind": "port",
+    base = {"value": Bs / dt, "unit": "slates/s", "cores": torch.get_num_threads(), "host_cores": ncpu,
+            "cpu_model": cpu_model(), "kind": "port",
             "sample": f"oracle/pivotcvae_oracle.py train step (dense [{Bs * cfg['S']},{cfg['N']}] logits + CE + KL + "
                       f"backward + Adam), B={Bs} slates of the same workload, {steps} steps, {dt:.2f} s/step"}
     parity = {"loss_rel_err": rel(hl.item(), ol), "recLoss_rel_err": rel(hrec.item(), orec),
@@ -264,34 +279,175 @@ def cpu_baseline_and_parity(model, st, cfg, dtype):
     return base, parity
 
 
+def self_launch(n, argv):
+    """--gpus N > 1 without a launcher: start one rank per GPU through torch.distributed.run and pass their output through.
+    Runs BEFORE anything in this process touches the GPU (importing torch and counting devices do not); the ranks are
+    child processes, this process only waits for them and exits with their code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = subprocess.call(cmd, env=env)
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
+def dry_run(args, world, rank):
+    """PCVAE_BENCH_DRYRUN=1: the launch / rendezvous / reduce-and-print skeleton on gloo without any GPU work (CPU test of the
+    N > 1 path: tests/test_bench_launch.py)."""
+    import torch.distributed as dist
+    B = args.global_batch or CONFIGS[args.config]["B"]
+    if B % world:
+        raise SystemExit("global batch not divisible by the number of GPUs")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or os.environ.get("PCVAE_BENCH_FORCE_DIST") == "1":
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ranks = dist.get_world_size()
+        dist.destroy_process_group()
+    else:
+        t, ranks = torch.tensor([1.0]), 1
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": ranks, "steps": args.steps, "warmup": args.warmup,
+                          "max_over_ranks": t.item(), "config": {"global_batch": B, "per_gpu_batch": B // world}}), flush=True)
+
+
+class StepTimer:
+    """the contract's timed region: W untimed steps, then exactly K steps between barrier + synchronize on both sides, MAX over
+    ranks; HIP events on the launch stream around the dominant kernel inside those steps"""
+
+    def __init__(self, trainer, batch, B, lo, use_dist, device):
+        self.tr, self.batch, self.B, self.lo, self.use_dist, self.device = trainer, batch, B, lo, use_dist, device
+
+    def sync_all(self):
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        import torch.distributed as dist
+        from pivotcvae_amd import ops
+        tr = self.tr
+        s, r, u = self.batch
+        events = []
+
+        def hook_begin():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            return e0, e1
+
+        def hook_end(pair):
+            pair[1].record()
+            events.append(pair)
+
+        for _ in range(warmup):
+            tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
+        graphed = tr.capture_graph and tr._graph is not None
+        if not graphed:
+            ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
+        self.sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, rec, kld = tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
+        self.sync_all()
+        dt = time.perf_counter() - t0
+        ops.CATALOG_CE_TIMING = None
+        if self.use_dist:
+            t = torch.tensor([dt], device=self.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        if graphed:
+            # HIP events cannot be recorded inside a hipGraph (ROCm 7.2: hipErrorInvalidHandle, tools/evt_graph_probe.py),
+            # so the dominant kernel is timed over the same number of EAGER steps right after the timed region:
+            # same kernel, same inputs, same launch stream.
+            tr.capture_graph = False
+            ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
+            for _ in range(steps):
+                tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
+            torch.cuda.synchronize()
+            ops.CATALOG_CE_TIMING = None
+            tr.capture_graph = True
+        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+        return dict(dt=dt, steps=steps, kern_ms=kern_ms, graphed=graphed, elbo=(loss, rec, kld))
+
+
+# what the catalog contraction computes in, per --dtype: (json dtype, MFMA peak it is priced against, MFMAs issued per
+# algorithmic MAC).  bf16x3 = hi/lo bf16 split of BOTH operands, three bf16 MFMAs per product with fp32 accumulation: fp32-
+# equivalent results (tests/test_hip_x3.py: same tolerances as the f32 kernel) on the bf16 pipe.
+ARITH = {"f32": ("f32", PEAK_TFLOPS["f32"], 1), "bf16": ("bf16", PEAK_TFLOPS["bf16"], 1),
+         "bf16x3": ("bf16x3", PEAK_TFLOPS["bf16"], 3)}
+
+
+def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None):
+    if sparse_kept is not None:
+        # the sparse (n_neg << N) path is a gather: ~R * n_kept rows of the fp32 table, 4 D bytes each, read once
+        nbytes = float(R_local) * sparse_kept * D * 4
+        ach = nbytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                "traffic": None, "ms_per_launch": kern_ms, "algorithmic_bytes_per_launch": nbytes}
+    flops = 4.0 * R_local * N * D   # logits 2RND + gradient direction 2RND (SURVEY.md 8d)
+    _, peak, mult = ARITH[dtype]
+    ach = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
+    out = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+           "ms_per_launch": kern_ms, "algorithmic_flops_per_launch": flops}
+    if mult != 1:
+        out["mfma_issue_frac"] = ach * mult / peak
+        out["note"] = (f"{mult} bf16 MFMAs per algorithmic multiply-add (hi*hi + hi*lo + lo*hi): `frac` prices the ALGORITHMIC "
+                       f"flops against the bf16 peak, `mfma_issue_frac` the MFMAs actually issued")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="4", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"],
-                    help="arithmetic of the catalog contraction: bf16 MFMA inputs with fp32 accumulate (default; ELBO "
-                         "parity with the fp32 oracle is measured live in the 'parity' block) or exact f32 MFMA")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the catalog contraction of the HEADLINE line.  Default: the reference's precision - "
+                         "bf16x3 (fp32-equivalent, three bf16 MFMAs per product) where the kernel exists (D = 128), else "
+                         "exact f32 MFMA; configs 3 and 5 are stated in bf16 (BASELINE.json).  The other arithmetics are "
+                         "measured as named blocks under `variants`")
     ap.add_argument("--n_neg", type=int, default=None, help="default: N (full-catalog softmax)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the mlp_roofline / gather_roofline / generate / eval blocks")
+    ap.add_argument("--no-variants", action="store_true", help="skip the `variants` blocks (other arithmetics, n_neg = 1000)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph", action="store_true", help="replay a hipGraph at any batch size (default: only when the "
-                                                         "per-rank batch is <= 2048 slates, where launches dominate)")
+                                                         "per-rank batch is <= 4096 slates, where launches matter)")
     ap.add_argument("--global-batch", type=int, default=None,
                     help="override the config's global batch (e.g. 1024 on one GPU = the per-rank load of the 8-GPU run)")
     args = ap.parse_args()
+
+    dry = os.environ.get("PCVAE_BENCH_DRYRUN") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        if not dry and torch.cuda.device_count() < args.gpus:   # counting devices does not initialise the GPU
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible")
+        self_launch(args.gpus, sys.argv[1:])
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if dry:
+        return dry_run(args, world, rank)
 
     import torch.distributed as dist
     from pivotcvae_amd import ops
     from pivotcvae_amd.train_generative import Trainer
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("PCVAE_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL group: exercises the N>1 code on one GPU
@@ -305,96 +461,89 @@ def main():
     N, S, D, B = cfg["N"], cfg["S"], cfg["D"], cfg["B"]
     if B % world:
         raise SystemExit("global batch not divisible by the number of GPUs")
+    if args.dtype is None:
+        args.dtype = {"3": "bf16", "5": "bf16"}.get(args.config, "bf16x3" if D in ops.X3_DIMS else "f32")
+    if args.dtype == "bf16x3" and D not in ops.X3_DIMS:
+        raise SystemExit(f"bf16x3 exists for D in {ops.X3_DIMS}")
     model, st = build_model(cfg, device, args.dtype)
-    # hipGraph replay pays off when the step is launch-bound (B/W <= 2048 slates per rank: ~60 launches of 5-30 us);
-    # at a full single-GPU batch the catalog kernel is 96 % of the step and eager launches keep the HIP events that
-    # time it inside the timed region
-    use_graph = (not args.no_graph) and (B // world <= 2048 or args.graph)
+    # hipGraph replay pays off when the step is launch-bound (per-rank batch <= 4096 slates: ~50 launches of 5-30 us);
+    # at a full single-GPU batch of config 4 the catalog kernel is > 95 % of the step and eager launches keep the HIP events
+    # that time it inside the timed region
+    use_graph = (not args.no_graph) and (B // world <= 4096 or args.graph)
     trainer = Trainer(model, lr=LR, beta=BETA, n_neg=args.n_neg, capture_graph=use_graph)
     s, r, u = synthetic_batch(cfg, B, device)
     (s, r, u), lo = trainer.shard(s, r, u)
     s, r, u = s.contiguous(), r.contiguous(), u.contiguous()
-
-    # HIP events around the dominant kernel, on the stream it is launched on (torch's current stream)
-    kernel_events = []
-
-    def hook_begin():
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        return e0, e1
-
-    def hook_end(pair):
-        pair[1].record()
-        kernel_events.append(pair)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        trainer.step(s, r, u, global_batch=B, row_offset=lo)
-    graphed = trainer.capture_graph and trainer._graph is not None
-    if not graphed:
-        ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, rec, kld = trainer.step(s, r, u, global_batch=B, row_offset=lo)
-    sync_all()
-    dt = time.perf_counter() - t0
-    ops.CATALOG_CE_TIMING = None
-    if use_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    if graphed:
-        # HIP events cannot be recorded inside a hipGraph (ROCm 7.2: hipErrorInvalidHandle, tools/evt_graph_probe.py),
-        # so the dominant kernel is timed over the same number of EAGER steps right after the timed region:
-        # same kernel, same inputs, same launch stream.
-        trainer.capture_graph = False
-        ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
-        for _ in range(args.steps):
-            trainer.step(s, r, u, global_batch=B, row_offset=lo)
-        torch.cuda.synchronize()
-        ops.CATALOG_CE_TIMING = None
-        trainer.capture_graph = True
-
-    kern_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    timer = StepTimer(trainer, (s, r, u), B, lo, use_dist, device)
     R_local = s.shape[0] * S
-    # algorithmic work of one launch: 4*R*N*D (logits 2RND + gradient direction 2RND), SURVEY.md 8(d)
-    flops = 4.0 * R_local * N * D
-    achieved = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
-    peak = PEAK_TFLOPS[args.dtype]
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get(f"config{args.config}_{args.dtype}_gpus{world}")
+
+    res = timer.run(args.steps, args.warmup)
+    dt, kern_ms, graphed = res["dt"], res["kern_ms"], res["graphed"]
+    loss, rec, kld = res["elbo"]
+    sparse = args.n_neg is not None and ops.sparse_ce_applies(args.n_neg / N, N)
+    roof = roofline_block(kernel_name(R_local, N, D, args.dtype) if not sparse else "catalog_ce_sparse_kernel",
+                          R_local, N, D, args.dtype, kern_ms, sparse_kept=(args.n_neg + 1) if sparse else None)
+    if not sparse:
+        roof["kernel"] += " (events also span its row-bound prologue and merge kernels, <1% together)"
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        roof["traffic"] = None
+        if os.path.exists(tpath):   # PMC counters cannot be read from inside the run: taken from the committed profile
+            roof["traffic"] = json.load(open(tpath)).get(f"config{args.config}_{args.dtype}_gpus{world}")
+            roof["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of this kernel, committed; not measured in this run)"
+    roof["timed_over"] = (f"{args.steps} eager steps right after the timed graph-replayed steps (HIP events cannot be "
+                          "recorded inside a hipGraph)") if graphed else "the timed steps"
 
     out = {
         "metric": "slates/sec + ELBO, N=1M catalog K=10 B=8192" if args.config == "4" else f"slates/sec config {args.config}",
         "value": B * args.steps / dt, "unit": "slates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": ARITH[args.dtype][0], "data": "synthetic",
         "config": {"workload": f"PivotCVAE gt_pi train step (fwd+bwd+Adam), catalog N={N} slate K={S} emb D={D} "
                                f"global batch B={B}, full-catalog softmax" + ("" if args.n_neg is None else f" n_neg={args.n_neg}"),
                    "global_batch": B, "per_gpu_batch": B // world, "parallelism": f"dp{world}",
-                   "catalog_arithmetic": args.dtype, "mlp_arithmetic": "f32",
+                   "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                   "catalog_arithmetic": args.dtype + (" (fp32-equivalent: hi/lo bf16 split of both operands, fp32 accumulate)"
+                                                       if args.dtype == "bf16x3" else ""),
+                   "mlp_arithmetic": "f32",
                    "launch": "hipGraph replay (zero-grad+fwd+bwd) + eager all-reduce + Adam" if graphed else "eager"},
         "elbo": {"loss": loss.item(), "recLoss": rec.item(), "KLD": kld.item()},
-        "roofline": {"kernel": kernel_name(R_local, N, D, args.dtype) + " (events also span its row-bound prologue and "
-                               "merge kernels, <1% together)", "bound": "mfma",
-                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                     "traffic": traffic, "ms_per_launch": kern_ms, "algorithmic_flops_per_launch": flops,
-                     "timed_over": (f"{args.steps} eager steps right after the timed graph-replayed steps (HIP events cannot be "
-                                    "recorded inside a hipGraph)") if graphed else "the timed steps"},
+        "roofline": roof,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    single = rank == 0 and world == 1
+    if single and not args.no_variants:
+        # the same workload in the other arithmetics and in the reference's default masked mode (n_neg = 1000), each with its
+        # own timed region (2 warm-up + 3 steps) and roofline; the headline above is never taken from here
+        variants = {}
+        was_graph = trainer.capture_graph
+        trainer.capture_graph = False
+        for dt_name in ("f32", "bf16x3", "bf16"):
+            if dt_name == args.dtype or (dt_name == "bf16x3" and D not in ops.X3_DIMS) or \
+                    (dt_name == "bf16" and D not in ops.BF16_DIMS) or args.n_neg is not None:
+                continue
+            if dt_name == "f32" and 4.0 * R_local * N * D > 2e14:   # config 5 in exact f32: minutes per step
+                continue
+            model.set_catalog_precision(dt_name)
+            v = timer.run(3, 2)
+            variants[dt_name] = {"value": B * v["steps"] / v["dt"], "unit": "slates/s", "ms_per_step": v["dt"] / v["steps"] * 1e3,
+                                 "dtype": ARITH[dt_name][0],
+                                 "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
+                                 "roofline": roofline_block(kernel_name(R_local, N, D, dt_name), R_local, N, D, dt_name, v["kern_ms"])}
+        model.set_catalog_precision(args.dtype)
+        if args.n_neg is None and N >= 100_000:
+            trainer.n_neg = 1000   # train_generative.py:44 default; in-kernel Philox keep set (sparse path: only kept rows are read)
+            v = timer.run(3, 2)
+            trainer.n_neg = None
+            variants["n_neg_1000"] = {"value": B * v["steps"] / v["dt"], "unit": "slates/s", "ms_per_step": v["dt"] / v["steps"] * 1e3,
+                                      "dtype": "f32", "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
+                                      "roofline": roofline_block("catalog_ce_sparse_kernel", R_local, N, D, "f32", v["kern_ms"],
+                                                                 sparse_kept=1001)}
+        trainer.capture_graph = was_graph
+        out["variants"] = variants
+    if single and not args.no_cpu_baseline:
         base, parity = cpu_baseline_and_parity(model, st, cfg, args.dtype)
         out["cpu_baseline"] = base
         out["parity"] = parity
-    if rank == 0 and world == 1 and not args.no_extras:
+    if single and not args.no_extras:
         out["mlp_roofline"] = mlp_roofline(trainer, s, r, u, B, lo)
         out["gather_roofline"] = gather_roofline(model, cfg, device, tables=4 if N * D * 4 <= (1 << 30) else 2)
         out["generate"] = generate_throughput(model, cfg, device)

@@ -193,6 +193,10 @@ int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E
 /* fp32 table -> bf16 hi (round-to-nearest-even) and optional bf16 lo (residual) copies */
 int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, pcvae_stream_t stream);
 
+/* fp32 table [N, D] -> the bf16x3 catalog kernel's table image [N, 2 D] bf16: row n = hi(E_n) | lo(E_n) with
+ * hi = RNE bf16(E), lo = RNE bf16(E - hi)  (hi + lo carries 16 mantissa bits of E)                           */
+int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* out, pcvae_stream_t stream);
+
 /* K9  candidate-set scores                              models/pivotcvae.py:265-271
  *     p[r, c] = <E[cand[r, c]], rx_r> ;  bwd: drx_r = sum_c dp[r, c] * E[cand[r, c]]            */
 int pcvae_candidate_scores(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* cand,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "pcvae_catalog_argmax": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_sample": [_P, _L, _P, _P, _L, _I, _I, _U64, _U64, _P, _P, _SZ, _P],
     "pcvae_split_bf16": [_P, _L, _P, _P, _P],
+    "pcvae_split_bf16x2": [_P, _L, _I, _P, _P],
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_candidate_scores_bwd": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],

@@ -17,6 +17,8 @@
 //    weight grad  dW[N,K] = dY[M,N]^T . X[M,K]    A row-contiguous, B row-contiguous, split over M
 #include "common.h"
 #include <cstdint>
+#include <cstdlib>
+#include <algorithm>
 
 using namespace pcvae;
 
@@ -399,9 +401,14 @@ extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const floa
     // fp32 atomics in the (pre-zeroed, accumulating) gradient buffer.
     // The split count minimises (waves of workgroups) x (K rounds per workgroup): 512 workgroups are resident at once (two
     // per CU at this kernel's register count), so 1104 workgroups of 11 rounds take three waves where 1012 of 12 take two.
+    // PCVAE_DETERMINISTIC=1 (environment, read per call): one split, so every gradient element receives exactly one atomic add
+    // onto the zeroed buffer - bit-reproducible from run to run, at the price of a mostly idle chip for the small layers.
+    // (The default, split over M with fp32 atomics, sums the partials in arrival order: equal to ~1e-7 relative, not bitwise.)
+    const char* det_env = getenv("PCVAE_DETERMINISTIC");
+    const bool deterministic = det_env && det_env[0] == '1';
     const int64_t tiles = cdiv(N, BM) * cdiv(K, BN), rounds_total = cdiv(M, BK);
     int64_t splits = 1, best = INT64_MAX;
-    for (int64_t sp = 1; sp <= std::min<int64_t>(64, rounds_total); ++sp) {
+    for (int64_t sp = 1; sp <= (deterministic ? 1 : std::min<int64_t>(64, rounds_total)); ++sp) {
         const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
         const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp;              // +1: prologue / epilogue of a workgroup
         if (cost < best) { best = cost; splits = nsp; }

@@ -50,6 +50,11 @@ class UserPivotCVAE(BaseCVAE):
         self.last_pivot = None      # pivot item ids chosen by the most recent decode()
         self.to(self.device)
 
+    def params_without_grad(self):
+        """trainable parameters that never receive a gradient under ANY pivot rule: the PSM stack (its output is
+        either ignored or feeds a non-differentiable argmax / sample).  torch.optim.Adam skips them (grad is None)."""
+        return [p for i in range(self._n_psm) for p in getattr(self, f"psm_{i + 1}").parameters()]
+
     # ---- encoder / prior -----------------------------------------------------------------------
     def encode(self, emb, c, u_emb=None):
         x = ops.concat([emb, c] if self.noUser else [emb, c, u_emb])
@@ -63,8 +68,9 @@ class UserPivotCVAE(BaseCVAE):
         return self._prior_from(self.get_condition(r), self._user_rows(u, r.shape[0]))
 
     # ---- pivot selection ------------------------------------------------------------------------
-    def _pivot_index(self, rule, pivot_output, true_pivot):
-        """Item id of the pivot for one of the rules gt / pt|pi / spt|spi / sgt (never differentiable)."""
+    def _pivot_index(self, rule, pivot_output, true_pivot, sample_offset=None):
+        """Item id of the pivot for one of the rules gt / pt|pi / spt|spi / sgt (never differentiable).
+        ``sample_offset``: stream position (a global slate index) of the sampled rules; None = this model's running offset."""
         if rule == "gt":
             return true_pivot
         if self.pivot_override is not None and rule in ("spt", "spi", "sgt"):
@@ -77,21 +83,21 @@ class UserPivotCVAE(BaseCVAE):
         else:  # sgt: scores of the ground-truth pivot's own embedding against the catalog
             query = ops.gather_rows(self.docEmbed.weight, true_pivot)
         B = query.shape[0]
-        return ops.catalog_sample(query, table, seed=self.rng_seed ^ 0x5A17, row_offset=self._next_offset(B),
-                                  prec=self.catalog_precision)
+        off = self._next_offset(B) if sample_offset is None else int(sample_offset)
+        return ops.catalog_sample(query, table, seed=self.rng_seed ^ 0x5A17, row_offset=off, prec=self.catalog_precision)
 
-    def pick_pivot(self, pivot_output, true_pivot):
+    def pick_pivot(self, pivot_output, true_pivot, sample_offset=None):
         """-> pivot embedding [B, D]; rule = TRAIN_RULE when a true pivot is given, else INFER_RULE."""
         training = len(true_pivot) > 0
-        p = self._pivot_index(self.TRAIN_RULE if training else self.INFER_RULE, pivot_output, true_pivot)
+        p = self._pivot_index(self.TRAIN_RULE if training else self.INFER_RULE, pivot_output, true_pivot, sample_offset)
         self.last_pivot = p
         return ops.gather_rows(self.docEmbed.weight, p)
 
-    def decode(self, z, c, u_emb=None, true_pivot=[]):
+    def decode(self, z, c, u_emb=None, true_pivot=[], sample_offset=None):
         B = z.shape[0]
         x = ops.concat([z, c] if self.noUser else [z, c, u_emb])
         pivot_output = ops.mlp(x, self._mlp_layers("psm", self._n_psm), last_linear=True)
-        pivot_emb = self.pick_pivot(pivot_output, true_pivot)
+        pivot_emb = self.pick_pivot(pivot_output, true_pivot, sample_offset)
         return self._complete(z, c, u_emb, pivot_emb)
 
     def _complete(self, z, c, u_emb, pivot_emb):
@@ -119,14 +125,15 @@ class UserPivotCVAE(BaseCVAE):
         return p, rx, z, emb, z_mu, z_logvar
 
     def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
-             eps_offset=None, terms_only=False):
+             eps_offset=None, terms_only=False, sample_offset=None):
         """Fused counterpart of train_generative.get_gen_loss (mask-train path) -> (loss, recLoss, KLD).
 
         The [B*S, N] logits never exist: the full-catalog softmax CE (with the reference's downsample
         semantics when n_neg < N) and its gradient come from one streaming pass over the catalog.
         ``row_offset`` = index of this shard's first slate in the global batch (data parallel), so the
         Philox mask / eps streams do not depend on the world size; ``inv_count`` overrides the 1/(B*S)
-        of the 'mean' (a rank passes 1/(B_local*S*world_size)).
+        of the 'mean' (a rank passes 1/(B_local*S*world_size)); ``sample_offset`` pins the stream position of the
+        sampled pivot rules (spt / sgt) the same way (global slate index of this shard's first slate).
         With TRAIN_RULE == "gt" the PSM is skipped: its output is unused and it never receives a gradient in
         the reference either.
         """
@@ -149,7 +156,7 @@ class UserPivotCVAE(BaseCVAE):
             pivot_emb = emb[:, : self.feature_size]
             rx = self._complete(z, cond, u_emb, pivot_emb)
         else:
-            rx = self.decode(z, cond, u_emb=u_emb, true_pivot=s[:, 0].contiguous())
+            rx = self.decode(z, cond, u_emb=u_emb, true_pivot=s[:, 0].contiguous(), sample_offset=sample_offset)
         keep_prob = 1.0 if n_neg is None else float(n_neg) / N
         if keep_prob > 1.0:
             raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")

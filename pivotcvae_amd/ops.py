@@ -451,30 +451,75 @@ def latent(mu, logvar, pmu, plogvar, eps=None, seed=0, offset=0):
 
 
 # -------------------------------------------------------------------------------------- K5 / K6
+CATALOG_DIMS = (16, 32, 64, 128, 256)   # widths the catalog kernels are instantiated for
+
+
+def _padded_width(D):
+    """narrowest supported catalog width >= D (the reference's default --dim is 8, train_generative.py:302)"""
+    for w in CATALOG_DIMS:
+        if w >= D:
+            return w
+    raise ValueError(f"catalog kernels support D <= {CATALOG_DIMS[-1]}, got D={D}")
+
+
 class CatalogTable:
-    """The frozen item table E[N, D] plus (lazily) its bf16 hi / lo copies for the MFMA bf16 modes."""
+    """The frozen item table E[N, D] plus, lazily and cached per table version: its bf16 copy (bf16 MFMA mode), the
+    interleaved [N, 2D] bf16 hi | lo image (bf16x3 mode), and a zero-padded fp32 copy for widths the kernels are not
+    instantiated for (zero columns change neither a logit nor the gradient of the real columns)."""
 
     def __init__(self, weight):
         self.weight = weight
         self._ver = None
-        self._hi = self._lo = None
+        self._hi = self._x3 = self._pad = None
         self._emax = 0.0
 
-    def operands(self, prec):
+    def _refresh(self):
         w = self.weight
-        if prec == PREC_F32:
-            return w, None
         key = (w.data_ptr(), w._version, tuple(w.shape))
         if self._ver != key:
-            w32 = w.detach().contiguous()
-            hi = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
-            lo = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
-            check(lib().pcvae_split_bf16(ptr(w32, F32), w32.numel(), ptr(hi), ptr(lo), stream()), "split_bf16")
-            # max row norm: lets the bf16 kernel skip the running max where |logit| provably stays small.
+            self._hi = self._x3 = self._pad = None
+            self._emax = 0.0
+            self._ver = key
+
+    def padded(self):
+        """-> (fp32 table of a supported width, that width)"""
+        self._refresh()
+        w = self.weight
+        D = w.shape[1]
+        Dp = _padded_width(D)
+        if Dp == D:
+            return w, D
+        if self._pad is None:
+            pad = torch.zeros(w.shape[0], Dp, dtype=F32, device=w.device)
+            copy2d(w.detach(), pad[:, :D])
+            self._pad = pad
+        return self._pad, Dp
+
+    def _max_norm(self, w32):
+        if self._emax == 0.0:
+            # max row norm: lets the bf16 kernels skip the running max where |logit| provably stays small.
             # One-off per table version (frozen table), like the bf16 copies themselves.
             self._emax = float(w32.pow(2).sum(1).max().sqrt().item()) * (1.0 + 1e-6)
-            self._hi, self._lo, self._ver = hi, lo, key
-        return self._hi, (self._lo if prec == PREC_BF16X3 else None)
+
+    def operands(self, prec):
+        """-> (E, E_lo) as pcvae_catalog_ce takes them for this precision mode"""
+        self._refresh()
+        w = self.weight
+        if prec == PREC_F32:
+            return self.padded()[0], None
+        w32 = w.detach().contiguous()
+        self._max_norm(w32)
+        if prec == PREC_BF16X3:
+            if self._x3 is None:
+                x3 = torch.empty(w32.shape[0], 2 * w32.shape[1], dtype=torch.int16, device=w.device)
+                check(lib().pcvae_split_bf16x2(ptr(w32, F32), w32.shape[0], w32.shape[1], ptr(x3), stream()), "split_bf16x2")
+                self._x3 = x3
+            return self._x3, w32   # E_lo carries the exact fp32 table: row blocks with large norms run the f32 kernel
+        if self._hi is None:
+            hi = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
+            check(lib().pcvae_split_bf16(ptr(w32, F32), w32.numel(), ptr(hi), None, stream()), "split_bf16")
+            self._hi = hi
+        return self._hi, None
 
     def e_max_norm(self, prec):
         return 0.0 if prec == PREC_F32 else self._emax
@@ -485,12 +530,35 @@ _ws_cache = {}
 CATALOG_CE_TIMING = None
 
 
+_ws_holder = None   # set by workspace_holder(): a dict that owns the scratch buffers instead of the module cache
+
+
+class workspace_holder:
+    """``with workspace_holder(d):`` every catalog call inside takes its scratch buffer from the dict ``d`` (grow-only, keyed like
+    the module cache).  A hipGraph bakes the scratch pointer into its kernels: the Trainer captures under its OWN holder and keeps
+    it alive with the graph, so no later, larger call on the device can free memory a replay still writes to."""
+
+    def __init__(self, holder):
+        self.holder = holder
+
+    def __enter__(self):
+        global _ws_holder
+        self.prev, _ws_holder = _ws_holder, self.holder
+        return self.holder
+
+    def __exit__(self, *exc):
+        global _ws_holder
+        _ws_holder = self.prev
+
+
 def _workspace(device, nbytes):
-    """Grow-only scratch buffer per device (the C ABI never allocates)."""
-    buf = _ws_cache.get(device)
+    """Grow-only scratch buffer per (device, stream): the C ABI never allocates, and two streams never share scratch."""
+    cache = _ws_cache if _ws_holder is None else _ws_holder
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-        _ws_cache[device] = buf
+        cache[key] = buf
     return buf
 
 
@@ -499,10 +567,31 @@ def _as_table(E):
 
 
 BF16_DIMS = (64, 128, 256)  # the bf16 MFMA kernels exist for these widths; narrower tables are tiny: exact f32 path
+X3_DIMS = ()                # widths the bf16x3 (fp32-equivalent) kernel exists for
+
+
+def sparse_ce_applies(keep_prob, N):
+    """does catalog_ce take the sparse (kept rows only) path for this keep probability?"""
+    return False
 
 
 def effective_precision(prec, D):
-    return prec if (prec == PREC_F32 or D in BF16_DIMS) else PREC_F32
+    """bf16 kernels exist for D in BF16_DIMS, the bf16x3 kernel for D in X3_DIMS; everything else computes in exact f32"""
+    if prec == PREC_BF16 and D in BF16_DIMS:
+        return PREC_BF16
+    if prec == PREC_BF16X3 and D in X3_DIMS:
+        return PREC_BF16X3
+    return PREC_F32
+
+
+def _pad_cols(x, Dp):
+    """[R, D] -> [R, Dp] with zero columns behind (a no-op when D == Dp)"""
+    R, D = x.shape
+    if D == Dp:
+        return x
+    out = torch.zeros(R, Dp, dtype=F32, device=x.device)
+    copy2d(x, out[:, :D])
+    return out
 
 
 def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32,
@@ -511,7 +600,7 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     table = _as_table(table)
     require_device(rx, table.weight, target, keep_mask)
     rx = _c2d(rx).contiguous()
-    R, D = rx.shape
+    R, D0 = rx.shape
     N = table.weight.shape[0]
     target = target.reshape(-1).to(torch.int64).contiguous()
     if target.numel() != R:
@@ -520,8 +609,14 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
         keep_mask = keep_mask.to(torch.uint8).contiguous()
         if tuple(keep_mask.shape) != (R, N):
             raise ValueError("catalog_ce: keep_mask must be [R, N]")
-    prec = effective_precision(prec, D)
+    prec = effective_precision(prec, D0)
+    if keep_mask is None and keep_prob < 1.0 and sparse_ce_applies(keep_prob, N):
+        return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx)
+    if keep_mask is not None or keep_prob < 1.0:
+        prec = PREC_F32 if prec == PREC_BF16X3 else prec   # masked calls: the x3 kernel is max-free / mask-free
     E, E_lo = table.operands(prec)
+    D = _padded_width(D0)
+    rx = _pad_cols(rx, D)
     nll = torch.empty(R, dtype=F32, device=rx.device)
     lse = torch.empty(R, dtype=F32, device=rx.device)
     dx = torch.empty(R, D, dtype=F32, device=rx.device) if want_dx else None
@@ -535,6 +630,8 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
                                  ptr(ws), ws.numel(), stream()), "catalog_ce")
     if timing:
         timing[1](tok)
+    if dx is not None and D != D0:
+        dx = dx[:, :D0]
     return nll, lse, dx
 
 
@@ -597,7 +694,9 @@ def catalog_argmax(x, table, prec=PREC_F32, return_best=False, screened=None):
         E_lo = table.weight
         mode, emax = PREC_SCREENED, table.e_max_norm(PREC_BF16)
     else:
-        E, E_lo, mode, emax = table.weight, None, PREC_F32, 0.0
+        E, D = table.padded()   # zero columns: fmaf(0, 0, acc) == acc, ids and scores stay bit-exact
+        x = _pad_cols(x, D)
+        E_lo, mode, emax = None, PREC_F32, 0.0
     idx = torch.empty(R, dtype=torch.int64, device=x.device)
     best = torch.empty(R, dtype=F32, device=x.device) if return_best else None
     nbytes = lib().pcvae_catalog_ws_bytes(R, N, D, 0)
@@ -612,9 +711,11 @@ def catalog_sample(x, table, seed=0, row_offset=0, prec=PREC_F32):
     table = _as_table(table)
     require_device(x, table.weight)
     x = _c2d(x.detach()).contiguous()
-    R, D = x.shape
+    R = x.shape[0]
     N = table.weight.shape[0]
-    E, E_lo = table.weight, None  # sampling scores are fp32 whatever the loss precision is
+    E, D = table.padded()   # sampling scores are fp32 whatever the loss precision is
+    x = _pad_cols(x, D)
+    E_lo = None
     idx = torch.empty(R, dtype=torch.int64, device=x.device)
     ws = _workspace(x.device, lib().pcvae_catalog_ws_bytes(R, N, D, 0))
     check(lib().pcvae_catalog_sample(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, PREC_F32, int(seed), int(row_offset),

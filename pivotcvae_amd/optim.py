@@ -5,7 +5,10 @@ state_dict keys are unchanged: each becomes a view), and so are their gradients.
 memset + one HIP kernel, and data parallelism needs exactly one all-reduce over the gradient buffer.
 
 Parameters that never receive a gradient (the PSM stack) keep a zero gradient; Adam with
-g = 0, m = 0, v = 0 leaves them bit-identical, which is what the reference's "skip grad None" does.
+g = 0, m = 0, v = 0 leaves them bit-identical, which is what the reference's "skip grad None" does.  With a
+non-zero weight_decay that is no longer automatic (g + wd * p != 0): torch.optim.Adam skips a parameter whose
+grad is None altogether, so the ranges of such parameters (``model.params_without_grad()``) are stepped with
+weight_decay = 0 - the flat buffer is then walked as a few contiguous segments instead of one.
 """
 import torch
 
@@ -31,12 +34,19 @@ class FlatAdam:
         self.tail = self.grad_ext[total:]
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        no_grad = {id(p) for p in getattr(model, "params_without_grad", lambda: [])()}
         off = 0
+        self.segments = []   # [offset, numel, weight_decay], adjacent ranges of equal decay merged
         for p in self.params:
             n = p.numel()
             self.flat[off:off + n].copy_(p.data.reshape(-1))
             p.data = self.flat[off:off + n].view(p.shape)
             p.grad = self.grad[off:off + n].view(p.shape)
+            wd = 0.0 if id(p) in no_grad else self.weight_decay
+            if self.segments and self.segments[-1][2] == wd:
+                self.segments[-1][1] += n
+            else:
+                self.segments.append([off, n, wd])
             off += n
         self.t = 0
 
@@ -55,5 +65,7 @@ class FlatAdam:
 
     def step(self, grad_scale=1.0):
         self.t += 1
-        ops.adam_step_(self.flat, self.grad, self.m, self.v, self.lr, self.t, self.betas[0], self.betas[1], self.eps,
-                       grad_scale, self.weight_decay)
+        for off, n, wd in self.segments:   # one launch unless weight decay is on AND some parameters never get a gradient
+            sl = slice(off, off + n)
+            ops.adam_step_(self.flat[sl], self.grad[sl], self.m[sl], self.v[sl], self.lr, self.t, self.betas[0], self.betas[1],
+                           self.eps, grad_scale, wd)

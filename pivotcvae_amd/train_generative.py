@@ -77,6 +77,23 @@ def recommendation_test(model, resp_model, bs, n_test_trial=100, seed=0):
     return acc / n_test_trial
 
 
+class _FixedWorkspace(dict):
+    """workspace holder for graph capture: whatever stream asks, it gets the ONE pre-allocated buffer (never a new allocation
+    inside the capture); a request larger than the warm-up's is a bug and raises"""
+
+    def __init__(self, buf):
+        super().__init__()
+        self.buf = buf
+
+    def get(self, key, default=None):
+        if self.buf is None:
+            raise RuntimeError("catalog scratch requested during hipGraph capture but the warm-up used none")
+        return self.buf
+
+    def __setitem__(self, key, value):
+        raise RuntimeError("catalog scratch grew during hipGraph capture (the warm-up runs the same shapes: this is a bug)")
+
+
 class Trainer:
     """One optimisation step of reference train_generative.py:124-134, data-parallel aware.
 
@@ -102,8 +119,11 @@ class Trainer:
         # hipGraph capture of zero-grad + forward + backward (the ~90 small launches of a step become one graph
         # launch; matters when a rank only holds B/8 slates).  eps is drawn OUTSIDE the graph into a static buffer
         # because kernel arguments (Philox offsets) are frozen at capture; the in-kernel Bernoulli mask (n_neg < N)
-        # has the same problem, so that mode stays eager.  The all-reduce and Adam stay outside the graph.
-        self.capture_graph = bool(capture_graph) and n_neg is None and loss_fn is None
+        # has the same problem, so that mode stays eager - and so do the SAMPLED pivot rules (spt / sgt): their Gumbel-max
+        # sampler takes (seed, row offset) as kernel arguments too, a replayed graph would redraw the same pivots every step.
+        # The all-reduce and Adam stay outside the graph.
+        self.capture_graph = bool(capture_graph) and n_neg is None and loss_fn is None and \
+            getattr(model, "TRAIN_RULE", "gt") in ("gt", "pt")
         self._graph = None
         self._static = None
 
@@ -122,6 +142,10 @@ class Trainer:
         self.opt.zero_grad()
         kw = dict(beta=self.beta, n_neg=self.n_neg, eps=eps, row_offset=row_offset, inv_count=1.0 / (B * S * self.world),
                   eps_offset=eps_offset, mask_seed=self.global_step)
+        if self._own_loss and getattr(self.model, "TRAIN_RULE", "gt") in ("spt", "sgt"):
+            # sampled pivots: the sampler's stream position is the slate's GLOBAL index in the run, like eps - independent of how
+            # the batch is sharded over ranks
+            kw["sample_offset"] = eps_offset // self.model.latent_size
         if self._own_loss:
             # d(rec + beta KLD) = 1 d rec + beta d KLD: seeding backward with the two constants saves the mul / add / fill / mul
             # launches of forming the sum and differentiating it (the logged loss is formed in step(), one launch)
@@ -146,13 +170,17 @@ class Trainer:
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up: scratch buffers, bf16 table copies, kernel attributes
+        # the catalog kernels' scratch pointer is baked into the graph: capture under this trainer's OWN buffer (kept in
+        # self._static), not the module-wide grow-only cache that a later, larger call may reallocate
+        warm = {}
+        with torch.cuda.stream(side), ops.workspace_holder(warm):  # warm-up: scratch buffers, bf16 table copies, kernel attributes
             for _ in range(2):
                 self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        st["ws"] = max(warm.values(), key=lambda t: t.numel()) if warm else None
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph), ops.workspace_holder(_FixedWorkspace(st["ws"])):
             st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
         self._graph, self._static = graph, st
 

@@ -469,12 +469,41 @@ def test_candidate_scores(ops):
 
 # ------------------------------------------------------------------------- argument validation
 def test_bad_arguments_are_rejected_before_launch(ops):
-    rx = rnd(8, 24).to(DEV)  # D=24 unsupported by the catalog kernels
+    from pivotcvae_amd import _hip
+    rx = rnd(8, 24).to(DEV)  # D=24: not a width the C ABI is instantiated for (the host op pads it, see below)
     E = rnd(50, 24).to(DEV)
-    with pytest.raises(RuntimeError, match="unsupported D"):
-        ops.catalog_ce_raw(rx, E, torch.zeros(8, dtype=torch.long, device=DEV))
+    nll = torch.empty(8, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    rc = _hip.lib().pcvae_catalog_ce(_hip.ptr(rx), 8, _hip.ptr(E), None, 50, 24, 0, 0.0,
+                                     _hip.ptr(torch.zeros(8, dtype=torch.long, device=DEV)), 1.0, 0, 0, None, _hip.ptr(nll),
+                                     None, None, _hip.ptr(ws), ws.numel(), _hip.stream())
+    assert rc == -1 and b"unsupported D" in _hip.lib().pcvae_last_error()
+    with pytest.raises(ValueError, match="D <= 256"):
+        ops.catalog_ce_raw(rnd(8, 320).to(DEV), rnd(50, 320).to(DEV), torch.zeros(8, dtype=torch.long, device=DEV))
     with pytest.raises(RuntimeError):
         ops.linear_fwd_raw(rnd(4, 8).to(DEV), rnd(3, 9).to(DEV), None, 0)
+
+
+@pytest.mark.parametrize("D", [8, 24, 100])
+def test_catalog_ops_pad_unsupported_widths(ops, D):
+    """The reference's default --dim is 8 (train_generative.py:302).  Widths the kernels are not instantiated for are zero-padded
+    to the next supported one on the host side: zero columns change no logit (fmaf(0, 0, acc) == acc exactly) and no gradient
+    component of the real columns.  CE / gradient / greedy ids / sampler against the oracle at the ORIGINAL width."""
+    R, N = 70, 333
+    rx, E = rnd(R, D, seed=1, scale=2.0), unit_rows(N, D, seed=2)
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    table = ops.CatalogTable(E.to(DEV))
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), table, tgt.to(DEV))
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+    assert dx.shape == (R, D)
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    idx, best = ops.catalog_argmax(rx.to(DEV), table, return_best=True)
+    oidx, obest = co.argmax(rx.numpy(), E.numpy())
+    assert np.array_equal(idx.cpu().numpy(), oidx) and np.array_equal(best.cpu().numpy(), obest)
+    smp = ops.catalog_sample(rx.to(DEV), table, seed=5)
+    assert smp.shape == (R,) and int(smp.min()) >= 0 and int(smp.max()) < N
 
 
 # ----------------------------------------------------------------- BASELINE.json full catalog size
