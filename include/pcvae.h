@@ -40,7 +40,8 @@ extern "C" {
 /* catalog precision modes (arithmetic the [R,D]x[D,N] contraction is computed in) */
 #define PCVAE_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact k-ordered fmaf chain (bit-exact ids) */
 #define PCVAE_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16 on a bf16 copy of the table, fp32 accumulate */
-#define PCVAE_PREC_BF16X3 2 /* split-bf16 (hi+lo) 3-product emulation of fp32 on the bf16 MFMA pipe (reserved) */
+#define PCVAE_PREC_BF16X3 2 /* fp32-equivalent on the bf16 MFMA pipe: hi/lo bf16 split of both operands, 3 MFMAs per product
+                               (D = 128; E = [N, 2D] bf16 image of pcvae_split_bf16x2, E_lo = the fp32 table) */
 #define PCVAE_PREC_SCREENED 3 /* argmax only: bf16 MFMA screening + exact fp32 rescoring of the few candidates;
                                 results identical to PCVAE_PREC_F32 (E = bf16 table, E_lo = fp32 table, D = 128) */
 

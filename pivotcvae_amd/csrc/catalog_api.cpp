@@ -17,12 +17,21 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
         need = std::max(need, std::max(ce, am) + (size_t)pl.nrb + 64);
     }
     need = std::max(need, (size_t)R * (8 + 4 + 4 + 64 * 4) + 64);  // screened argmax: keys, thresholds, <= 64 partial maxima
+    if (D == 128) need = std::max(need, catalog_x3_ws_bytes(R, N, D));
     return need + 256;
+}
+
+// bf16x3: its own partials (always with U), the row-block flags, then the f32 kernel's partials for flagged row blocks
+size_t pcvae::catalog_x3_ws_bytes(int64_t R, int64_t N, int D) {
+    const CatalogPlan px = catalog_plan(R, N, D, PCVAE_PREC_BF16X3), pf = catalog_plan(R, N, D, PCVAE_PREC_F32);
+    const size_t rx = (size_t)px.nsplit * (size_t)R, rf = (size_t)pf.nsplit * (size_t)R;
+    return rx * (2 + (size_t)D) * sizeof(float) + (((size_t)px.nrb + 255) / 256) * 256 + rf * (2 + (size_t)D) * sizeof(float) + 64;
 }
 
 extern "C" int pcvae_catalog_ce_variant(int64_t R, int64_t N, int D, int prec) {
     if (R <= 0 || N <= 0 || !supported_d(D)) return -1;
     if (prec == PCVAE_PREC_F32) return 0;
+    if (prec == PCVAE_PREC_BF16X3) return D == 128 ? 3 : -1;
     if (prec != PCVAE_PREC_BF16 || (D != 64 && D != 128 && D != 256)) return -1;
     return catalog_bf16_pipelined(D, catalog_plan(R, N, D, PCVAE_PREC_BF16).tiles_per_split) ? 2 : 1;
 }
@@ -52,6 +61,17 @@ extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const
         (void)E_lo;
         return catalog_ce_bf16(rx, R, reinterpret_cast<const uint16_t*>(E), N, D, e_max_norm, target, keep_prob, seed,
                                row_offset, keep_mask, nll, lse, dx, ws, as_stream(stream));
+    }
+    if (prec == PCVAE_PREC_BF16X3) {
+        // E = the [N, 2 D] bf16 hi | lo image (pcvae_split_bf16x2), E_lo = the fp32 table itself (exact target logit / target
+        // row, and the exact f32 kernel for masked calls and for row blocks whose norms rule out the max-free kernel)
+        PCVAE_REQUIRE(D == 128 && E_lo && ((uintptr_t)E_lo % 16 == 0) && e_max_norm > 0.f,
+                      "catalog_ce(bf16x3): needs D = 128, the fp32 table in E_lo and e_max_norm > 0");
+        if (keep_mask || keep_prob < 1.0f)
+            return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E_lo), N, D, target, keep_prob, seed, row_offset,
+                                  keep_mask, nll, lse, dx, ws, as_stream(stream));
+        return catalog_ce_x3(rx, R, reinterpret_cast<const uint16_t*>(E), reinterpret_cast<const float*>(E_lo), N, D,
+                             e_max_norm, target, nll, lse, dx, ws, as_stream(stream));
     }
     set_error("catalog_ce: precision mode %d not available in this build", prec);
     return PCVAE_EINVAL;

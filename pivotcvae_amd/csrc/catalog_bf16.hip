@@ -2030,9 +2030,50 @@ __global__ void catalog_screen_decode_kernel(ScreenParams p, int64_t* __restrict
     if (best) best[r] = unordered_bits((unsigned int)(key >> 32));
 }
 
+#include "catalog_x3.h"
+
 }  // namespace
 
 namespace pcvae {
+
+int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
+                  const int64_t* target, float* nll, float* lse, float* dx, void* ws, hipStream_t st) {
+    if (D != 128) {
+        set_error("catalog_ce(bf16x3): D=%d (the kernel exists for D = 128)", D);
+        return PCVAE_EINVAL;
+    }
+    constexpr int CT = 2;
+    using XG = X3Geo<128, CT>;
+    const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16X3);
+    CatParamsB p{};
+    p.rx = rx; p.E = Ex; p.target = target; p.R = R; p.N = N;
+    p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
+    const int64_t ns = pl.nsplit;
+    p.pm = reinterpret_cast<float*>(ws);
+    p.pl = p.pm + ns * R;
+    p.pU = p.pl + ns * R;
+    uint8_t* flags = reinterpret_cast<uint8_t*>(p.pU + ns * R * D);   // [nrb] behind the partials
+    // row blocks whose logit bound allows raw exp2 run the max-free bf16x3 kernel; the others (flag 1) the exact f32 kernel
+    hipLaunchKernelGGL((catalog_row_bound_kernel<128>), dim3((unsigned)p.nrb), dim3(256), 0, st, rx, R, e_max_norm, flags);
+    p.safe_flags = flags;
+    constexpr int lds_pipe = XG::NB * 16384;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_x3_pipe_kernel<128, CT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(cdiv(R, XG::ROWS) * p.nsplit));
+    hipLaunchKernelGGL((catalog_ce_x3_pipe_kernel<128, CT>), grid, dim3(256), lds_pipe, st, p);
+    int rc = check_launch("catalog_ce_x3");
+    if (rc != PCVAE_OK) return rc;
+    hipLaunchKernelGGL((catalog_ce_merge_x3_kernel<128>), dim3((unsigned)cdiv(R, 4)), dim3(256), 0, st, p, Ef, nll, lse, dx);
+    rc = check_launch("catalog_ce_merge_x3");
+    if (rc != PCVAE_OK) return rc;
+    // flagged row blocks (normally none): the exact f32 kernel on its own partials behind the flags, rows of flag 1 only
+    char* ws2 = reinterpret_cast<char*>(flags) + ((p.nrb + 255) / 256) * 256;
+    return catalog_ce_f32_flagged(rx, R, Ef, N, D, target, nll, lse, dx, ws2, flags, st);
+}
 
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,

@@ -43,6 +43,7 @@ struct CatParams {
     float* pl;            // [nsplit][R]   sum of exp          (argmax: unused)
     float* pU;            // [nsplit][R][D] numerator vector   (CE with dx only)
     int64_t* pn;          // [nsplit][R]   argmax index
+    const uint8_t* flags; // CE only, or null: one byte per 256-row block; only blocks whose flag is 1 are computed / written
 };
 
 template <int D>
@@ -98,6 +99,7 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_ce_f32_kernel
     const int li = lane & 31, h = lane >> 5;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / p.nrb, rb = logical % p.nrb;
+    if (p.flags && p.flags[rb >> 1] != 1) return;   // fallback mode of the bf16x3 path: this row block was done there
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
 
@@ -251,6 +253,7 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_f32_kernel(CatParams p, 
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= p.R) return;
+    if (p.flags && p.flags[r >> 8] != 1) return;
     float M = -INFINITY;
     for (int j = 0; j < p.nsplit; ++j) M = fmaxf(M, p.pm[(int64_t)j * p.R + r]);
     float L = 0.f;
@@ -424,6 +427,20 @@ int launch_argmax(const CatParams& p, bool sample, int64_t* idx, float* best, hi
 }  // namespace
 
 namespace pcvae {
+
+int catalog_ce_f32_flagged(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target, float* nll,
+                           float* lse, float* dx, void* ws, const uint8_t* flags, hipStream_t st) {
+    const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);
+    CatParams p{};
+    p.rx = rx; p.E = E; p.target = target; p.R = R; p.N = N; p.flags = flags;
+    p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
+    p.pm = reinterpret_cast<float*>(ws);
+    p.pl = p.pm + (int64_t)pl.nsplit * R;
+    p.pU = p.pl + (int64_t)pl.nsplit * R;
+    if (D == 128) return launch_ce<128>(p, MASK_NONE, dx != nullptr, nll, lse, dx, st);
+    set_error("catalog_ce_f32_flagged: D=%d", D);
+    return PCVAE_EINVAL;
+}
 
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,

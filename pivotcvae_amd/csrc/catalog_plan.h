@@ -19,8 +19,9 @@ struct CatalogPlan {
 //   bf16 kernels: 256-row workgroups (8 waves), 1 resident per CU, ranges are whole 128-item LDS chunks
 static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     const bool f32 = prec == PCVAE_PREC_F32;
+    const bool x3 = prec == PCVAE_PREC_BF16X3;   // table rows of 4 D bytes: the geometry of the D = 256 bf16 kernel
     const int rows_wg = f32 ? 128 : 256;
-    const int quant = f32 ? 1 : 4;
+    const int quant = (f32 || x3) ? 1 : 4;
     CatalogPlan p;
     p.nrb = (int)cdiv(R, rows_wg);
     p.ntiles = (int)cdiv(N, 32);
@@ -30,7 +31,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // Ranges stay long enough that the per-range prologue (rx fragments) and epilogue (partials) are amortised.
     const int64_t slots = 256 * (f32 ? 2 : 1);
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
-    const int64_t nblk = (!f32 && D == 256) ? cdiv(R, 128) : p.nrb;
+    const int64_t nblk = (!f32 && (D == 256 || x3)) ? cdiv(R, 128) : p.nrb;
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
     int64_t best_cost = -1;
     for (int64_t ns = 1; ns <= cap; ++ns) {
@@ -53,6 +54,13 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
         p.tiles_per_split = (int)tps;
         p.nsplit = (int)cdiv(p.ntiles, tps);
     }
+    // bf16x3: one fill slot + steady-state trips of 6 slots; 6k+1 tiles leave no fenced slot at all
+    if (x3 && p.tiles_per_split >= 64) {
+        int64_t tps = p.tiles_per_split;
+        tps += ((1 - tps % 6) + 6) % 6;
+        p.tiles_per_split = (int)tps;
+        p.nsplit = (int)cdiv(p.ntiles, tps);
+    }
     return p;
 }
 
@@ -71,6 +79,12 @@ int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D,
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
                     const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, hipStream_t st);
+int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
+                  const int64_t* target, float* nll, float* lse, float* dx, void* ws, hipStream_t st);
+// the exact f32 kernel restricted to the 256-row blocks whose flag is 1 (the fallback of the max-free bf16x3 kernel)
+int catalog_ce_f32_flagged(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target, float* nll,
+                           float* lse, float* dx, void* ws, const uint8_t* flags, hipStream_t st);
+size_t catalog_x3_ws_bytes(int64_t R, int64_t N, int D);
 int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, int D, float e_max_norm,
                             int64_t* idx, float* best, void* ws, hipStream_t st);
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,

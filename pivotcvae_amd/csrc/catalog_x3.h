@@ -1,0 +1,579 @@
+// K5 in fp32-EQUIVALENT arithmetic on the bf16 matrix cores ("bf16x3"): the fused full-catalog softmax cross-entropy of
+// catalog_bf16.hip with BOTH operands of both contractions split into bf16 hi + lo halves and three bf16 MFMAs per product
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate; the dropped lo*lo term is 2^-18 relative).  Replaces, at reference precision,
+// `mm` + `downsample(n_neg = N)` + `CrossEntropyLoss` + their backward (models/pivotcvae.py:274, train_generative.py:59).
+//
+// This file is included by catalog_bf16.hip INSIDE its anonymous namespace (it reuses that file's LDS geometry, LDS-DMA staging
+// and inline-asm MFMA / LDS-read helpers); it is not a translation unit of its own.
+//
+// Table image (pcvae_split_bf16x2): row n = hi(E_n)[D] | lo(E_n)[D] bf16 = 4 D bytes.  For D = 128 that is exactly the LDS geometry
+// of the D = 256 bf16 kernel (FastGeo<256>: 512-byte rows, the 16-chunk XOR swizzle inside each 256-byte half, one 32-item
+// subtile per 16 KB ring chunk), so the ring, the seams and both conflict-free read patterns are shared with it:
+//   logits    k-steps 0..3 read the hi half, 4..7 the lo half of a row.  Step (s, rt):
+//               s < 4 : acc[rt][ct] += A_hi(s) . xh[ct][s]   and   += A_hi(s) . xl[ct][s]
+//               s >= 4: acc[rt][ct] += A_lo(s) . xh[ct][s-4]
+//   numerators p = exp2(acc) (fp32) -> ph = RNE bf16(p), pl = RNE bf16(p - ph) (p - ph is exact in fp32)
+//   row sums  lsum[ct] += ones . ph[ct]  and  += ones . pl[ct]    (the same 16-bit numerators the gradient chain multiplies)
+//   gradient  d tiles 0..7 are E_hi^T, 8..15 E_lo^T:
+//               DT < 8 : U[DT][ct] += T_hi(DT) . ph[ct]  and  += T_hi(DT) . pl[ct]
+//               DT >= 8: U[DT-8][ct] += T_lo(DT) . ph[ct]
+// 100 MFMAs per 32-item subtile and 32-row wave (2 x 24 CT + 4 row sums at CT = 2) against the bf16 kernel's 36: ~2.8x its
+// time, ~4x faster than the exact f32-MFMA kernel, at the f32 kernel's tolerances (tests/test_hip_x3.py).
+//
+// Schedule (one wave per SIMD, CT = 2 column tiles of 16 rows per wave, every MFMA / LDS read / VALU op an inline-asm statement
+// in schedule order - see catalog_ce_bf16_pipe_kernel for the method and for what hipcc may not place in these loops):
+//   slot t:  L(t)    logits chain of subtile t (48 MFMAs)  ||  lo halves of subtile t-1's numerators (5 cheap VALU ops per pair)
+//            G(t-1)  row sums + gradient chain of subtile t-1 (52 MFMAs)  ||  exponentials + hi halves of subtile t (3 ops per
+//                    pair), the seam (counted vmcnt + s_barrier + refill of the ring) and the first A fragments of L(t+1) in
+//                    the middle of the chain.
+// A single accumulation chain of v_mfma_f32_16x16x32_bf16 issues back to back at full rate (MI355X_MICROARCH.md, cycle
+// constants), so the two or three MFMAs that update one accumulator need no interleaving.
+// Max-free like the bf16 fast kernels (row blocks whose Cauchy-Schwarz logit bound exceeds 90 are flagged by
+// catalog_row_bound_kernel and run the exact f32 kernel instead: catalog_ce_x3 below).
+#pragma once
+
+#ifndef X3_AD
+#define X3_AD 2      // logits chain: A fragments requested ahead (the first X3_AD of a slot are issued at the previous seam)
+#endif
+#ifndef X3_TD
+#define X3_TD 2      // gradient chain: d tiles requested ahead (two transposed reads each)
+#endif
+
+template <int D, int CT>
+struct X3Geo {
+    static constexpr int DL = 2 * D;                       // table / LDS row width in bf16 elements: hi | lo
+    using GL = FastGeo<DL>;
+    static_assert(D == 128, "bf16x3 is built for D = 128: a 512-byte table row, one 32-item subtile per 16 KB ring chunk");
+    static_assert(GL::SUB == 1 && GL::KS == 8 && GL::NDT == 16, "layout of FastGeo<256>");
+    static constexpr int KSH = D / 32;                     // k-steps per half
+    static constexpr int NI = 2 * GL::KS;                  // steps of the logits chain: (k-step, row tile)
+    static constexpr int NDT = D / 16;                     // 16-wide d tiles of U
+    static constexpr int NDTL = GL::NDT;                   // transposed tiles: hi then lo
+    static constexpr int ML = 2 * KSH * 2 * CT + 2 * KSH * CT;          // MFMAs of L
+    static constexpr int MG = 2 * CT + NDT * 2 * CT + NDT * CT;         // MFMAs of G (row sums first)
+    static constexpr int P = 4 * CT;                       // numerator pairs per slot: (row tile, column tile, half)
+    static constexpr int GOPS = 3 * P;                     // during G: 2 exponentials + 1 packed conversion (hi) per pair
+    static constexpr int LOPS = 5 * P;                     // during the next L: shift, mask, 2 subtractions, packed conversion (lo)
+    static constexpr int ROWS = 4 * 16 * CT;               // rows per workgroup (4 waves)
+    static constexpr int NB = 6, PF = 3, TR = NB;          // ring buffers, chunks requested ahead, slots per steady-state trip
+    // VALU ops behind MFMA position m of G: [gfirst(m), gfirst(m + 1)); none behind the first two MFMAs (the accumulators the
+    // first exponentials read were written by the last MFMAs of L)
+    static constexpr int gfirst(int m) {
+        if (m <= 2) return 0;
+        const int v = ((m - 2) * GOPS + (MG - 3)) / (MG - 2);
+        return v > GOPS ? GOPS : v;
+    }
+    // ... of L: [lfirst(m), lfirst(m + 1)); the last two gaps stay free (the packed lo numerators are MFMA operands right after L)
+    static constexpr int lfirst(int m) {
+        const int v = (m * LOPS + (ML - 3)) / (ML - 2);
+        return v > LOPS ? LOPS : v;
+    }
+};
+
+template <int CT>
+struct X3Regs {
+    f32x4 acc[2][CT];          // logits of the current subtile [row tile][column tile] (log2 domain)
+    unsigned wh[2][CT][4];     // [slot parity][ct][2 rt + h]: bf16 pair of hi halves (read by G one slot after it is written)
+    unsigned wl[CT][4];        // lo halves (written during L, read by the G right behind it)
+    float e[4 * CT][2];        // the fp32 numerators between the two conversions
+    float tmp[2];
+};
+
+// G-phase op V: v = 0, 1: exponentials of pair 0; then for pair j >= 1: exp, exp, hi conversion of pair j - 1 (a transcendental
+// result needs an independent instruction before its VALU consumer); last: hi conversion of pair P - 1
+template <int CT, int V>
+__device__ __forceinline__ void x3_gop(X3Regs<CT>& r, unsigned (&wh)[CT][4]) {
+    constexpr int P = 4 * CT, VOPS = 3 * P;
+    if constexpr (V < 2 || (V < VOPS - 1 && (V + 1) % 3 != 2)) {
+        constexpr int k = V < 2 ? 0 : (V + 1) / 3, which = V < 2 ? V : (V + 1) % 3;
+        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+        asm volatile("v_exp_f32 %0, %1" : "=v"(r.e[k][which]) : "v"(r.acc[rt][ct][2 * h + which]));
+    } else {
+        constexpr int k = V == VOPS - 1 ? P - 1 : (V + 1) / 3 - 1;
+        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wh[ct][2 * rt + h]) : "v"(r.e[k][0]), "v"(r.e[k][1]));
+    }
+}
+// L-phase op V (pair k = V / 5): the lo half of pair k = RNE bf16(e - float(hi)) - the difference is exact in fp32
+template <int CT, int V>
+__device__ __forceinline__ void x3_lop(X3Regs<CT>& r, const unsigned (&wh)[CT][4]) {
+    constexpr int k = V / 5, j = V % 5;
+    constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+    if constexpr (j == 0) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r.tmp[0]) : "v"(wh[ct][2 * rt + h]));
+    else if constexpr (j == 1) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r.tmp[1]) : "v"(wh[ct][2 * rt + h]));
+    else if constexpr (j == 2) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r.tmp[0]) : "v"(r.e[k][0]));
+    else if constexpr (j == 3) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r.tmp[1]) : "v"(r.e[k][1]));
+    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r.wl[ct][2 * rt + h]) : "v"(r.tmp[0]), "v"(r.tmp[1]));
+}
+template <int D, int CT, int M, int V = X3Geo<D, CT>::gfirst(M)>
+__device__ __forceinline__ void x3_gops(X3Regs<CT>& r, unsigned (&wh)[CT][4]) {
+    using XG = X3Geo<D, CT>;
+    if constexpr (M < XG::MG && V < XG::gfirst(M + 1)) {
+        x3_gop<CT, V>(r, wh);
+        x3_gops<D, CT, M, V + 1>(r, wh);
+    }
+}
+template <int D, int CT, int M, int V = X3Geo<D, CT>::lfirst(M)>
+__device__ __forceinline__ void x3_lops(X3Regs<CT>& r, const unsigned (&wh)[CT][4]) {
+    using XG = X3Geo<D, CT>;
+    if constexpr (M < XG::ML && V < XG::lfirst(M + 1)) {
+        x3_lop<CT, V>(r, wh);
+        x3_lops<D, CT, M, V + 1>(r, wh);
+    }
+}
+// all ops of one phase back to back (fill slot, drain: no MFMAs to hide them under)
+template <int D, int CT, int M = 0>
+__device__ __forceinline__ void x3_all_gops(X3Regs<CT>& r, unsigned (&wh)[CT][4]) {
+    if constexpr (M < X3Geo<D, CT>::MG) {
+        x3_gops<D, CT, M>(r, wh);
+        x3_all_gops<D, CT, M + 1>(r, wh);
+    }
+}
+template <int D, int CT, int M = 0>
+__device__ __forceinline__ void x3_all_lops(X3Regs<CT>& r, const unsigned (&wh)[CT][4]) {
+    if constexpr (M < X3Geo<D, CT>::ML) {
+        x3_lops<D, CT, M>(r, wh);
+        x3_all_lops<D, CT, M + 1>(r, wh);
+    }
+}
+
+template <int CT>
+__device__ __forceinline__ void x3_pack(const unsigned (&w)[CT][4], bf16x8 (&pb)[CT]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const u32x4 v = {w[ct][0], w[ct][1], w[ct][2], w[ct][3]};
+        pb[ct] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+// first MFMA position of logits step I: steps 0 .. 2 KSH - 1 are hi steps (2 CT MFMAs), the rest lo steps (CT MFMAs)
+template <int D, int CT>
+__host__ __device__ constexpr int x3_lpos(int I) {
+    constexpr int NH = 2 * X3Geo<D, CT>::KSH;
+    return I < NH ? I * 2 * CT : NH * 2 * CT + (I - NH) * CT;
+}
+
+// L(t): logits chain into r.acc with the lo halves of the PREVIOUS subtile's numerators (wh_prev -> r.wl) in its gaps
+template <int D, int CT, int OFF, int I, bool HAS_PREV, bool COLD>
+__device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf16x8 (&af)[X3Geo<D, CT>::NI],
+                                          const bf16x8 (&xh)[CT][X3Geo<D, CT>::KSH], const bf16x8 (&xl)[CT][X3Geo<D, CT>::KSH],
+                                          X3Regs<CT>& r, const unsigned (&wh_prev)[CT][4]) {
+    using XG = X3Geo<D, CT>;
+    if constexpr (I < XG::NI) {
+        if constexpr (I + X3_AD < XG::NI) pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);
+        lgkm_wait<(I + X3_AD < XG::NI ? X3_AD : XG::NI - 1 - I)>();
+        constexpr int s = I >> 1, rt = I & 1;
+        constexpr int M0 = x3_lpos<D, CT>(I);
+#define PCVAE_X3_L(POS, INIT, XB)                                                                          \
+        {                                                                                                  \
+            constexpr int cti_ = (POS) % CT;                                                               \
+            if constexpr (INIT) mfma_v0<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);              \
+            else mfma_v<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);                              \
+            if constexpr (HAS_PREV && !COLD) x3_lops<D, CT, M0 + (POS)>(r, wh_prev);                       \
+        }
+        if constexpr (s < XG::KSH) {
+            PCVAE_X3_L(0, s == 0, xh)
+            if constexpr (CT > 1) PCVAE_X3_L(1, s == 0, xh)
+            PCVAE_X3_L(CT, false, xl)
+            if constexpr (CT > 1) PCVAE_X3_L(CT + 1, false, xl)
+        } else {
+            PCVAE_X3_L(0, false, xh)
+            if constexpr (CT > 1) PCVAE_X3_L(1, false, xh)
+        }
+#undef PCVAE_X3_L
+        x3_logits<D, CT, OFF, I + 1, HAS_PREV, COLD>(lbase, a0, af, xh, xl, r, wh_prev);
+    }
+}
+
+struct X3Seam {             // all wave-uniform
+    const uint16_t* E;
+    int64_t n_stage;        // first item of the chunk to request
+    char* stage_buf;        // ring buffer it goes to (fenced slots: fast_stage)
+    unsigned stage_lds;     // the same buffer as an LDS byte address (steady-state seams: pipe_stage)
+    unsigned next_lbase;    // LDS address (minus the immediate) of the NEXT slot's subtile
+};
+
+// first MFMA position of gradient step DT (after the 2 CT row-sum MFMAs): hi tiles 2 CT MFMAs, lo tiles CT
+template <int D, int CT>
+__host__ __device__ constexpr int x3_gpos(int DT) {
+    constexpr int NDT = X3Geo<D, CT>::NDT;
+    return 2 * CT + (DT < NDT ? DT * 2 * CT : NDT * 2 * CT + (DT - NDT) * CT);
+}
+
+// G(t-1): gradient chain of the previous subtile (numerators pbh / pbl) with the exponentials + hi halves of subtile t
+// (r.acc -> r.e, wh_cur) in its gaps; in the middle: the seam and the first A fragments of the next slot
+template <int D, int CT, int OFFG, int OFFL_NEXT, int DT, bool HAS_G, int VM, bool COLD>
+__device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[X3Geo<D, CT>::NDTL],
+                                        s16x4 (&th)[X3Geo<D, CT>::NDTL], const bf16x8 (&pbh)[CT], const bf16x8 (&pbl)[CT],
+                                        X3Regs<CT>& r, unsigned (&wh_cur)[CT][4], f32x4 (&U)[X3Geo<D, CT>::NDT][CT],
+                                        const X3Seam& sm, const int wave_u, const int (&lane_off)[4], const int a0,
+                                        bf16x8 (&af)[X3Geo<D, CT>::NI]) {
+    using XG = X3Geo<D, CT>;
+    constexpr int NDTL = XG::NDTL, SEAM_AT = NDTL / 2;
+    if constexpr (DT < NDTL) {
+        if constexpr (DT == SEAM_AT) {
+            if constexpr (COLD) {
+                pipe_fence();
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (sm.n_stage >= 0) fast_stage<XG::DL, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
+                pipe_fence();
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+                pipe_stage<XG::DL>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
+            }
+            pipe_a_prologue<XG::DL, OFFL_NEXT, X3_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
+        }
+        if constexpr (HAS_G) {
+            constexpr int extra = (DT >= SEAM_AT && DT < SEAM_AT + X3_TD) ? X3_AD : 0;
+            if constexpr (DT + X3_TD < NDTL) tr_issue<XG::DL, OFFG, DT + X3_TD>(lbase_g, t0, tl[DT + X3_TD], th[DT + X3_TD]);
+            lgkm_wait<2 * ((DT + X3_TD < NDTL ? DT + X3_TD : NDTL - 1) - DT) + extra>();
+        }
+        const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+        constexpr int M0 = x3_gpos<D, CT>(DT);
+        constexpr int UD = DT % XG::NDT;
+#define PCVAE_X3_G(POS, PB)                                                                                \
+        {                                                                                                  \
+            if constexpr (HAS_G) mfma_a<COLD>(U[UD][(POS) % CT], a, PB[(POS) % CT]);                       \
+            if constexpr (!COLD) x3_gops<D, CT, M0 + (POS)>(r, wh_cur);                                    \
+        }
+        if constexpr (DT < XG::NDT) {
+            PCVAE_X3_G(0, pbh)
+            if constexpr (CT > 1) PCVAE_X3_G(1, pbh)
+            PCVAE_X3_G(CT, pbl)
+            if constexpr (CT > 1) PCVAE_X3_G(CT + 1, pbl)
+        } else {
+            PCVAE_X3_G(0, pbh)
+            if constexpr (CT > 1) PCVAE_X3_G(1, pbh)
+        }
+#undef PCVAE_X3_G
+        x3_grad<D, CT, OFFG, OFFL_NEXT, DT + 1, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pbh, pbl, r, wh_cur, U, sm, wave_u, lane_off,
+                                                                  a0, af);
+    } else if constexpr (COLD) {
+        pipe_fence();
+    }
+}
+
+// one slot.  PAR = parity of slot t: the hi numerators of subtile t go to r.wh[PAR], G(t-1) reads r.wh[PAR ^ 1]
+template <int D, int CT, int PAR, int OFFL, int OFFG, int OFFL_NEXT, bool HAS_G, int VM, bool COLD>
+__device__ __forceinline__ void x3_slot(const unsigned lbase_l, const unsigned lbase_g, const FastLane& L,
+                                        const bf16x8 (&xh)[CT][X3Geo<D, CT>::KSH], const bf16x8 (&xl)[CT][X3Geo<D, CT>::KSH],
+                                        bf16x8 (&af)[X3Geo<D, CT>::NI], X3Regs<CT>& r, f32x4 (&U)[X3Geo<D, CT>::NDT][CT],
+                                        f32x4 (&lsum)[CT], const X3Seam& sm, const int wave_u, const int (&lane_off)[4]) {
+    using XG = X3Geo<D, CT>;
+    if constexpr (COLD) pipe_fence();
+    x3_logits<D, CT, OFFL, 0, HAS_G, COLD>(lbase_l, L.a0, af, xh, xl, r, r.wh[PAR ^ 1]);
+    if constexpr (COLD && HAS_G) {      // fenced slots: nothing overlapped - the lo halves of the previous subtile now
+        pipe_fence();
+        x3_all_lops<D, CT>(r, r.wh[PAR ^ 1]);
+        asm volatile("s_nop 1" ::: "memory");
+    }
+    bf16x8 pbh[CT], pbl[CT];
+    x3_pack<CT>(r.wh[PAR ^ 1], pbh);
+    x3_pack<CT>(r.wl, pbl);
+    s16x4 tl[XG::NDTL], th[XG::NDTL];
+    if constexpr (HAS_G) {
+        pipe_tr_prologue<XG::DL, OFFG, X3_TD>(lbase_g, L.t0, tl, th);
+#define PCVAE_X3_ONES(POS, PB)                                                                             \
+        {                                                                                                  \
+            mfma_a<COLD>(lsum[(POS) % CT], L.ones, PB[(POS) % CT]);                                        \
+            if constexpr (!COLD) x3_gops<D, CT, (POS)>(r, r.wh[PAR]);                                      \
+        }
+        PCVAE_X3_ONES(0, pbh)
+        if constexpr (CT > 1) PCVAE_X3_ONES(1, pbh)
+        PCVAE_X3_ONES(CT, pbl)
+        if constexpr (CT > 1) PCVAE_X3_ONES(CT + 1, pbl)
+#undef PCVAE_X3_ONES
+    }
+    if constexpr (COLD) {               // exponentials + hi halves of this subtile, nothing overlapped
+        pipe_fence();
+        x3_all_gops<D, CT>(r, r.wh[PAR]);
+        asm volatile("s_nop 1" ::: "memory");
+    }
+    x3_grad<D, CT, OFFG, OFFL_NEXT, 0, HAS_G, VM, COLD>(lbase_g, L.t0, tl, th, pbh, pbl, r, r.wh[PAR], U, sm, wave_u, lane_off,
+                                                        L.a0, af);
+}
+
+// ---- fenced gradient of one subtile (drain, ragged tail): nothing overlapped
+template <int D, int CT, int DT = 0>
+__device__ __forceinline__ void x3_cold_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[X3Geo<D, CT>::NDTL],
+                                             s16x4 (&th)[X3Geo<D, CT>::NDTL], const bf16x8 (&pbh)[CT], const bf16x8 (&pbl)[CT],
+                                             f32x4 (&U)[X3Geo<D, CT>::NDT][CT]) {
+    using XG = X3Geo<D, CT>;
+    if constexpr (DT < XG::NDTL) {
+        if constexpr (DT + 2 < XG::NDTL) tr_issue<XG::DL, 0, DT + 2>(lbase_g, t0, tl[DT + 2], th[DT + 2]);
+        lgkm_wait<2 * ((DT + 2 < XG::NDTL ? DT + 2 : XG::NDTL - 1) - DT)>();
+        const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            mfma_a<true>(U[DT % XG::NDT][ct], a, pbh[ct]);
+            if constexpr (DT < XG::NDT) mfma_a<true>(U[DT % XG::NDT][ct], a, pbl[ct]);
+        }
+        x3_cold_grad<D, CT, DT + 1>(lbase_g, t0, tl, th, pbh, pbl, U);
+    }
+}
+template <int D, int CT>
+__device__ __forceinline__ void x3_cold_gradient(const unsigned lbase_g, const FastLane& L, const bf16x8 (&pbh)[CT],
+                                                 const bf16x8 (&pbl)[CT], f32x4 (&U)[X3Geo<D, CT>::NDT][CT], f32x4 (&lsum)[CT]) {
+    using XG = X3Geo<D, CT>;
+    s16x4 tl[XG::NDTL], th[XG::NDTL];
+    pipe_fence();
+    tr_issue<XG::DL, 0, 0>(lbase_g, L.t0, tl[0], th[0]);
+    tr_issue<XG::DL, 0, 1>(lbase_g, L.t0, tl[1], th[1]);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        mfma_a<true>(lsum[ct], L.ones, pbh[ct]);
+        mfma_a<true>(lsum[ct], L.ones, pbl[ct]);
+    }
+    x3_cold_grad<D, CT>(lbase_g, L.t0, tl, th, pbh, pbl, U);
+    pipe_fence();
+}
+
+// one subtile on its own (ragged tail): logits, bound check, numerators, gradient - nothing overlapped, every MFMA fenced
+template <int D, int CT, int I = 0>
+__device__ __forceinline__ void x3_cold_logits(const unsigned lbase, const int a0, bf16x8 (&af)[X3Geo<D, CT>::NI],
+                                               const bf16x8 (&xh)[CT][X3Geo<D, CT>::KSH], const bf16x8 (&xl)[CT][X3Geo<D, CT>::KSH],
+                                               f32x4 (&acc)[2][CT]) {
+    using XG = X3Geo<D, CT>;
+    if constexpr (I < XG::NI) {
+        pipe_a_issue<XG::DL, 0, I>(lbase, a0, af[I]);
+        lgkm_wait<0>();
+        constexpr int s = I >> 1, rt = I & 1;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            if constexpr (s == 0) mfma_v0<true>(acc[rt][ct], af[I], xh[ct][0]);
+            else mfma_v<true>(acc[rt][ct], af[I], xh[ct][s % XG::KSH]);
+            if constexpr (s < XG::KSH) mfma_v<true>(acc[rt][ct], af[I], xl[ct][s]);
+        }
+        x3_cold_logits<D, CT, I + 1>(lbase, a0, af, xh, xl, acc);
+    }
+}
+__device__ __forceinline__ unsigned x3_pack_rne(float a, float b) {   // two fp32 -> packed bf16 pair (RNE), a in the low half
+    unsigned r;
+    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int D, int CT>
+__device__ __forceinline__ void x3_solo(const unsigned lbase, const int64_t n0, const int64_t N, const FastLane& L,
+                                        const bf16x8 (&xh)[CT][X3Geo<D, CT>::KSH], const bf16x8 (&xl)[CT][X3Geo<D, CT>::KSH],
+                                        f32x4 (&U)[X3Geo<D, CT>::NDT][CT], f32x4 (&lsum)[CT]) {
+    using XG = X3Geo<D, CT>;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    f32x4 acc[2][CT];
+    bf16x8 af[XG::NI];
+    pipe_fence();
+    x3_cold_logits<D, CT>(lbase, L.a0, af, xh, xl, acc);
+    pipe_fence();
+    bf16x8 pbh[CT], pbl[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        u32x4 wh, wl;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * h;
+                const bool ok0 = n0 + 16 * rt + 4 * L.g + i < N, ok1 = n0 + 16 * rt + 4 * L.g + i + 1 < N;
+                const float e0 = ok0 ? __builtin_amdgcn_exp2f(acc[rt][ct][i]) : 0.f;
+                const float e1 = ok1 ? __builtin_amdgcn_exp2f(acc[rt][ct][i + 1]) : 0.f;
+                const unsigned hi = x3_pack_rne(e0, e1);
+                wh[2 * rt + h] = hi;
+                wl[2 * rt + h] = x3_pack_rne(e0 - __uint_as_float(hi << 16), e1 - __uint_as_float(hi & 0xffff0000u));
+            }
+        pbh[ct] = __builtin_bit_cast(bf16x8, wh);
+        pbl[ct] = __builtin_bit_cast(bf16x8, wl);
+    }
+    asm volatile("s_nop 1" ::: "memory");
+    x3_cold_gradient<D, CT>(lbase, L, pbh, pbl, U, lsum);
+}
+
+// rx row fragments: xh = RNE bf16(rx * log2 e), xl = RNE bf16(rx * log2 e - xh), laid out like the bf16 kernels' B operand
+template <int D>
+__device__ __forceinline__ void x3_load_x(const float* __restrict__ rx, const int64_t row, const int g, bf16x8 (&xh)[D / 32],
+                                          bf16x8 (&xl)[D / 32]) {
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s) {
+        const int c0 = 8 * fchunk<2 * D>(s, g);   // hi-half chunk of k-step s (the lo k-step s + D/32 multiplies the same columns)
+        const float4 v0 = *reinterpret_cast<const float4*>(rx + row * D + c0);
+        const float4 v1 = *reinterpret_cast<const float4*>(rx + row * D + c0 + 4);
+        const float v[8] = {v0.x * kLog2e, v0.y * kLog2e, v0.z * kLog2e, v0.w * kLog2e,
+                            v1.x * kLog2e, v1.y * kLog2e, v1.z * kLog2e, v1.w * kLog2e};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const __bf16 h = (__bf16)v[j];
+            xh[s][j] = h;
+            xl[s][j] = (__bf16)(v[j] - (float)h);
+        }
+    }
+}
+
+template <int D, int CT>
+__global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p) {
+    using XG = X3Geo<D, CT>;
+    using GL = typename XG::GL;
+    constexpr int CB = 16384, NW = 4, ROWS = XG::ROWS, TR = XG::TR, NB = XG::NB, PF = XG::PF, DL = XG::DL;
+    static_assert(TR % 2 == 0, "the numerator parity must repeat every trip");
+    static_assert(XG::gfirst(XG::MG) == XG::GOPS && XG::lfirst(XG::ML - 2) == XG::LOPS, "every numerator op has a gap");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int nrb = (int)((p.R + ROWS - 1) / ROWS);
+    const int split = logical / nrb, rb = logical % nrb;
+    if (p.safe_flags[(int)(((int64_t)rb * ROWS) / ROWS_WG)] != 0) return;   // large |rx|: the exact f32 kernel handles this block
+    const int t_beg = split * p.tiles_per_split;
+    const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
+    const int64_t nbase = (int64_t)t_beg * 32;
+    int T = (int)min((int64_t)(t_end - t_beg), (p.N - nbase) / GL::BNF);    // full 32-item subtiles = ring chunks = slots
+    T = max(T, 0);
+
+    const int64_t rw = (int64_t)rb * ROWS + wave * 16 * CT;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int lane_off[4];
+    fast_lane_off<DL, NW>(lane, wave, lane_off);
+#pragma unroll
+    for (int c0 = 0; c0 <= PF; ++c0)   // requests beyond the last chunk repeat it: a constant number of chunks in flight
+        if (T > 0) fast_stage<DL, NW>(p.E, nbase + (int64_t)min(c0, T - 1) * GL::BNF, smem + c0 * CB, wave_u, lane_off);
+
+    bf16x8 xh[CT][XG::KSH], xl[CT][XG::KSH];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int64_t r = rw + 16 * ct + c;
+        x3_load_x<D>(p.rx, r < p.R ? r : p.R - 1, g, xh[ct], xl[ct]);
+    }
+    f32x4 U[XG::NDT][CT];
+    f32x4 lsum[CT];
+#pragma unroll
+    for (int dt = 0; dt < XG::NDT; ++dt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) U[dt][ct][i] = 0.f;
+            asm volatile("" : "+a"(U[dt][ct]));
+        }
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lsum[ct][i] = 0.f;
+        asm volatile("" : "+a"(lsum[ct]));
+    }
+    const FastLane L = fast_lane<DL>(lane);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    X3Regs<CT> r;
+    bf16x8 af[XG::NI];
+
+    auto lds_of = [&](int t) { return lds0 + (unsigned)((t % NB) * CB); };
+    auto seam_of = [&](int t) {          // the seam slot t carries: request chunk t + 1 + PF (beyond the end: the last one again)
+        X3Seam sm;
+        sm.E = p.E;
+        const int cs = t + 1 + PF;
+        sm.n_stage = nbase + (int64_t)min(cs, T - 1) * GL::BNF;
+        sm.stage_buf = smem + (cs % NB) * CB;
+        sm.stage_lds = lds0 + (unsigned)((cs % NB) * CB);
+        sm.next_lbase = lds0;
+        return sm;
+    };
+
+    int t = 0;
+    if (T > 0) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PF * 4) : "memory");   // chunk 0 landed
+        pipe_a_prologue<DL, 0, X3_AD>(lds0, L.a0, af);
+        {   // slot 0: nothing to drain yet
+            X3Seam sm = seam_of(0);
+            sm.next_lbase = lds_of(T > 1 ? 1 : 0);
+            x3_slot<D, CT, 0, 0, 0, 0, false, 0, true>(lds0, lds0, L, xh, xl, af, r, U, lsum, sm, wave_u, lane_off);
+        }
+        t = 1;
+        // steady state: TR slots per trip, every LDS offset an immediate
+        for (; t + TR <= T; t += TR) {
+#define PCVAE_X3S(UU)                                                                                                     \
+            {                                                                                                             \
+                constexpr int TL = 1 + UU, TG = UU, TN = 2 + UU;                                                          \
+                constexpr int OL = (TL % NB) * CB, OG = (TG % NB) * CB, ON = (TN % NB) * CB;                              \
+                X3Seam s2 = seam_of(t + UU);                                                                              \
+                s2.stage_lds = lds0 + ((TL + 1 + PF) % NB) * CB;   /* t = 1 (mod TR): a constant */                       \
+                x3_slot<D, CT, TL & 1, OL, OG, ON, true, (PF - 1) * 4, false>(lds0, lds0, L, xh, xl, af, r, U, lsum, s2, wave_u, \
+                                                                           lane_off);                                     \
+            }
+            PCVAE_X3S(0) PCVAE_X3S(1) PCVAE_X3S(2) PCVAE_X3S(3) PCVAE_X3S(4) PCVAE_X3S(5)
+#undef PCVAE_X3S
+            pipe_fence();  // latch
+        }
+        // at most TR - 1 slots are left: fenced slots with runtime ring offsets (their seams drain the ring: vmcnt(0))
+        for (; t < T; ++t) {
+            X3Seam s2 = seam_of(t);
+            s2.next_lbase = lds_of(t + 1 < T ? t + 1 : t);
+            if (t & 1) x3_slot<D, CT, 1, 0, 0, 0, true, 0, true>(lds_of(t), lds_of(t - 1), L, xh, xl, af, r, U, lsum, s2, wave_u, lane_off);
+            else x3_slot<D, CT, 0, 0, 0, 0, true, 0, true>(lds_of(t), lds_of(t - 1), L, xh, xl, af, r, U, lsum, s2, wave_u, lane_off);
+        }
+        {   // drain: the lo halves of the last subtile's numerators, then its gradient chain
+            bf16x8 pbh[CT], pbl[CT];
+            pipe_fence();
+            if ((T - 1) & 1) { x3_all_lops<D, CT>(r, r.wh[1]); x3_pack<CT>(r.wh[1], pbh); }
+            else { x3_all_lops<D, CT>(r, r.wh[0]); x3_pack<CT>(r.wh[0], pbh); }
+            x3_pack<CT>(r.wl, pbl);
+            asm volatile("s_nop 1" ::: "memory");
+            x3_cold_gradient<D, CT>(lds_of(T - 1), L, pbh, pbl, U, lsum);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may outlive its wave
+    // ---- tail: the ragged last subtile of the catalog (and ranges shorter than one chunk), staged synchronously
+    for (int tt = t_beg + T; tt < t_end; tt += 4) {
+        __syncthreads();
+        fast_stage_tail<DL, NW>(p.E, p.N, (int64_t)tt * 32, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int nsub = min(4, t_end - tt);
+        for (int st = 0; st < nsub; ++st) x3_solo<D, CT>(lds0 + st * GL::ST, (int64_t)(tt + st) * 32, p.N, L, xh, xl, U, lsum);
+    }
+    pipe_fence();
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const float l = lsum[ct][0];
+        const int64_t row = rw + 16 * ct + c;
+        if (row < p.R) {
+            const int64_t o = (int64_t)split * p.R + row;
+            if (g == 0) { p.pm[o] = 0.f; p.pl[o] = l; }
+#pragma unroll
+            for (int dt = 0; dt < XG::NDT; ++dt)
+                *reinterpret_cast<float4*>(p.pU + o * D + 16 * dt + 4 * g) =
+                    make_float4(U[dt][ct][0], U[dt][ct][1], U[dt][ct][2], U[dt][ct][3]);
+        }
+    }
+}
+
+// one wave per row: sum the split partials (all max-free: pm = 0), exact fp32 target logit and target row from the fp32 table
+template <int D>
+__global__ void __launch_bounds__(256) catalog_ce_merge_x3_kernel(CatParamsB p, const float* __restrict__ Ef,
+                                                                  float* __restrict__ nll, float* __restrict__ lse,
+                                                                  float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.R) return;
+    if (p.safe_flags[r / ROWS_WG] != 0) return;   // this row block ran the exact f32 kernel (its merge writes the row)
+    float L = lane < p.nsplit ? p.pl[(int64_t)lane * p.R + r] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o, 64);
+    const int64_t t = p.target[r];
+    const bool t_ok = t >= 0 && t < p.N;
+    float zt = 0.f;   // the k-ordered fmaf chain of the f32 kernel / oracle
+    if (t_ok)
+        for (int k = 0; k < D; ++k) zt = fmaf(Ef[t * D + k], p.rx[r * D + k], zt);
+    const float lse_r = log2f(L) * kLn2;
+    if (lane == 0) {
+        nll[r] = t_ok ? lse_r - zt : NAN;
+        if (lse) lse[r] = lse_r;
+    }
+    if (dx) {
+        const float invL = 1.f / L;
+        for (int d = lane; d < D; d += 64) {
+            float u = 0.f;
+            for (int j = 0; j < p.nsplit; ++j) u += p.pU[((int64_t)j * p.R + r) * D + d];
+            dx[r * D + d] = t_ok ? u * invL - Ef[t * D + d] : NAN;
+        }
+    }
+}

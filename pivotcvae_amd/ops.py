@@ -567,7 +567,7 @@ def _as_table(E):
 
 
 BF16_DIMS = (64, 128, 256)  # the bf16 MFMA kernels exist for these widths; narrower tables are tiny: exact f32 path
-X3_DIMS = ()                # widths the bf16x3 (fp32-equivalent) kernel exists for
+X3_DIMS = (128,)            # widths the bf16x3 (fp32-equivalent) kernel exists for
 
 
 def sparse_ce_applies(keep_prob, N):

@@ -1,0 +1,183 @@
+"""-m gpu: the bf16x3 catalog CE kernel (PCVAE_PREC_BF16X3, D = 128): fp32-equivalent results on the bf16 matrix cores.
+
+Both operands of both contractions are split into bf16 hi + lo halves and every product is three bf16 MFMAs
+(hi*hi + hi*lo + lo*hi) with fp32 accumulation.  Two references:
+  * the fp32 C oracle (oracle/catalog_oracle.c) at THE SAME tolerances the exact f32-MFMA kernel is held to
+    (tests/test_hip_kernels.py::test_catalog_ce_full_softmax: lse / nll 2e-6, gradient 2e-5) - the claim "fp32-equivalent";
+  * an emulation of the kernel's own arithmetic on the CPU, which pins indexing / ring / fill / drain / tail logic on
+    shapes where those paths are most of the work.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import catalog_oracle as co
+from oracle import pivotcvae_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LOG2E = np.float32(1.4426950408889634)
+LN2 = 0.6931471805599453
+D = 128
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from pivotcvae_amd import ops as _ops
+    assert D in _ops.X3_DIMS
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def split(x):
+    h = x.to(torch.bfloat16).to(torch.float32)
+    return h, (x - h).to(torch.bfloat16).to(torch.float32)
+
+
+def emulate_x3(rx, E, tgt):
+    """the kernel's arithmetic: log2-domain logits from the three hi/lo products, raw exp2, numerators split into bf16 hi + lo,
+    row sums and gradient from those 16-bit numerators; target logit and target row in exact fp32"""
+    xh, xl = split(rx * LOG2E)
+    eh, el = split(E)
+    xh, xl, eh, el = xh.double(), xl.double(), eh.double(), el.double()
+    s2 = (xh @ eh.t() + xl @ eh.t() + xh @ el.t()).float()
+    ph, pl = split(torch.exp2(s2))
+    ph, pl = ph.double(), pl.double()
+    L = (ph + pl).sum(1, keepdim=True)
+    lse = (torch.log2(L) * LN2).squeeze(1)
+    nll = lse - (rx.double() * E.double()[tgt]).sum(1)
+    dx = (ph @ eh + pl @ eh + ph @ el) / L - E.double()[tgt]
+    return nll.float(), lse.float(), dx.float()
+
+
+def run(ops, rx, E, tgt, **kw):
+    from pivotcvae_amd._hip import PREC_BF16X3
+    return ops.catalog_ce_raw(rx.to(DEV), ops.CatalogTable(E.to(DEV)), tgt.to(DEV), prec=PREC_BF16X3, **kw)
+
+
+# tiles per catalog range T = N // 32 (one range: small catalogs): 0 (tail only), 1 (fill + drain), 2..6 (fenced slots),
+# 7.. (steady-state trips of 6), ragged tails, row counts around the 128-row workgroup and the 256-row flag blocks
+SHAPES = [(35, 20), (130, 32), (64, 33), (257, 64), (100, 100), (128, 224), (256, 225), (300, 4099), (257, 9000), (64, 333),
+          (513, 2048 + 96), (100, 300000), (1, 70000), (129, 40001)]
+
+
+@pytest.mark.parametrize("R,N", SHAPES)
+def test_x3_ce_is_fp32_equivalent(ops, R, N):
+    rx, E = rnd(R, D, seed=1, scale=2.0), orc.normalize_rows(rnd(N, D, seed=2))
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    tgt[0], tgt[-1] = 0, N - 1
+    nll, lse, dx = run(ops, rx, E, tgt)
+    # (1) against the fp32 oracle, at the f32 kernel's own tolerances
+    if R * N <= 40_000_000:
+        wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+        np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    # (2) against its own arithmetic (fp32 accumulation order is the only difference)
+    en, el, ed = emulate_x3(rx, E, tgt)
+    torch.testing.assert_close(lse.cpu(), el, rtol=1e-6, atol=2e-6)
+    torch.testing.assert_close(nll.cpu(), en, rtol=1e-6, atol=3e-6)
+    assert (dx.cpu() - ed).abs().max() < 2e-6
+    # loss-only call: same kernel, same numbers
+    nll2, lse2, none = run(ops, rx, E, tgt, want_dx=False)
+    assert none is None and torch.equal(nll2, nll) and torch.equal(lse2, lse)
+
+
+def test_x3_peaked_rows_and_large_norms(ops):
+    """|rx| = 60: the logit bound (60 log2 e = 86.6 <= 90) still admits the max-free kernel, exp2 spans 2^+-86; rows scaled past
+    the bound flag their 256-row block, which then runs the exact f32 kernel (blocks 0 and 2 stay on bf16x3, block 1 does not)."""
+    R, N = 700, 8192
+    E = orc.normalize_rows(rnd(N, D, seed=2))
+    rx = rnd(R, D, seed=1, scale=0.1)
+    rx[3] = E[N - 5] * 60.0
+    rx[200] = -E[17] * 60.0
+    rx[255] = E[0] * 59.0
+    rx[300] = E[4000] * 75.0      # block 1: over the bound
+    rx[511] = E[4001] * 300.0
+    rx[600] = E[N - 1] * 60.0
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    tgt[3], tgt[300] = N - 5, 4000
+    nll, lse, dx = run(ops, rx, E, tgt)
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+    # nll = lse - z_t cancels on peaked rows (lse = 60 +- 1 ulp): absolute error 2e-6 of the lse's magnitude
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=2e-6 * 62.0)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    assert torch.isfinite(dx).all()
+
+
+def test_x3_masked_calls_run_the_exact_kernel(ops):
+    from tests import philox_ref
+    R, N = 70, 1000
+    rx, E = rnd(R, D, seed=4, scale=2.0), orc.normalize_rows(rnd(N, D, seed=5))
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(6))
+    keep = (torch.rand(R, N, generator=torch.Generator().manual_seed(7)) < 0.2).to(torch.uint8)
+    nll, _, dx = run(ops, rx, E, tgt, keep_mask=keep.to(DEV))
+    wn, _, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy(), keep.numpy())
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+
+
+def test_x3_full_size_catalog_properties(ops):
+    """N = 1M (the north-star table), chunked fp64 reference computed by torch on the device (an independent path)."""
+    N, R = 1_000_000, 200
+    g = torch.Generator(device=DEV).manual_seed(5)
+    E = torch.rand(N, D, device=DEV, generator=g) * 2 - 1
+    E = E / E.norm(dim=1, keepdim=True)
+    rx = (torch.rand(R, D, device=DEV, generator=g) * 2 - 1) * 1.5
+    tgt = torch.randint(0, N, (R,), device=DEV, generator=g)
+    from pivotcvae_amd._hip import PREC_BF16X3
+    nll, lse, dx = ops.catalog_ce_raw(rx, ops.CatalogTable(E), tgt, prec=PREC_BF16X3)
+    m = torch.full((R,), -float("inf"), device=DEV, dtype=torch.float64)
+    ssum = torch.zeros(R, device=DEV, dtype=torch.float64)
+    num = torch.zeros(R, D, device=DEV, dtype=torch.float64)
+    for c0 in range(0, N, 125_000):
+        lg = rx.double() @ E[c0:c0 + 125_000].double().t()
+        mn = torch.maximum(m, lg.max(1)[0])
+        sc = torch.exp(m - mn)
+        pe = torch.exp(lg - mn[:, None])
+        ssum = ssum * sc + pe.sum(1)
+        num = num * sc[:, None] + pe @ E[c0:c0 + 125_000].double()
+        m = mn
+    want_lse = m + torch.log(ssum)
+    zt = (rx.double() * E[tgt].double()).sum(1)
+    want_dx = num / ssum[:, None] - E[tgt].double()
+    torch.testing.assert_close(lse.double(), want_lse, rtol=2e-6, atol=2e-6)
+    torch.testing.assert_close(nll.double(), want_lse - zt, rtol=2e-6, atol=3e-6)
+    assert (dx.double() - want_dx).abs().max() < 2e-5 * want_dx.abs().max()
+    assert float((dx + E[tgt]).norm(dim=1).max()) <= 1.0 + 1e-5
+
+
+def test_x3_model_level_elbo_and_gradients(ops):
+    """One train step of a D = 128 model with the catalog in bf16x3 vs the same step in exact f32: ELBO terms 1e-6, every
+    parameter gradient to 2e-5 of its scale (the north_star tolerance is 1e-4 on the ELBO)."""
+    import pivotcvae_amd as pa
+    S, Z, N, NU, B, H, HP = 5, 8, 6007, 50, 200, 64, 32
+    C = S + 1
+    torch.manual_seed(0)
+    e_raw, u_raw = orc.synthetic_tables(N, NU, D, seed=0)
+    st = dict(enc=[S * D + C + D, H, H], psm=[Z + C + D, H, H, D], scm=[Z + C + 2 * D, H, H, (S - 1) * D], prior=[C + D, HP, HP])
+    g = torch.Generator().manual_seed(1)
+    s = torch.randint(0, N, (B, S), generator=g).to(DEV)
+    u = torch.randint(0, NU, (B, 1), generator=g).to(DEV)
+    r = (torch.rand(B, S, generator=g) < 0.5).float().to(DEV)
+    eps = torch.randn(B, Z, generator=torch.Generator().manual_seed(2)).to(DEV)
+    res = {}
+    for prec in ("f32", "bf16x3"):
+        torch.manual_seed(0)
+        m = pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"](torch.nn.Embedding.from_pretrained(e_raw), torch.nn.Embedding.from_pretrained(u_raw),
+                                                  S, D, Z, C, st["enc"], st["psm"], st["scm"], st["prior"], False, DEV)
+        m.set_catalog_precision(prec)
+        loss, rec, kld = m.loss(s, r, u, 0.001, eps=eps)
+        loss.backward()
+        res[prec] = ([loss.item(), rec.item(), kld.item()],
+                     {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    np.testing.assert_allclose(res["bf16x3"][0], res["f32"][0], rtol=1e-6)
+    assert res["f32"][1].keys() == res["bf16x3"][1].keys() and len(res["f32"][1]) >= 16
+    for k, gf in res["f32"][1].items():
+        gx = res["bf16x3"][1][k]
+        assert (gx - gf).abs().max() <= 2e-5 * gf.abs().max() + 1e-9, k
