@@ -182,6 +182,18 @@ int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo
 int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
                          float e_max_norm, int64_t* idx, float* best, void* ws, size_t ws_bytes, pcvae_stream_t stream);
 
+/* K5, sparse form for n_neg << N                        train_generative.py:36-44,59 (downsample(pred, slates, 1000) + CE)
+ *     Same result as pcvae_catalog_ce with keep_prob < 1, but only the KEPT items of a row are touched: masked-out logits are
+ *     the constant 0 (exp(0) = 1 each in the denominator, no gradient), so the kernel enumerates the kept set of a row
+ *     directly - geometric gap sampling, lane l of the row's wave walks catalog segment l, gaps floor(ln U / ln(1 - keep_prob))
+ *     with U from Philox4x32-10 keyed by (seed, row_offset + r, lane, draw): i.i.d. Bernoulli(keep_prob) per item, the
+ *     target always kept, independent of sharding - gathers those rows of the fp32 table and runs an online softmax over
+ *     them plus the closed-form (N - n_kept) * exp(0) term.  Exact fp32; HBM-bound (~R * keep_prob * N * 4 D bytes).
+ *     NOTE: this is a different Philox stream from pcvae_catalog_ce's per-item mask (same distribution).            */
+int pcvae_catalog_ce_sparse(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
+                            float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
+                            pcvae_stream_t stream);
+
 /* K10 sampled pivot                                     models/pivotcvae.py:349-351, 371-373
  *     idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) over the whole catalog, drawn with the Gumbel-max trick
  *     (argmax_n log sigmoid(s_n) - log(-log u_n), u_n = Philox(seed, row_offset + r, n)); the reference's

@@ -570,9 +570,39 @@ BF16_DIMS = (64, 128, 256)  # the bf16 MFMA kernels exist for these widths; narr
 X3_DIMS = (128,)            # widths the bf16x3 (fp32-equivalent) kernel exists for
 
 
+SPARSE_MAX_KEEP_PROB = 0.03   # above this the dense masked kernel (one pass over the catalog) is the cheaper one
+
+
 def sparse_ce_applies(keep_prob, N):
-    """does catalog_ce take the sparse (kept rows only) path for this keep probability?"""
-    return False
+    """does catalog_ce take the sparse (kept rows only) path for this keep probability?  (train_generative.py:44: n_neg = 1000)"""
+    return 0.0 < keep_prob <= SPARSE_MAX_KEEP_PROB and N < 2 ** 31 - 1
+
+
+def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, want_dx=True):
+    """catalog_ce_raw for keep_prob << 1: only the kept rows of the fp32 table are read (pcvae_catalog_ce_sparse).
+    -> (nll [R], lse [R], dx [R, D] or None).  Exact fp32 whatever the table's precision mode is."""
+    table = _as_table(table)
+    require_device(rx, table.weight, target)
+    rx = _c2d(rx).contiguous()
+    R, D0 = rx.shape
+    E, D = table.padded()
+    rx = _pad_cols(rx, D)
+    N = E.shape[0]
+    target = target.reshape(-1).to(torch.int64).contiguous()
+    if target.numel() != R:
+        raise ValueError("catalog_ce: one target per row expected")
+    nll = torch.empty(R, dtype=F32, device=rx.device)
+    lse = torch.empty(R, dtype=F32, device=rx.device)
+    dx = torch.empty(R, D, dtype=F32, device=rx.device) if want_dx else None
+    timing = CATALOG_CE_TIMING
+    tok = timing[0]() if timing else None
+    check(lib().pcvae_catalog_ce_sparse(ptr(rx, F32), R, ptr(E, F32), N, D, ptr(target), float(keep_prob), int(seed),
+                                        int(row_offset), ptr(nll, F32), ptr(lse, F32), ptr(dx), stream()), "catalog_ce_sparse")
+    if timing:
+        timing[1](tok)
+    if dx is not None and D != D0:
+        dx = dx[:, :D0]
+    return nll, lse, dx
 
 
 def effective_precision(prec, D):

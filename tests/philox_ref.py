@@ -41,3 +41,42 @@ def keep_mask(R, N, keep_prob, seed, row_offset=0):
     th = keep_prob * 4294967296.0
     thresh = 0 if th <= 0 else (0xFFFFFFFF if th >= 4294967295.0 else int(th))
     return (u < np.uint32(thresh)).astype(np.uint8)
+
+
+def sparse_keep_mask(R, N, keep_prob, seed, row_offset=0):
+    """uint8 [R, N]: the kept set pcvae_catalog_ce_sparse enumerates (target column not forced).
+
+    Lane l (0..63) of a row walks catalog segment [l * seg, min(N, (l + 1) * seg)), seg = ceil(N / 64), with gaps
+    floor(ln U / ln(1 - p)); Philox call j of (row, lane) has counter (row_lo, row_hi, lane + 64 j, "SPAR") and yields the
+    gaps 2 j (words x, y) and 2 j + 1 (words z, w); U = (2 u52 + 1) / 2^53 with u52 = x << 20 | y >> 12."""
+    keep_prob = float(np.float32(keep_prob))     # the C ABI takes a float
+    inv_log_q = 1.0 / np.log1p(-keep_prob)
+    seg = (N + 63) // 64
+    rows = np.arange(R, dtype=np.uint64) + np.uint64(row_offset)
+    c0 = np.broadcast_to((rows & MASK32).astype(np.uint32)[:, None], (R, 64))
+    c1 = np.broadcast_to((rows >> np.uint64(32)).astype(np.uint32)[:, None], (R, 64))
+    lane = np.broadcast_to(np.arange(64, dtype=np.int64)[None, :], (R, 64))
+    hi = np.minimum(N, (lane + 1) * seg)
+    pos = lane * seg - 1
+    done = pos + 1 >= hi
+    out = np.zeros((R, N), np.uint8)
+    rr = np.broadcast_to(np.arange(R)[:, None], (R, 64))
+
+    def gaps(a, b):
+        u52 = (a.astype(np.uint64) << np.uint64(20)) | (b.astype(np.uint64) >> np.uint64(12))
+        U = (2 * u52 + 1).astype(np.float64) * 2.0 ** -53
+        g = np.floor(np.log(U) * inv_log_q)
+        return np.where(g < 4.0e18, g, 4.0e18).astype(np.int64)
+
+    call = 0
+    while not done.all():
+        x, y, z, w = philox4x32_10(c0, c1, (lane + 64 * call).astype(np.uint32), np.uint32(0x53504152), seed & 0xFFFFFFFF,
+                                   (seed >> 32) & 0xFFFFFFFF)
+        call += 1
+        for g in (gaps(x, y), gaps(z, w)):
+            npos = np.where(g >= hi - pos, hi, pos + 1 + g)
+            pos = np.where(done, pos, npos)
+            done = done | (pos >= hi)
+            live = ~done
+            out[rr[live], pos[live]] = 1
+    return out

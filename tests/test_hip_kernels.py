@@ -320,6 +320,72 @@ def test_catalog_ce_explicit_mask(ops, R, N, D):
     np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
 
 
+SPARSE_CASES = [(35, 5000, 16, 0.01), (70, 50000, 128, 0.002), (33, 20000, 64, 0.02), (20, 3000, 256, 0.3), (40, 100, 32, 0.05),
+                (9, 40, 128, 0.5), (10, 50000, 64, 0.1), (12, 3000, 8, 0.05), (5, 1, 16, 0.5), (70, 63, 32, 0.2)]
+
+
+@pytest.mark.parametrize("R,N,D,p", SPARSE_CASES)
+def test_catalog_ce_sparse_is_the_documented_stream(ops, R, N, D, p):
+    """The sparse path (n_neg << N: only the kept rows are read) against the oracle's dense masked CE with the SAME kept set,
+    rebuilt on the host from the documented Philox stream (tests/philox_ref.sparse_keep_mask): exact-parity check, at the f32
+    kernel's tolerances.  Cases: every width incl. a padded one (D = 8), more kept items than one LDS batch holds
+    (50000 x 0.1 > 2048), segments shorter than a lane (N < 64), N = 1, targets first / last."""
+    rx, E = rnd(R, D, seed=8, scale=2.0), unit_rows(N, D, seed=9)
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(10))
+    tgt[0], tgt[-1] = 0, N - 1
+    seed, off = 1234567, 1000
+    nll, lse, dx = ops.catalog_ce_sparse_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), p, seed=seed, row_offset=off)
+    keep = philox_ref.sparse_keep_mask(R, N, p, seed, off)
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy(), keep)
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    nll2, lse2, none = ops.catalog_ce_sparse_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), p, seed=seed, row_offset=off, want_dx=False)
+    assert none is None and torch.equal(nll2, nll) and torch.equal(lse2, lse)
+    # a shard of the rows draws what the whole batch drew for those rows (row_offset = global row index)
+    h = R // 2
+    if h:
+        nll3, _, dx3 = ops.catalog_ce_sparse_raw(rx[h:].to(DEV), E.to(DEV), tgt[h:].to(DEV), p, seed=seed, row_offset=off + h)
+        assert torch.equal(nll3, nll[h:]) and torch.equal(dx3, dx[h:])
+
+
+def test_catalog_ce_sparse_kept_counts(ops):
+    """Reads the kept COUNT of every row back out of the kernel: all table rows equal e0 and x = ln(3) e0, so every kept logit is
+    ln 3 and L = N + 2 n_kept exactly.  Counts equal the host restatement's row by row, and are Binomial(N, p) in mean and variance."""
+    R, N, D, p = 600, 100_000, 32, 0.01
+    e0 = torch.zeros(D)
+    e0[3] = 1.0
+    E = e0.repeat(N, 1)
+    rx = (np.log(3.0) * e0).repeat(R, 1).float()
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(1))
+    _, lse, _ = ops.catalog_ce_sparse_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), p, seed=99, row_offset=7, want_dx=False)
+    L = torch.exp(lse.double().cpu())
+    kept = ((L - N) / 2.0).round().long().numpy()
+    assert np.abs((L - N) / 2.0 - kept).max() < 0.2
+    keep = philox_ref.sparse_keep_mask(R, N, p, 99, 7)
+    keep[np.arange(R), tgt.numpy()] = 1
+    assert np.array_equal(kept, keep.sum(1))
+    mean, var = kept.mean(), kept.var()
+    assert abs(mean - (N * p + 1)) < 4 * (N * p / R) ** 0.5 + 1 and 0.8 * N * p < var < 1.25 * N * p
+
+
+def test_catalog_ce_routes_small_keep_prob_to_the_sparse_path(ops):
+    R, N, D = 40, 30000, 64
+    rx, E = rnd(R, D, seed=8, scale=2.0), unit_rows(N, D, seed=9)
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(10))
+    p = 1000.0 / N * 0.5
+    assert ops.sparse_ce_applies(p, N) and not ops.sparse_ce_applies(0.2, N)
+    a = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), keep_prob=p, seed=3, row_offset=5)
+    b = ops.catalog_ce_sparse_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), p, seed=3, row_offset=5)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # autograd wrapper: mean-reduced loss and its gradient
+    rd = rx.to(DEV).requires_grad_(True)
+    loss = ops.catalog_ce(rd, E.to(DEV), tgt.to(DEV), p, 3, 5)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), b[0].mean().item(), rtol=1e-6)
+    torch.testing.assert_close(rd.grad, b[2] / R, rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("R,N,D,p", [(35, 203, 16, 0.3), (130, 4099, 64, 0.05)])
 def test_catalog_ce_philox_mask_is_the_documented_stream(ops, R, N, D, p):
     """In-kernel Bernoulli mask == the host restatement of the same Philox stream -> exact CE check."""

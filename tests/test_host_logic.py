@@ -193,3 +193,20 @@ def test_catalog_kernel_choice_and_range_alignment(monkeypatch):
     monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1000000000")
     assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_BF16) == 1
     assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 256, _hip.PREC_BF16) == 2
+
+
+def test_sparse_keep_stream_is_bernoulli():
+    """the host restatement of the sparse path's kept-set stream (geometric gaps per catalog segment): i.i.d. Bernoulli(p)
+    marginals - mean, variance of the row counts, and a flat profile over catalog positions (segment boundaries included)"""
+    R, N, p = 300, 20000, 0.01
+    k = philox_ref.sparse_keep_mask(R, N, p, seed=5, row_offset=11)
+    cnt = k.sum(1).astype(np.int64)
+    assert abs(cnt.mean() - N * p) < 4 * (N * p / R) ** 0.5
+    assert 0.8 * N * p < cnt.var() < 1.25 * N * p
+    col = k.astype(np.int64).sum(0).reshape(100, -1).sum(1)           # 100 position buckets of 200 items: each ~ Poisson(R * 200 * p = 600)
+    assert np.abs(col - 600).max() < 5 * 600 ** 0.5
+    # neighbouring items are independent: P(both kept) = p^2
+    both = int((k[:, :-1] & k[:, 1:]).astype(np.int64).sum())
+    assert abs(both - R * (N - 1) * p * p) < 5 * (R * (N - 1) * p * p) ** 0.5
+    # row_offset is the global row index: a shard equals the corresponding rows of the whole batch
+    assert np.array_equal(philox_ref.sparse_keep_mask(100, N, p, seed=5, row_offset=211), k[200:])
