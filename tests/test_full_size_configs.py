@@ -1,0 +1,171 @@
+"""-m gpu: BASELINE.json's configs 2-5 at their STATED sizes (N, S, D, B): one Trainer.step and one recommend each, checked
+through size-independent properties - the dense [B*S, N] logits cannot exist at these sizes (328 GB at config 4), so nothing
+here forms them:
+
+  * the step's reconstruction term equals the mean of the per-row nll the catalog kernel reports for the same rx;
+  * on a row sample: lse / nll / gradient direction against a chunked fp64 softmax computed by torch ON THE DEVICE (an
+    independent path through the same data), at the tolerance of the arithmetic (f32 and bf16x3: the f32 kernel's; bf16: stated);
+  * sum_n softmax_n = 1  <=>  ||dx + E[target]|| = ||sum_n p_n E_n|| <= max ||E_n|| = 1;
+  * the PSM stack and the frozen tables are bit-unchanged by the step, every trained tensor moved, all finite;
+  * f32 / bf16x3 / bf16 ELBO terms agree to the stated tolerance;
+  * greedy generation: ids in range, the screened (bf16 + exact rescoring) ids equal the f32 kernel's, slot 0 is the pivot,
+    greedy decode is idempotent on table rows;
+  * config 5 also runs the in-loop evaluation with the reference's 5-column context (train_generative.py:179).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def chunked_reference(rx, E, tgt, chunk=125_000):
+    """fp64 online softmax over catalog chunks -> (lse, nll, dx) for the given rows, on the device"""
+    R, D = rx.shape
+    N = E.shape[0]
+    m = torch.full((R,), -float("inf"), device=rx.device, dtype=torch.float64)
+    ssum = torch.zeros(R, device=rx.device, dtype=torch.float64)
+    num = torch.zeros(R, D, device=rx.device, dtype=torch.float64)
+    xd = rx.double()
+    for c0 in range(0, N, chunk):
+        Ec = E[c0:c0 + chunk].double()
+        lg = xd @ Ec.t()
+        mn = torch.maximum(m, lg.max(1)[0])
+        sc = torch.exp(m - mn)
+        pe = torch.exp(lg - mn[:, None])
+        ssum = ssum * sc + pe.sum(1)
+        num = num * sc[:, None] + pe @ Ec
+        m = mn
+    lse = m + torch.log(ssum)
+    zt = (xd * E[tgt].double()).sum(1)
+    return lse, lse - zt, num / ssum[:, None] - E[tgt].double()
+
+
+def model_rx(model, s, r, u, eps):
+    """the rows the catalog kernel sees in model.loss (gt rule), recomputed from the model's own pieces"""
+    from pivotcvae_amd import ops
+    B, S = s.shape
+    D = model.feature_size
+    with torch.no_grad():
+        cond = model.get_condition(r)
+        emb = ops.gather_rows(model.docEmbed.weight, s.reshape(-1), group=S)
+        u_emb = model._user_rows(u, B)
+        pmu, plv = model._prior_from(cond, u_emb)
+        z_mu, z_lv = model.encode(emb, cond, u_emb)
+        z, _, _ = ops.latent(z_mu, z_lv, pmu, plv, eps)
+        return model._complete(z, cond, u_emb, emb[:, :D]).reshape(-1, D).contiguous()
+
+
+# per arithmetic: (lse/nll rtol, atol, gradient tolerance relative to its scale)
+TOL = {"f32": (2e-6, 4e-6, 2e-5), "bf16x3": (2e-6, 4e-6, 2e-5), "bf16": (2e-3, 3e-2, 2e-2)}
+CASES = [("2", ["f32"]), ("3", ["bf16", "f32"]), ("4", ["bf16x3", "bf16", "f32"]), ("5", ["bf16"])]
+
+
+@pytest.mark.parametrize("config,dtypes", CASES)
+def test_config_at_stated_size(config, dtypes):
+    import bench
+    from pivotcvae_amd import ops
+    from pivotcvae_amd._hip import PREC_NAMES
+    from pivotcvae_amd.train_generative import Trainer, recommendation_test
+    cfg = bench.CONFIGS[config]
+    N, S, D, B = cfg["N"], cfg["S"], cfg["D"], cfg["B"]
+    model, st = bench.build_model(cfg, torch.device(DEV), dtypes[0])
+    E = model.docEmbed.weight
+    s, r, u = bench.synthetic_batch(cfg, B, torch.device(DEV))
+    eps = torch.randn(B, bench.Z, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    def snapshot(v):   # the frozen tables are up to 10 GB: a strided sample + a checksum instead of a copy
+        return v.detach().clone() if v.numel() < (1 << 27) else (v[::997].clone(), v.double().sum())
+
+    def unchanged(v, snap):
+        return torch.equal(v, snap) if torch.is_tensor(snap) else (torch.equal(v[::997], snap[0]) and torch.equal(v.double().sum(), snap[1]))
+
+    before = {k: snapshot(v) for k, v in model.state_dict().items()}
+
+    # ---- the catalog kernels at this size, every arithmetic of the config, on the model's own rx
+    rx = model_rx(model, s, r, u, eps)
+    tgt = s.reshape(-1)
+    table = model.catalog_table()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    pick = torch.randint(0, B * S, (64,), device=DEV, generator=g)
+    want_lse, want_nll, want_dx = chunked_reference(rx[pick], E, tgt[pick])
+    rec = {}
+    for name in dtypes:
+        nll, lse, dx = ops.catalog_ce_raw(rx, table, tgt, prec=PREC_NAMES[name])
+        assert torch.isfinite(nll).all() and torch.isfinite(dx).all()
+        eff = name   # widths without a bf16 / bf16x3 kernel compute in exact f32 (ops.effective_precision)
+        if (name == "bf16x3" and D not in ops.X3_DIMS) or (name == "bf16" and D not in ops.BF16_DIMS):
+            eff = "f32"
+        rt, at, gt = TOL[eff]
+        torch.testing.assert_close(lse[pick].double(), want_lse, rtol=rt, atol=at)
+        torch.testing.assert_close(nll[pick].double(), want_nll, rtol=rt, atol=at)
+        assert (dx[pick].double() - want_dx).abs().max() < gt * want_dx.abs().max()
+        # softmax sums to one: ||sum_n p_n E_n|| <= 1 (bf16: the target row enters as its bf16 rounding)
+        Et = E[tgt] if name != "bf16" else E[tgt].to(torch.bfloat16).float()
+        assert float((dx + Et).norm(dim=1).max()) <= 1.0 + (1e-3 if name == "bf16" else 1e-5)
+        rec[name] = nll.double().mean().item()
+    for name in dtypes[1:]:   # batch reconstruction term across arithmetics (north_star: ELBO within 1e-4 relative)
+        np.testing.assert_allclose(rec[name], rec[dtypes[0]], rtol=1e-4)
+
+    # ---- one optimisation step at the config's arithmetic
+    tr = Trainer(model, lr=bench.LR, beta=bench.BETA)
+    loss, rc, kld = tr.step(s, r, u, eps=eps)
+    assert all(torch.isfinite(t).item() for t in (loss, rc, kld))
+    np.testing.assert_allclose(rc.item(), rec[dtypes[0]], rtol=2e-6)   # the step's recLoss IS the mean of those per-row nll
+    np.testing.assert_allclose(loss.item(), rc.item() + bench.BETA * kld.item(), rtol=1e-6)
+    after = model.state_dict()
+    for k, v in after.items():
+        assert torch.isfinite(v).all(), k
+        if k.startswith(("psm_", "docEmbed", "userEmbed")):
+            assert unchanged(v, before[k]), f"{k} must be bit-unchanged (no gradient reaches it)"
+        else:
+            assert not torch.equal(v, before[k]), f"{k} did not move"
+            assert (v - before[k]).abs().max() <= bench.LR * 1.001   # Adam's first step moves every weight by <= lr
+
+    # ---- greedy generation at this size
+    with torch.no_grad():
+        gB = min(B, 2048)
+        ctx = r[:gB]
+        items, z_mu = model.recommend(ctx, u[:gB], return_item=True, eps=eps[:gB])
+        assert items.shape == (gB * S,) and int(items.min()) >= 0 and int(items.max()) < N
+        assert torch.equal(items.view(gB, S)[:, 0], model.last_pivot)   # slot 0 of rx is the pivot's own (unit-norm) row
+        if D in ops.BF16_DIMS and N >= ops.SCREENED_MIN_ITEMS:           # screened ids == the plain f32 kernel's
+            rxg, _ = model.recommend(ctx[:256], u[:256], return_item=False, eps=eps[:256])
+            a = ops.catalog_argmax(rxg.reshape(-1, D), table, screened=True)
+            b = ops.catalog_argmax(rxg.reshape(-1, D), table, screened=False)
+            assert torch.equal(a, b)
+        rows = torch.randint(0, N, (128,), device=DEV, generator=g)
+        assert torch.equal(ops.catalog_argmax(E[rows].contiguous(), table), rows)   # idempotent on (distinct, unit-norm) rows
+
+    if config == "5":   # in-loop evaluation with the reference's 5-column context whatever S is
+        from pivotcvae_amd.env.response_model import UserResponseModel_MLP
+        torch.manual_seed(5)
+        resp = UserResponseModel_MLP(8, bench.N_USER - 1, D, S, [(S + 1) * D, 256, 256, S], DEV, False)
+        resp.docEmbed = model.docEmbed
+        resp.maxItemId = N - 1
+        stats = recommendation_test(model, resp.to(DEV), 512, n_test_trial=1)
+        assert stats.shape == (5, 3) and torch.isfinite(stats).all()
+        assert (stats[:, 0] <= stats[:, 1]).all() and (stats[:, 1] <= stats[:, 2]).all() and float(stats.max()) <= S
+
+
+def test_config4_default_masked_mode_at_stated_size():
+    """config 4 in the reference's default mode n_neg = 1000 (sparse path): one step, finite, and the reconstruction term is within
+    sampling noise of the full-softmax one's lower bound structure: E[L_masked] = N - n + sum_kept e^s, so rec_masked ~ log N-ish"""
+    import bench
+    from pivotcvae_amd.train_generative import Trainer
+    cfg = bench.CONFIGS["4"]
+    model, _ = bench.build_model(cfg, torch.device(DEV), "f32")
+    s, r, u = bench.synthetic_batch(cfg, cfg["B"], torch.device(DEV))
+    tr = Trainer(model, lr=bench.LR, beta=bench.BETA, n_neg=1000)
+    l0, r0, k0 = tr.step(s, r, u)
+    l1, r1, k1 = tr.step(s, r, u)
+    for t in (l0, r0, k0, l1, r1, k1):
+        assert torch.isfinite(t).item()
+    # untrained model, unit-norm table: logits ~ 0, masked softmax over N entries -> rec ~ log N
+    assert abs(r0.item() - np.log(cfg["N"])) < 0.2 and r1.item() < r0.item() + 1e-3
