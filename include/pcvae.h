@@ -210,6 +210,23 @@ int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, pc
  * hi = RNE bf16(E), lo = RNE bf16(E - hi)  (hi + lo carries 16 mantissa bits of E)                           */
 int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* out, pcvae_stream_t stream);
 
+/* a13  simulator click models as in-loop evaluators     env/response_model.py:129-150 (URM), 286-295 (URM_P), 315-323 (URM_P_MR)
+ *     out[b, s] = sigmoid(<E[slate]/||E[slate]||, U[user]> + item_bias[slate] + user_bias[user])
+ *                 (+ sum_d U[user, d] * pos_dep[d * S + s] + pos_bias[s]      when pos_bias / pos_dep are given: URM_P)
+ *                 (+ mr_factor * <E[slate]/||.||, sigmoid(mean_s E[slate_s]/||.||)>   when use_mr: URM_P_MR)
+ *     U is the RAW user table (the reference overwrites the normalised lookup, :141-142); pos_dep is the [S, D] buffer read
+ *     as [D, S] (`.view(featureSize, slateSize)`, :292).  D <= 256.                                              */
+int pcvae_urm_forward(const float* E, const float* item_bias, int64_t n_items, const float* U, const float* user_bias,
+                      int64_t n_users, const int64_t* slates, const int64_t* users, const float* pos_bias,
+                      const float* pos_dep, float mr_factor, int use_mr, int64_t B, int S, int D, float* out,
+                      pcvae_stream_t stream);
+
+/* (f)3 candidate sets for the sampled-softmax path      data_loader.py:46-58
+ *     cand[r, :] = Cn uniform ids in [0, n_items) (Philox keyed by (seed, row_offset + r, column); or the recorded draw `raw`);
+ *     if feature[r] is among them tgt[r] = the first such column, else cand[r, 0] = feature[r] and tgt[r] = 0.   */
+int pcvae_candidate_draw(const int64_t* feature, int64_t R, int64_t n_items, int Cn, uint64_t seed, uint64_t row_offset,
+                         const int64_t* raw, int64_t* cand, int64_t* tgt, pcvae_stream_t stream);
+
 /* K9  candidate-set scores                              models/pivotcvae.py:265-271
  *     p[r, c] = <E[cand[r, c]], rx_r> ;  bwd: drx_r = sum_c dp[r, c] * E[cand[r, c]]            */
 int pcvae_candidate_scores(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* cand,

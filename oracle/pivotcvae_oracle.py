@@ -258,6 +258,43 @@ def response_mlp(sd, slates, users, no_user=False):
     return x
 
 
+def urm_forward(sd, slates, users, S, pos_bias=None, pos_dep=None, mr_factor=None):
+    """URM / URM_P / URM_P_MR.core_forward as written (env/response_model.py:129-150, 286-295, 315-323): the item rows are
+    L2-normalised per item, the user row is the RAW one (its normalised lookup is overwritten at :141-142), positional term
+    with posDependentBias [S, D] read as [D, S] (``.view``, not a transpose), relation term against sigmoid(mean item)."""
+    B = slates.shape[0]
+    D = sd["docEmbed.weight"].shape[1]
+    d = F.normalize(sd["docEmbed.weight"][slates], p=2, dim=-1).view(B, S, -1)
+    d_bias = sd["itemBias.weight"][slates].view(B, S)
+    u = sd["userEmbed.weight"][users.view(B)]
+    u_bias = sd["userBias.weight"][users.view(B)]
+    out = torch.bmm(d, u.view(B, D, 1)).view(B, S) + d_bias
+    out = (out.transpose(0, 1) + u_bias.view(-1)).transpose(0, 1)
+    p = torch.sigmoid(out)
+    if pos_dep is not None:
+        p = p.reshape(-1, S) + torch.mm(u.view(-1, D), pos_dep.view(D, S)) + pos_bias.view(-1)
+    if mr_factor is not None:
+        att = torch.sigmoid(torch.mean(d.view(-1, S, D), dim=1))
+        p = p + torch.bmm(d.view(-1, S, D), att.view(-1, D, 1)).view(-1, S) * mr_factor
+    return p
+
+
+def candidate_targets(features, raw):
+    """data_loader.UserSlateResponseDataset.__getitem__ (:46-58) applied to a recorded uniform draw ``raw`` [.., S, Cn]: if the
+    slot's true item is among its candidates the target is the first column holding it, else column 0 becomes the item.
+    -> (candidates, targets)"""
+    cand = raw.clone()
+    flat_c, flat_f = cand.view(-1, cand.shape[-1]), features.reshape(-1)
+    tgt = torch.zeros(flat_f.shape[0], dtype=torch.long)
+    for i in range(flat_f.shape[0]):
+        hit = (flat_c[i] == flat_f[i]).nonzero()
+        if len(hit):
+            tgt[i] = hit[0, 0]
+        else:
+            flat_c[i, 0] = flat_f[i]
+    return cand, tgt.view(features.shape)
+
+
 def response_loss_and_grads(sd, slates, users, targets, no_user=False):
     """pretrain_env.py:82-90: BCELoss(sigmoid(logits), targets) (mean) and the gradient of every parameter."""
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}

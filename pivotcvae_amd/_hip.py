@@ -52,6 +52,8 @@ SIGNATURES = {
     "pcvae_catalog_sample": [_P, _L, _P, _P, _L, _I, _I, _U64, _U64, _P, _P, _SZ, _P],
     "pcvae_split_bf16": [_P, _L, _P, _P, _P],
     "pcvae_split_bf16x2": [_P, _L, _I, _P, _P],
+    "pcvae_urm_forward": [_P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _I, _L, _I, _I, _P, _P],
+    "pcvae_candidate_draw": [_P, _L, _L, _I, _U64, _U64, _P, _P, _P, _P],
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_candidate_scores_bwd": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],

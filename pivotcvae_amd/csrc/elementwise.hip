@@ -561,6 +561,149 @@ extern "C" int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* 
 }
 
 // =============================================================================================
+// a13: the simulators' click model as in-loop evaluator - URM / URM_P / URM_P_MR.core_forward
+// (env/response_model.py:129-150, 286-295, 315-323), forward only, one wave per slate:
+//   d_s   = E[slate_s] / max(||E[slate_s]||, 1e-12)                      per-item L2 normalisation
+//   p_s   = sigmoid(<d_s, u> + itemBias[slate_s] + userBias[user])       u = RAW user row (the reference computes the
+//                                                                        normalised one and overwrites it, :141-142)
+//   URM_P    : p_s += sum_d u[d] * posDep[d * S + s] + posBias[s]        posDependentBias [S, D] REINTERPRETED as [D, S]
+//                                                                        (`.view(featureSize, slateSize)`, :292 - not a transpose)
+//   URM_P_MR : p_s += mr * <d_s, sigmoid(mean_s' d_s')>
+// =============================================================================================
+__global__ void __launch_bounds__(256) urm_forward_kernel(const float* __restrict__ E, const float* __restrict__ item_bias,
+                                                          const float* __restrict__ U, const float* __restrict__ user_bias,
+                                                          const int64_t* __restrict__ slates, const int64_t* __restrict__ users,
+                                                          const float* __restrict__ pos_bias, const float* __restrict__ pos_dep,
+                                                          float mr_factor, int use_mr, int64_t B, int S, int D,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t uid = users[b];
+    const float ub = user_bias[uid];
+    auto wave_sum = [](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    // pass 1: raw score per slot, mean of the normalised rows (lane owns columns lane, lane + 64, ...: D <= 256)
+    float mean[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const int64_t n = slates[b * S + s];
+        float e[4], ss = 0.f, dot = 0.f, pd = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = lane + 64 * q;
+            e[q] = d < D ? E[n * D + d] : 0.f;
+            ss = fmaf(e[q], e[q], ss);
+        }
+        const float inv = 1.f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = lane + 64 * q;
+            if (d < D) {
+                const float dn = e[q] * inv, u = U[uid * D + d];
+                dot = fmaf(dn, u, dot);
+                mean[q] += dn;
+                if (pos_dep) pd = fmaf(u, pos_dep[(int64_t)d * S + s], pd);
+            }
+        }
+        dot = wave_sum(dot);
+        if (pos_dep) pd = wave_sum(pd);
+        float sc = 1.f / (1.f + __expf(-(dot + item_bias[n] + ub)));
+        if (pos_dep) sc += pd + pos_bias[s];
+        if (lane == 0) out[b * S + s] = sc;
+    }
+    if (!use_mr) return;
+    // pass 2: relation term against the slate attention sigmoid(mean of the normalised rows)
+    float att[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) att[q] = 1.f / (1.f + __expf(-mean[q] / (float)S));
+    for (int s = 0; s < S; ++s) {
+        const int64_t n = slates[b * S + s];
+        float e[4], ss = 0.f, rel = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = lane + 64 * q;
+            e[q] = d < D ? E[n * D + d] : 0.f;
+            ss = fmaf(e[q], e[q], ss);
+        }
+        const float inv = 1.f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (lane + 64 * q < D) rel = fmaf(e[q] * inv, att[q], rel);
+        rel = wave_sum(rel);
+        if (lane == 0) out[b * S + s] += mr_factor * rel;
+    }
+}
+
+extern "C" int pcvae_urm_forward(const float* E, const float* item_bias, int64_t n_items, const float* U, const float* user_bias,
+                                 int64_t n_users, const int64_t* slates, const int64_t* users, const float* pos_bias,
+                                 const float* pos_dep, float mr_factor, int use_mr, int64_t B, int S, int D, float* out,
+                                 pcvae_stream_t stream) {
+    PCVAE_REQUIRE(E && item_bias && U && user_bias && slates && users && out, "urm_forward: null pointer");
+    PCVAE_REQUIRE(B >= 0 && S > 0 && D > 0 && D <= 256 && n_items > 0 && n_users > 0, "urm_forward: bad shape B=%lld S=%d D=%d",
+                  (long long)B, S, D);
+    PCVAE_REQUIRE((pos_bias == nullptr) == (pos_dep == nullptr), "urm_forward: pos_bias and pos_dep come together");
+    if (B == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(urm_forward_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), E, item_bias, U, user_bias,
+                       slates, users, pos_bias, pos_dep, mr_factor, use_mr, B, S, D, out);
+    return check_launch("urm_forward");
+}
+
+// =============================================================================================
+// (f)3: candidate sets on the device (data_loader.py:46-58).  Per slate slot: Cn uniform item ids; if the slot's true item is
+// among them, the target is the FIRST column holding it, else column 0 is overwritten with it and the target is 0.
+// One wave per slot; element (row, c) of the raw draw is 64 Philox bits mod n_items (counter (row, c >> 1, "CAND"), row = GLOBAL
+// slot index: independent of sharding); `raw` non-null replays a recorded draw instead (parity against the reference's rule).
+// =============================================================================================
+__global__ void __launch_bounds__(256) candidate_draw_kernel(const int64_t* __restrict__ feature, int64_t R, int64_t n_items, int Cn,
+                                                             uint64_t seed, uint64_t row_offset, const int64_t* __restrict__ raw,
+                                                             int64_t* __restrict__ cand, int64_t* __restrict__ tgt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int64_t f = feature[r];
+    const uint64_t grow = row_offset + (uint64_t)r;
+    int first = Cn;   // lowest column holding the true item among this lane's columns
+    for (int c0 = 2 * lane; c0 < Cn; c0 += 128) {   // a lane draws columns c0, c0 + 1 from one Philox call
+        int64_t v[2];
+        if (raw) {
+            v[0] = raw[r * Cn + c0];
+            v[1] = c0 + 1 < Cn ? raw[r * Cn + c0 + 1] : -1;
+        } else {
+            const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(c0 >> 1), 0x43414E44u /*"CAND"*/,
+                                             (uint32_t)seed, (uint32_t)(seed >> 32));
+            v[0] = (int64_t)((((uint64_t)ph.x << 32) | ph.y) % (uint64_t)n_items);
+            v[1] = (int64_t)((((uint64_t)ph.z << 32) | ph.w) % (uint64_t)n_items);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (c0 + k < Cn) {
+                cand[r * Cn + c0 + k] = v[k];
+                if (v[k] == f && c0 + k < first) first = c0 + k;
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+    if (lane == 0) {
+        if (first == Cn) { cand[r * Cn] = f; first = 0; }   // (lane 0 wrote column 0 itself: same-thread ordering)
+        tgt[r] = first;
+    }
+}
+
+extern "C" int pcvae_candidate_draw(const int64_t* feature, int64_t R, int64_t n_items, int Cn, uint64_t seed, uint64_t row_offset,
+                                    const int64_t* raw, int64_t* cand, int64_t* tgt, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(feature && cand && tgt, "candidate_draw: null pointer");
+    PCVAE_REQUIRE(R >= 0 && n_items > 0 && Cn > 0, "candidate_draw: bad shape R=%lld n_items=%lld Cn=%d", (long long)R,
+                  (long long)n_items, Cn);
+    if (R == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(candidate_draw_kernel, dim3((unsigned)cdiv(R, 4)), dim3(256), 0, as_stream(stream), feature, R, n_items, Cn,
+                       seed, row_offset, raw, cand, tgt);
+    return check_launch("candidate_draw");
+}
+
+// =============================================================================================
 // K9: candidate-set scores.  fwd: lane per candidate (each lane streams its own table row, the rx
 // row is wave-uniform); bwd: wave per slate row, lanes over d (coalesced row reads).
 // =============================================================================================

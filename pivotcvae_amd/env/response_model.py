@@ -4,7 +4,9 @@ sampler (:10-13), forward-only on the HIP path.
 ``Environment`` (owner of the RAW, un-normalised ``docEmbed`` / ``userEmbed`` tables that the CVAE copies and
 normalises), ``UserResponseModel_MLP.forward`` (no-grad, the in-loop evaluation of ``train_generative.py:169-195``),
 ``forward_train`` (the same forward with hand-written backward kernels, for ``pivotcvae_amd.pretrain_env``) and
-``sample_users``.  The simulators' dataset generation is out of scope.
+``sample_users``; and the simulators ``URM`` / ``URM_P`` / ``URM_P_MR`` (:97-154, 264-323) as in-loop evaluators - the
+``resp_model`` of every ``--dataset urm*`` run (train_generative.py:247,185): forward only, one fused kernel.  The simulators'
+dataset generation is out of scope.
 """
 import math
 
@@ -96,3 +98,65 @@ class UserResponseModel_MLP(Environment):
             lin = getattr(self, f"mlp_{i}")
             x = ops.linear_fwd_raw(x, lin.weight, lin.bias, ACT_RELU if i < self._n else ACT_NONE)
         return x
+
+
+class URM(Environment):
+    """Matrix-factorisation click simulator (env/response_model.py:97-154): p = sigmoid(<normalised item, raw user> + item bias
+    + user bias) per slot.  Used as the evaluator of the in-loop recommendation test; ``forward`` returns the [B, S] scores
+    ``core_forward`` computes first (train_generative.py:185 then applies a sigmoid on top - for these models a second one)."""
+
+    def __init__(self, maxIID, maxUID, slate_size, latent_size, device, no_user):
+        super().__init__(maxIID, maxUID, latent_size, slate_size, device, no_user)
+        assert not no_user
+        self.itemBias = nn.Embedding(maxIID + 1, 1)
+        self.itemBias.weight.data = torch.zeros_like(self.itemBias.weight.data)
+        self.userBias = nn.Embedding(maxUID + 1, 1)
+        self.userBias.weight.data = torch.zeros_like(self.userBias.weight.data)
+
+    def _extras(self):
+        return {}
+
+    def to(self, *args, **kwargs):
+        out = super().to(*args, **kwargs)
+        out.device = args[0] if args else kwargs.get("device", out.device)
+        return out
+
+    @torch.no_grad()
+    def forward(self, slates, users):
+        return ops.urm_forward(self.docEmbed.weight, self.itemBias.weight, self.userEmbed.weight, self.userBias.weight,
+                               slates.reshape(slates.shape[0], -1), users, **self._extras())
+
+
+class URM_P(URM):
+    """URM + positional bias (env/response_model.py:264-303): a per-position constant and a user-dependent term
+    U[u] . posDependentBias, where the [S, D] buffer is READ AS [D, S] (the reference's ``.view(featureSize, slateSize)``)."""
+
+    def __init__(self, maxIID, maxUID, slate_size, latent_size, device, no_user, p_bias_max, p_bias_min):
+        super().__init__(maxIID, maxUID, slate_size, latent_size, device, no_user)
+        self.p_bias_max, self.p_bias_min = p_bias_max, p_bias_min
+        self.posBias = torch.tensor([p_bias_max - i * (p_bias_max - p_bias_min) / slate_size for i in range(slate_size)],
+                                    dtype=torch.float32).to(device)
+        a = math.sqrt(0.5 / latent_size)
+        self.posDependentBias = torch.empty(slate_size * latent_size, dtype=torch.float32).uniform_(-a, a) \
+            .reshape(slate_size, latent_size).to(device)
+
+    def _extras(self):
+        return dict(pos_bias=self.posBias, pos_dep=self.posDependentBias)
+
+    def to(self, *args, **kwargs):
+        out = super().to(*args, **kwargs)
+        out.posBias = out.posBias.to(*args, **kwargs)   # plain tensors, not buffers (reference :298-302): moved by hand
+        out.posDependentBias = out.posDependentBias.to(*args, **kwargs)
+        return out
+
+
+class URM_P_MR(URM_P):
+    """URM_P + an item-relation term (env/response_model.py:305-323): mr_factor * <normalised item, sigmoid(mean of the slate's
+    normalised items)>."""
+
+    def __init__(self, maxIID, maxUID, slate_size, latent_size, device, no_user, p_bias_max, p_bias_min, mr_factor):
+        super().__init__(maxIID, maxUID, slate_size, latent_size, device, no_user, p_bias_max, p_bias_min)
+        self.mrFactor = mr_factor
+
+    def _extras(self):
+        return dict(pos_bias=self.posBias, pos_dep=self.posDependentBias, mr_factor=self.mrFactor)

@@ -785,6 +785,44 @@ def candidate_scores(rx, E, cand):
     return _CandidateScores.apply(rx, E, cand)
 
 
+def candidate_draw(slates, n_items, n_candidate, seed=0, row_offset=0, raw=None):
+    """Candidate sets of the sampled-softmax path on the device (data_loader.py:46-58).
+
+    slates [B, S] int64 -> (sample_candidates [B, S, Cn] int64, sample_targets [B, S] int64): Cn uniform ids per slot; the
+    slot's true item is the target - the first column that holds it, or column 0 overwritten with it.  ``raw`` [B, S, Cn]
+    replays a recorded draw (parity with the reference's numpy stream, which cannot be matched on the device)."""
+    require_device(slates, raw)
+    B, S = slates.shape
+    f = slates.reshape(-1).to(torch.int64).contiguous()
+    Cn = int(n_candidate)
+    cand = torch.empty(B * S, Cn, dtype=torch.int64, device=slates.device)
+    tgt = torch.empty(B * S, dtype=torch.int64, device=slates.device)
+    if raw is not None:
+        raw = raw.reshape(B * S, Cn).to(torch.int64).contiguous()
+    check(lib().pcvae_candidate_draw(ptr(f), B * S, int(n_items), Cn, int(seed), int(row_offset), ptr(raw), ptr(cand), ptr(tgt),
+                                     stream()), "candidate_draw")
+    return cand.view(B, S, Cn), tgt.view(B, S)
+
+
+def urm_forward(E, item_bias, U, user_bias, slates, users, pos_bias=None, pos_dep=None, mr_factor=None):
+    """URM / URM_P / URM_P_MR.core_forward (env/response_model.py:129-150, 286-295, 315-323) -> [B, S] scores."""
+    require_device(E, item_bias, U, user_bias, slates, users, pos_bias, pos_dep)
+    B, S = slates.shape
+    D = E.shape[1]
+    sl = slates.to(torch.int64).contiguous()
+    us = users.reshape(-1).to(torch.int64).contiguous()
+    if us.numel() != B:
+        raise ValueError("urm_forward: one user per slate expected")
+    out = torch.empty(B, S, dtype=F32, device=E.device)
+    check(lib().pcvae_urm_forward(ptr(E.contiguous(), F32), ptr(item_bias.reshape(-1).contiguous(), F32), E.shape[0],
+                                  ptr(U.contiguous(), F32), ptr(user_bias.reshape(-1).contiguous(), F32), U.shape[0], ptr(sl), ptr(us),
+                                  ptr(pos_bias.contiguous(), F32) if pos_bias is not None else None,
+                                  ptr(pos_dep.contiguous(), F32) if pos_dep is not None else None,
+                                  float(mr_factor or 0.0), 1 if mr_factor is not None else 0, B, S, D, ptr(out, F32), stream()),
+          "urm_forward")
+    return out
+
+
 # ------------------------------------------------------- in-loop evaluation (response model)
 def normalize_rows_(x):
     """x[r, :] /= max(||x[r, :]||, 1e-12) in place (F.normalize(p=2, dim=1))."""
@@ -816,7 +854,7 @@ class _DenseCE(torch.autograd.Function):
     """mean softmax cross-entropy over a small dense class axis (the candidate path), fused loss + gradient."""
 
     @staticmethod
-    def forward(ctx, p, target):
+    def forward(ctx, p, target, inv_count):
         require_device(p, target)
         p = _c2d(p)
         R, C = p.shape
@@ -825,8 +863,8 @@ class _DenseCE(torch.autograd.Function):
         dp = torch.empty(R, C, dtype=F32, device=p.device) if p.requires_grad else None
         check(lib().pcvae_dense_ce(ptr(p, F32), _ld(p), R, C, ptr(target), ptr(nll, F32), ptr(dp), C, stream()), "dense_ce")
         out = torch.empty((), dtype=F32, device=p.device)
-        check(lib().pcvae_sum(ptr(nll, F32), R, 1.0 / R, ptr(out, F32), stream()), "sum")
-        ctx.inv = 1.0 / R
+        check(lib().pcvae_sum(ptr(nll, F32), R, float(inv_count), ptr(out, F32), stream()), "sum")
+        ctx.inv = float(inv_count)
         if dp is not None:
             ctx.save_for_backward(dp)
         return out
@@ -838,12 +876,13 @@ class _DenseCE(torch.autograd.Function):
         out = torch.empty_like(dp)
         check(lib().pcvae_scale_rows(ptr(dp, F32), _ld(dp), ptr(out, F32), _ld(out), dp.shape[0], dp.shape[1], ptr(g, F32),
                                      ctx.inv, stream()), "scale_rows")
-        return out, None
+        return out, None, None
 
 
-def dense_ce(p, target):
-    """nn.CrossEntropyLoss()(p, target) for a small dense [R, C] logits tensor."""
-    return _DenseCE.apply(p, target)
+def dense_ce(p, target, inv_count=None):
+    """nn.CrossEntropyLoss()(p, target) for a small dense [R, C] logits tensor.  ``inv_count`` replaces the 1/R of the mean
+    (a data-parallel rank passes 1/(R_local * world_size))."""
+    return _DenseCE.apply(p, target, (1.0 / p.shape[0]) if inv_count is None else inv_count)
 
 
 # ------------------------------------------------------------------------------------------- K8

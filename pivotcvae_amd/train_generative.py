@@ -35,13 +35,23 @@ def _batch_to_device(batch_data, device):
     return slates, users, targets
 
 
-def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None):
-    """-> (loss, recLoss, KLD), as reference get_gen_loss.  ``lossFun`` is only used on the candidate path."""
+def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None, seed=0, row_offset=0):
+    """-> (loss, recLoss, KLD), as reference get_gen_loss.  ``lossFun`` is only used on the candidate path.
+
+    Candidate path (``model.candidateFlag``): the reference's dataset builds the candidate sets per item in a Python loop on the
+    host (data_loader.py:46-58).  A batch that carries ``sample_candidates`` / ``sample_targets`` is used as given; one that
+    does not gets them drawn on the device (``ops.candidate_draw``: ``model.nCandidate`` columns - what
+    ``trainset.init_sampling(nneg)`` sets in the reference, default ``n_neg`` - Philox stream (seed, row_offset + slot))."""
     slates, users, targets = _batch_to_device(batch_data, model.device)
     if model.candidateFlag:
         pMu, pLogvar = model.get_prior(targets, users)
-        cand = torch.as_tensor(np.asarray(batch_data["sample_candidates"]), dtype=torch.long).to(model.device)
-        tgt = torch.as_tensor(np.asarray(batch_data["sample_targets"]), dtype=torch.long).to(model.device)
+        if "sample_candidates" in batch_data:
+            cand = torch.as_tensor(np.asarray(batch_data["sample_candidates"]), dtype=torch.long).to(model.device)
+            tgt = torch.as_tensor(np.asarray(batch_data["sample_targets"]), dtype=torch.long).to(model.device)
+        else:
+            N = model.docEmbed.weight.shape[0]
+            cand, tgt = ops.candidate_draw(slates, N, int(getattr(model, "nCandidate", n_neg)), seed=seed,
+                                           row_offset=row_offset * slates.shape[1])
         pred, _rx, _z, _emb, mu, logvar = model.forward(slates, targets, candidates=cand, u=users, eps=eps)
         # the reference passes nn.CrossEntropyLoss(); that case runs our dense-CE kernel, anything else is called as given
         plain_ce = isinstance(lossFun, torch.nn.CrossEntropyLoss) and lossFun.weight is None and \
@@ -50,7 +60,8 @@ def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None):
         KLD = ops.kld(mu, logvar, pMu, pLogvar)
         return recLoss + beta * KLD, recLoss, KLD
     N = model.docEmbed.weight.shape[0]
-    return model.loss(slates, targets, users, beta, n_neg=None if n_neg == N else n_neg, eps=eps)
+    return model.loss(slates, targets, users, beta, n_neg=None if n_neg == N else n_neg, eps=eps, mask_seed=seed,
+                      row_offset=row_offset)
 
 
 @torch.no_grad()
@@ -233,3 +244,172 @@ class Trainer:
         self.opt.step()
         self.global_step += 1
         return loss, rec, kld
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# epoch loop
+# ---------------------------------------------------------------------------------------------------------------------------
+def _dataset_arrays(ds):
+    """(slates [L, S], users [L, 1], responses [L, S]) of a data_loader.UserSlateResponseDataset-like object or a dict"""
+    get = (lambda k: ds[k]) if isinstance(ds, dict) else (lambda k: getattr(ds, k))
+    slates = torch.as_tensor(np.asarray(get("slates")), dtype=torch.long)
+    users = torch.as_tensor(np.asarray(get("users")), dtype=torch.long).reshape(slates.shape[0], -1)[:, :1]
+    resp = torch.as_tensor(np.asarray(get("responses"))).to(torch.float)
+    return slates, users, resp
+
+
+def candidate_loss(model, s, r, u, beta, n_candidate, seed=0, row_offset=0, inv_count=None, eps=None, eps_offset=None):
+    """The candidate path of get_gen_loss as a Trainer loss function: candidate sets drawn on the device, streams pinned to global
+    slate indices (independent of sharding), the mean scaled by ``inv_count``.  -> (loss, recLoss, KLD)"""
+    B, S = s.shape
+    N = model.docEmbed.weight.shape[0]
+    cand, tgt = ops.candidate_draw(s, N, n_candidate, seed=seed, row_offset=row_offset * S)
+    if eps is None:
+        eps = torch.empty(B, model.latent_size, dtype=torch.float32, device=s.device)
+        off = model._next_offset(B * model.latent_size) if eps_offset is None else int(eps_offset)
+        ops.philox_normal_(eps, seed=model.rng_seed, offset=off)
+    was = model.candidateFlag
+    model.candidateFlag = True
+    try:
+        pMu, pLogvar = model.get_prior(r, u)
+        pred, _rx, _z, _emb, mu, logvar = model.forward(s, r, candidates=cand, u=u, eps=eps)
+    finally:
+        model.candidateFlag = was
+    rec = ops.dense_ce(pred, tgt.reshape(-1), inv_count)
+    kld = ops.kld(mu, logvar, pMu, pLogvar)
+    return rec + beta * kld, rec, kld
+
+
+def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs, epochs, lr, decay, beta, n_neg=1000,
+                     n_test_trial=100, seed=0, process_group=None, capture_graph=False, trainer=None, val_loss_fn=None,
+                     eval_fn=None):
+    """Counterpart of reference train_generative.train_on_dataset (:67-214) for catalogs of any size, single GPU or one process
+    per GPU (data parallel over the batch, ONE all-reduce per step).
+
+    Per epoch, like the reference: shuffled training batches -> zero_grad / get_gen_loss / backward / Adam (default
+    ``n_neg = 1000`` in mask-train mode, :126 + :44; candidate sets of ``trainset.nCandidate`` columns when
+    ``model.candidateFlag``); validation under no_grad at ``n_neg = trainset.nCandidate`` (:157); the in-loop recommendation
+    test against ``resp_model`` (:169-195); the whole-module pickle when the validation loss improves by more than 1e-3
+    (:198-202) and the final move to CPU (:209-213).  The same lines are logged.  ``decay`` is logged and NOT applied, as in
+    the reference (:103).
+
+    What differs, on purpose: the datasets' index arrays are uploaded once and stay resident in HBM; batches are slices of a
+    permutation drawn ON the device (same on every rank); candidate sets and Bernoulli masks are drawn in the kernels; nothing
+    is synchronised with the host inside an epoch (the reference does a ``loss.item()`` per step, :128) - the per-batch
+    losses accumulate on the device and are read once per epoch.  Under data parallelism every rank takes bs / world slates of
+    each batch (a last batch that does not divide is cut to a multiple of the world size), rank 0 logs and saves.
+
+    ``trainer`` / ``val_loss_fn`` / ``eval_fn`` are injection points for the CPU tests of the loop logic."""
+    import torch.distributed as dist
+    device = model.docEmbed.weight.device
+    use_dist = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(process_group) if use_dist else 0
+    world = dist.get_world_size(process_group) if use_dist else 1
+
+    def log(msg):
+        if rank == 0:
+            logger.log(msg)
+
+    log("----------------------------------------")
+    log("Train user response model as simulator")
+    log("\tbatch size: " + str(bs))
+    log("\tnumber of epoch: " + str(epochs))
+    log("\tlearning rate: " + str(lr))
+    log("\tweight decay: " + str(decay))
+    log("\tbeta: " + str(beta))
+    log("----------------------------------------")
+    if rank == 0:
+        model.log(logger)
+    log("----------------------------------------")
+
+    n_cand = int(getattr(trainset, "nCandidate", n_neg) if not isinstance(trainset, dict) else trainset.get("nCandidate", n_neg))
+    N = model.docEmbed.weight.shape[0]
+    S = model.slate_size
+    tr_s, tr_u, tr_r = (t.to(device) for t in _dataset_arrays(trainset))
+    va_s, va_u, va_r = (t.to(device) for t in _dataset_arrays(valset))
+    L = tr_s.shape[0]
+
+    if trainer is None:
+        if model.candidateFlag:
+            fn = lambda m, s, r, u, beta, n_neg, eps, row_offset, inv_count, eps_offset, mask_seed, **_: \
+                candidate_loss(m, s, r, u, beta, n_cand, seed=mask_seed, row_offset=row_offset, inv_count=inv_count, eps=eps,
+                               eps_offset=eps_offset)
+            trainer = Trainer(model, lr=lr, beta=beta, n_neg=None, process_group=process_group, loss_fn=fn)
+        else:
+            trainer = Trainer(model, lr=lr, beta=beta, n_neg=None if n_neg >= N else n_neg, process_group=process_group,
+                              capture_graph=capture_graph)
+    if val_loss_fn is None:
+        def val_loss_fn(m, s, r, u, row_offset):   # forward only, n_neg = the dataset's candidate count (reference :157)
+            if m.candidateFlag:
+                return candidate_loss(m, s, r, u, beta, n_cand, seed=0x5641, row_offset=row_offset)
+            return m.loss(s, r, u, beta, n_neg=None if n_cand >= N else n_cand, mask_seed=0x5641, row_offset=row_offset)
+    if eval_fn is None:
+        eval_fn = lambda m: recommendation_test(m, resp_model, bs, n_test_trial=n_test_trial, seed=seed)
+
+    gen = torch.Generator(device=device)
+    best_val = float("inf")
+    temper = 2
+    history = {"train": [], "val": []}
+    for epoch in range(epochs):
+        log("Epoch " + str(epoch + 1))
+        gen.manual_seed((seed << 20) + epoch)            # the same permutation on every rank
+        perm = torch.randperm(L, device=device, generator=gen)
+        acc = torch.zeros((), dtype=torch.float32, device=device)
+        n_batches = 0
+        for lo in range(0, L, bs):
+            idx = perm[lo:lo + bs]
+            gb = (idx.shape[0] // world) * world
+            if gb == 0:
+                continue
+            idx = idx[:gb]
+            per = gb // world
+            mine = idx[rank * per:(rank + 1) * per]
+            loss, _rec, _kld = trainer.step(tr_s[mine], tr_r[mine], tr_u[mine], global_batch=gb, row_offset=rank * per)
+            acc += loss.to(acc.device)
+            n_batches += 1
+        history["train"].append(float(acc) / max(n_batches, 1))
+        log("train loss: " + str(history["train"][-1]))
+
+        # validation: every rank evaluates its slice of each batch; the sums are combined once
+        sums = torch.zeros(4, dtype=torch.float64, device=device)   # loss, rec, kld, batches
+        with torch.no_grad():
+            for lo in range(0, va_s.shape[0], bs):
+                hi = min(lo + bs, va_s.shape[0])
+                if (lo // bs) % world != rank:
+                    continue
+                l_, r_, k_ = val_loss_fn(model, va_s[lo:hi], va_r[lo:hi], va_u[lo:hi], lo)
+                sums += torch.stack([l_.double(), r_.double(), k_.double(), torch.ones((), dtype=torch.float64, device=device)]).to(device)
+        if use_dist:
+            dist.all_reduce(sums, group=process_group)
+        v_loss, v_rec, v_kld = (float(x) / max(float(sums[3]), 1.0) for x in sums[:3])
+        history["val"].append(v_loss)
+        log("validation Loss: " + str(v_loss) + " = " + str(v_rec) + " + " + str(beta) + " * " + str(v_kld))
+
+        # recommendation test
+        if resp_model is not None or eval_fn is not None:
+            stats = eval_fn(model)
+            if stats is not None:
+                stats = stats.detach().cpu()
+                for i in range(stats.shape[0]):
+                    log("Expected response (" + str(i + 1) + "): " + str(stats[i, 0].numpy()) + "; " + str(stats[i, 1].numpy()) +
+                        "; " + str(stats[i, 2].numpy()))
+
+        # save best model (reference :198-208; early termination is commented out there too)
+        if epoch == 0 or v_loss < best_val - 1e-3:
+            if rank == 0:
+                torch.save(model, open(model_path, "wb"))
+            log("Save best model")
+            temper = 3
+            best_val = v_loss
+        else:
+            temper -= 1
+            log("Temper down to " + str(temper))
+    if use_dist:
+        dist.barrier(group=process_group)
+    if rank == 0:
+        log("Move model to cpu before saving")
+        best = torch.load(open(model_path, "rb"), weights_only=False)
+        best.to("cpu")
+        best.device = "cpu"
+        torch.save(best, open(model_path, "wb"))
+    return history

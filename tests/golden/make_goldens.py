@@ -15,6 +15,8 @@ What is recorded per case (sets G1..G7):
   G5 recommend(): pivot ids, item ids, z_mu, score margins (models/pivotcvae.py:278-296)
   G6 candidate path p[R,Cn] + recLoss                      (models/pivotcvae.py:265-271)
   G7 UserResponseModel_MLP click logits                    (env/response_model.py:76-87)
+  G10 URM / URM_P / URM_P_MR click scores                  (env/response_model.py:129-154, 286-295, 315-323)
+  G11 candidate sets: recorded uniform draw -> first-hit / overwrite rule   (data_loader.py:46-58)
 
 The reference draws eps / Bernoulli masks / Categorical samples from torch's global
 generator.  We do not try to replay that stream on the device: the draws are RECORDED
@@ -328,6 +330,58 @@ def make_response_training(name, N, NU, D, S, B, H, seed, lr, decay, steps=3):
     print(f"{name}: {len(out)} arrays, losses {losses}")
 
 
+def make_urm(name, N, NU, D, S, B, seed):
+    """G10: the simulators as evaluators - URM / URM_P / URM_P_MR.forward (env/response_model.py:97-154, 264-323) on the same
+    tables, biases, slates and users (non-zero biases: the constructors' zeros would hide them)."""
+    torch.manual_seed(seed)
+    urm = quiet(ref_env.URM, N - 1, NU - 1, S, D, "cpu", False)
+    urm.itemBias.weight.data.uniform_(-0.5, 0.5)
+    urm.userBias.weight.data.uniform_(-0.5, 0.5)
+    sd = {k: v.clone() for k, v in urm.state_dict().items()}
+    urm_p = quiet(ref_env.URM_P, N - 1, NU - 1, S, D, "cpu", False, 0.2, -0.1)
+    urm_p.load_state_dict(sd)
+    urm_mr = quiet(ref_env.URM_P_MR, N - 1, NU - 1, S, D, "cpu", False, 0.2, -0.1, 0.35)
+    urm_mr.load_state_dict(sd)
+    urm_mr.posBias, urm_mr.posDependentBias = urm_p.posBias.clone(), urm_p.posDependentBias.clone()
+    g = torch.Generator().manual_seed(seed + 1)
+    s = torch.randint(0, N, (B, S), generator=g)
+    s[2] = s[2, 0]                                    # a slate of one repeated item
+    u = torch.randint(0, NU, (B,), generator=g)
+    with torch.no_grad():
+        out = {"sd/" + k: v.numpy().copy() for k, v in sd.items()}
+        out.update(s=s.numpy(), u=u.numpy(), p_urm=urm(s, u).numpy(), p_urm_p=urm_p(s, u).numpy(), p_urm_p_mr=urm_mr(s, u).numpy(),
+                   posBias=urm_p.posBias.numpy().copy(), posDependentBias=urm_p.posDependentBias.numpy().copy())
+    out["meta"] = np.array(json.dumps(dict(name=name, N=N, NU=NU, D=D, S=S, B=B, seed=seed, p_bias_max=0.2, p_bias_min=-0.1,
+                                           mr_factor=0.35, torch=torch.__version__)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(out)} arrays")
+
+
+def make_candidates(name, N, S, Cn, L, seed):
+    """G11: data_loader.UserSlateResponseDataset.__getitem__ with sampling (data_loader.py:46-58): the uniform draw it makes
+    (re-derived by seeding numpy the same way right before) and what the first-hit / overwrite rule turns it into.  A small N
+    makes hits (also repeated ones) common."""
+    import data_loader as ref_dl
+    g = np.random.RandomState(seed)
+    slates = g.randint(0, N, size=(L, S))
+    users = g.randint(0, 5, size=(L,))
+    resp = (g.rand(L, S) < 0.5).astype(np.float64)
+    ds = quiet(ref_dl.UserSlateResponseDataset, slates, users, resp, False)
+    quiet(ds.init_sampling, Cn)
+    raws, cands, tgts = [], [], []
+    for i in range(L):
+        np.random.seed(seed + 100 + i)
+        raws.append(np.random.randint(ds.max_iid + 1, size=(S, Cn)))
+        np.random.seed(seed + 100 + i)
+        item = ds[i]
+        cands.append(np.asarray(item["sample_candidates"]).copy())
+        tgts.append(np.asarray(item["sample_targets"]).copy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), slates=slates, raw=np.stack(raws), candidates=np.stack(cands),
+                        targets=np.stack(tgts), max_iid=np.array(ds.max_iid),
+                        meta=np.array(json.dumps(dict(name=name, N=N, S=S, Cn=Cn, L=L, seed=seed))))
+    print(f"{name}: hits in {int((np.stack(tgts) > 0).sum())} of {L * S} slots")
+
+
 def make_analysis(name="response_analysis"):
     """G9: analysis.get_coverage / get_ILS (analysis.py:5-30) on slates with repeated items."""
     import analysis as ref_analysis
@@ -349,6 +403,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "response_analysis":
         make_analysis()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":   # G10 / G11 only (every earlier case stays byte-identical)
+        make_urm("response_urm", N=203, NU=11, D=16, S=5, B=9, seed=601)
+        make_candidates("candidate_sets", N=40, S=5, Cn=12, L=16, seed=701)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "response_training":   # mint only the new case (the others stay byte-identical)
         make_response_training("response_training", N=203, NU=11, D=16, S=5, B=12, H=24, seed=501, lr=1e-2, decay=1e-3)
         return
@@ -368,6 +426,8 @@ def main():
     make_response_model("response_mlp", N=203, NU=11, D=16, S=5, B=9, H=24, seed=401)
     make_response_training("response_training", N=203, NU=11, D=16, S=5, B=12, H=24, seed=501, lr=1e-2, decay=1e-3)
     make_analysis()
+    make_urm("response_urm", N=203, NU=11, D=16, S=5, B=9, seed=601)
+    make_candidates("candidate_sets", N=40, S=5, Cn=12, L=16, seed=701)
 
 
 if __name__ == "__main__":

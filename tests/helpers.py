@@ -38,7 +38,7 @@ class Golden:
 
 def model_cases():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    return [n for n in names if not n.startswith("response_")]
+    return [n for n in names if not n.startswith(("response_", "candidate_"))]
 
 
 def load(name):

@@ -80,3 +80,18 @@ def sparse_keep_mask(R, N, keep_prob, seed, row_offset=0):
             live = ~done
             out[rr[live], pos[live]] = 1
     return out
+
+
+def candidate_raw(R, Cn, n_items, seed, row_offset=0):
+    """int64 [R, Cn]: the uniform draw of pcvae_candidate_draw before the first-hit / overwrite rule: columns 2k, 2k + 1 of row r
+    are the words (x, y) and (z, w) of Philox call (row, k, "CAND") as 64-bit numbers mod n_items."""
+    rows = (np.arange(R, dtype=np.uint64) + np.uint64(row_offset))[:, None]
+    k = np.arange((Cn + 1) // 2, dtype=np.uint32)[None, :]
+    c0 = np.broadcast_to((rows & MASK32).astype(np.uint32), (R, k.shape[1]))
+    c1 = np.broadcast_to((rows >> np.uint64(32)).astype(np.uint32), (R, k.shape[1]))
+    x, y, z, w = philox4x32_10(c0, c1, np.broadcast_to(k, c0.shape), np.uint32(0x43414E44), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    a = ((x.astype(np.uint64) << np.uint64(32)) | y.astype(np.uint64)) % np.uint64(n_items)
+    b = ((z.astype(np.uint64) << np.uint64(32)) | w.astype(np.uint64)) % np.uint64(n_items)
+    out = np.empty((R, 2 * k.shape[1]), np.int64)
+    out[:, 0::2], out[:, 1::2] = a.astype(np.int64), b.astype(np.int64)
+    return out[:, :Cn]

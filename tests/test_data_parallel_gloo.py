@@ -114,3 +114,78 @@ def test_shard_rejects_indivisible_batches():
     assert lo == 4 and a.reshape(-1).tolist() == [4, 5, 6, 7]
     with pytest.raises(ValueError):
         tr.shard(torch.arange(7).reshape(7, 1))
+
+
+# ------------------------------------------------------------------------------------------------ epoch loop
+class _ListLogger:
+    def __init__(self):
+        self.lines = []
+
+    def log(self, msg):
+        self.lines.append(str(msg))
+
+
+def _epoch_run(g, path, world_rank=None):
+    """pivotcvae_amd.train_generative.train_on_dataset on CPU: 14 slates, batches of 6 (6 + 6 + 2), 2 epochs; the oracle is
+    injected as the compute (training loss, validation loss), the loop / sharding / logging / checkpoint logic is the product's."""
+    from pivotcvae_amd.train_generative import train_on_dataset
+    s, r, u = (torch.cat([g.t(k), g.t(k)]) for k in ("s", "r", "u"))
+    eps = torch.cat([g.t("full/eps"), g.t("full/eps")])
+    train = {"slates": s.numpy(), "users": u.numpy(), "responses": r.numpy(), "nCandidate": 50}
+    val = {"slates": s[:8].numpy(), "users": u[:8].numpy(), "responses": r[:8].numpy()}
+    model = _cpu_model(g)
+    tr = _make_trainer(model, g, eps)
+    cfg = g.cfg()
+
+    def val_loss(m, vs, vr, vu, row_offset):
+        sd = dict(m.named_parameters())
+        sd.update({k: v for k, v in m.state_dict().items() if k not in sd})
+        f = orc.forward(sd, cfg, vs, vr, vu, eps[row_offset:row_offset + vs.shape[0]])
+        pmu, plv = orc.prior(sd, cfg, vr, vu)
+        rec = torch.nn.functional.cross_entropy(f["p"], vs.reshape(-1))
+        k = orc.kld(f["z_mu"], f["z_logvar"], pmu, plv)
+        return rec + g.meta["beta"] * k, rec, k
+
+    logger = _ListLogger()
+    hist = train_on_dataset(train, val, model, path, logger, None, bs=6, epochs=2, lr=g.meta["lr"], decay=0.0, beta=g.meta["beta"],
+                            trainer=tr, val_loss_fn=val_loss,
+                            eval_fn=lambda m: torch.tensor([[0.5, 1.0, 1.5]] * 5), seed=3)
+    return model, logger, hist
+
+
+def _epoch_worker(rank, world, port, name, out, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, logger, hist = _epoch_run(load(name), os.path.join(tmp, "model_dp.pkl"))
+    out[rank] = ({k: v.detach().clone() for k, v in model.state_dict().items()}, logger.lines, hist)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_train_on_dataset_two_ranks_equals_single_process(tmp_path):
+    name = "pivotcvae_gt_pi_user"
+    model, logger, hist = _epoch_run(load(name), str(tmp_path / "model.pkl"))
+    # the reference's log lines, in its order
+    text = "\n".join(logger.lines)
+    for needle in ("Train user response model as simulator", "\tbatch size: 6", "\tweight decay: 0.0", "Epoch 1", "train loss: ",
+                   "validation Loss: ", " + 0.001 * ", "Expected response (1): 0.5; 1.0; 1.5", "Expected response (5): ",
+                   "Save best model", "Epoch 2", "Move model to cpu before saving"):
+        assert needle in text, needle
+    assert logger.lines.index("Epoch 1") < logger.lines.index("Save best model") < logger.lines.index("Epoch 2")
+    assert len(hist["train"]) == 2 and hist["train"][1] < hist["train"][0]      # it trains
+    best = torch.load(open(tmp_path / "model.pkl", "rb"), weights_only=False)
+    assert best.device == "cpu" and sorted(best.state_dict()) == sorted(model.state_dict())
+    # two ranks: same permutation, every batch split in two, one all-reduce per step -> the same run
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_epoch_worker, args=(world, port, name, out, str(tmp_path)), nprocs=world, join=True)
+    (sd0, lines0, h0), (sd1, lines1, h1) = out[0], out[1]
+    assert lines1 == []                                   # rank 0 logs
+    np.testing.assert_allclose(h0["train"], hist["train"], rtol=1e-5)
+    np.testing.assert_allclose(h0["val"], hist["val"], rtol=1e-5)
+    np.testing.assert_allclose(h1["val"], h0["val"], rtol=0, atol=0)
+    for k, v in model.state_dict().items():
+        assert torch.equal(sd0[k], sd1[k]), k
+        torch.testing.assert_close(sd0[k], v, rtol=2e-5, atol=1e-7)
+    assert os.path.exists(tmp_path / "model_dp.pkl")

@@ -229,6 +229,85 @@ def test_g7_response_model_and_click_stats():
     assert torch.equal(users, sample_users(rm, 20000, seed=3).cpu())
 
 
+def test_g10_urm_simulators_as_evaluators():
+    """URM / URM_P / URM_P_MR.forward on the device (one fused kernel) against the reference's outputs, and as the evaluator of
+    the in-loop recommendation test (train_generative.py:185 applies a sigmoid on top of their probabilities)."""
+    from pivotcvae_amd.env.response_model import URM, URM_P, URM_P_MR
+    from pivotcvae_amd.train_generative import recommendation_test
+    g = load("response_urm")
+    m = g.meta
+    s, u = dev(g.t("s")), dev(g.t("u"))
+    models = {"p_urm": URM(m["N"] - 1, m["NU"] - 1, m["S"], m["D"], "cpu", False),
+              "p_urm_p": URM_P(m["N"] - 1, m["NU"] - 1, m["S"], m["D"], "cpu", False, m["p_bias_max"], m["p_bias_min"]),
+              "p_urm_p_mr": URM_P_MR(m["N"] - 1, m["NU"] - 1, m["S"], m["D"], "cpu", False, m["p_bias_max"], m["p_bias_min"],
+                                     m["mr_factor"])}
+    assert sorted(models["p_urm"].state_dict()) == sorted(g.sd)     # same state_dict keys as the reference classes
+    for key, rm in models.items():
+        rm.load_state_dict(g.sd)
+        if key != "p_urm":
+            close(rm.posBias, g.t("posBias"), rtol=1e-6, atol=1e-7)   # the constructor's own positional constants
+            rm.posDependentBias = g.t("posDependentBias").clone()
+        rm = rm.to(DEV)
+        assert rm.device == DEV
+        close(rm(s, u), g.t(key), rtol=1e-5, atol=1e-6)
+        close(rm(s, u.reshape(-1, 1)), g.t(key), rtol=1e-5, atol=1e-6)
+    # as evaluator of a generative model over the same catalog
+    gm = load("pivotcvae_gt_pi_user")
+    model = build_from_golden(gm)
+    rm = models["p_urm_p_mr"].to(DEV)
+    out = recommendation_test(model, rm, bs=32, n_test_trial=2, seed=5).cpu()
+    assert tuple(out.shape) == (5, 3) and torch.all(out[:, 0] <= out[:, 1]) and torch.all(out[:, 1] <= out[:, 2])
+    assert torch.all(out > 0) and torch.all(out < 5)
+
+
+def test_g11_candidate_draw():
+    """On-device candidate sets (data_loader.py:46-58): the rule on the reference's recorded draw (golden G11), the documented
+    Philox stream (host restatement), and the properties the loss relies on."""
+    from pivotcvae_amd import ops
+    from tests import philox_ref
+    g = load("candidate_sets")
+    slates, raw = dev(g.t("slates")), dev(g.t("raw"))
+    cand, tgt = ops.candidate_draw(slates, int(g.a["max_iid"]) + 1, raw.shape[-1], raw=raw)
+    assert torch.equal(cand.cpu(), g.t("candidates")) and torch.equal(tgt.cpu(), g.t("targets"))
+    # the in-kernel stream
+    B, S, Cn, N = 37, 5, 50, 60
+    gen = torch.Generator().manual_seed(3)
+    sl = torch.randint(0, N, (B, S), generator=gen)
+    cand, tgt = ops.candidate_draw(dev(sl), N, Cn, seed=77, row_offset=10)
+    want_raw = torch.from_numpy(philox_ref.candidate_raw(B * S, Cn, N, 77, 10)).view(B, S, Cn)
+    wc, wt = orc.candidate_targets(sl, want_raw)
+    assert torch.equal(cand.cpu(), wc) and torch.equal(tgt.cpu(), wt)
+    assert int((wt > 0).sum()) > 10 and int((wt == 0).sum()) > 10     # both branches of the rule
+    assert torch.equal(torch.gather(cand.cpu(), 2, tgt.cpu()[..., None])[..., 0], sl)   # the true item sits at its target
+    # a shard draws what the whole batch drew for those slots
+    c2, t2 = ops.candidate_draw(dev(sl[20:]), N, Cn, seed=77, row_offset=10 + 20 * S)
+    assert torch.equal(c2, cand[20:]) and torch.equal(t2, tgt[20:])
+    # uniform marginals
+    big, _ = ops.candidate_draw(dev(torch.zeros(400, 5, dtype=torch.long)), 100, 200, seed=5)
+    freq = torch.bincount(big[:, :, 1:].reshape(-1).cpu(), minlength=100).float()
+    assert (freq / freq.sum() - 0.01).abs().max() < 0.0015
+
+
+def test_candidate_path_draws_its_own_sets():
+    """get_gen_loss on the candidate path when the batch carries no candidate sets (the reference builds them per item in a
+    Python loop, data_loader.py:46-58): drawn on the device, loss finite and differentiable, equal to feeding the same sets in."""
+    from pivotcvae_amd import ops
+    from pivotcvae_amd.train_generative import get_gen_loss
+    g = load("pivotcvae_gt_pi_user")
+    model = build_from_golden(g)
+    model.candidateFlag = True
+    model.nCandidate = 20
+    batch = {"slates": g.a["s"], "users": g.a["u"], "responses": g.a["r"]}
+    eps = dev(g.t("fwd/eps"))
+    loss, rec, kld = get_gen_loss(batch, model, torch.nn.CrossEntropyLoss(), 0.001, eps=eps, seed=9)
+    loss.backward()
+    assert torch.isfinite(loss) and model.scm_1.weight.grad.abs().max() > 0
+    cand, tgt = ops.candidate_draw(dev(g.t("s")), model.docEmbed.weight.shape[0], 20, seed=9)
+    batch2 = dict(batch, sample_candidates=cand.cpu().numpy(), sample_targets=tgt.cpu().numpy())
+    loss2, rec2, kld2 = get_gen_loss(batch2, model, torch.nn.CrossEntropyLoss(), 0.001, eps=eps)
+    assert torch.equal(rec, rec2) and torch.equal(kld, kld2)
+
+
 def test_g8_response_model_training_steps():
     """pivotcvae_amd.pretrain_env.ResponseTrainer (gather + scatter-add backward, whole-vector normalisation and its
     backward, ReLU MLP, BCE of the sigmoid, Adam with weight decay over one flat buffer incl. the tables) against the
@@ -364,3 +443,41 @@ def test_recommendation_test_matches_oracle_composition():
     assert tuple(out.shape) == (5, 3)
     o3 = out.cpu()
     assert torch.all(o3[:, 0] <= o3[:, 1]) and torch.all(o3[:, 1] <= o3[:, 2]) and torch.all(o3 >= 0) and torch.all(o3 <= 5)
+
+
+@pytest.mark.parametrize("candidate", [False, True])
+def test_train_on_dataset_on_the_hip_path(tmp_path, candidate):
+    """the epoch loop (train_generative.py:67-214 counterpart) end to end on the device: mask-train and candidate mode, validation,
+    in-loop evaluation against a URM simulator, best-model pickle moved to the CPU; the loss goes down."""
+    from pivotcvae_amd.env.response_model import URM_P_MR
+    from pivotcvae_amd.train_generative import train_on_dataset
+    g = load("pivotcvae_gt_pi_user")
+    gu = load("response_urm")
+    model = build_from_golden(g)
+    model.candidateFlag = candidate
+    m = gu.meta
+    rm = URM_P_MR(m["N"] - 1, m["NU"] - 1, m["S"], m["D"], "cpu", False, 0.2, -0.1, 0.35)
+    rm.load_state_dict(gu.sd)
+    rm = rm.to(DEV)
+    gen = torch.Generator().manual_seed(0)
+    L, N, S = 96, g.meta["N"], g.meta["S"]
+    train = {"slates": torch.randint(0, N, (L, S), generator=gen).numpy(), "users": torch.randint(0, g.meta["NU"], (L, 1), generator=gen).numpy(),
+             "responses": (torch.rand(L, S, generator=gen) < 0.5).float().numpy(), "nCandidate": 40}
+    val = {k: v[:32] for k, v in train.items() if k != "nCandidate"}
+
+    class Log:
+        lines = []
+
+        def log(self, msg):
+            self.lines.append(msg)
+
+    path = str(tmp_path / "gen.pkl")
+    hist = train_on_dataset(train, val, model, path, Log(), rm, bs=32, epochs=3, lr=3e-3, decay=0.0, beta=0.001, n_neg=N,
+                            n_test_trial=2)
+    assert len(hist["train"]) == 3 and hist["train"][-1] < hist["train"][0] and all(np.isfinite(hist["val"]))
+    text = "\n".join(Log.lines)
+    assert "Expected response (5): " in text and "Save best model" in text and "validation Loss: " in text
+    best = torch.load(open(path, "rb"), weights_only=False)
+    assert best.device == "cpu" and best.candidateFlag == candidate
+    assert not torch.equal(best.state_dict()["scm_1.weight"], g.sd["scm_1.weight"])
+    assert torch.equal(best.state_dict()["psm_1.weight"], g.sd["psm_1.weight"])       # the PSM never trains (SURVEY 0.7)

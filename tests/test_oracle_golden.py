@@ -119,6 +119,31 @@ def test_g7_response_mlp():
     close(orc.response_mlp(g.sd, g.t("s"), g.t("u")), g.t("logits"))
 
 
+def test_g10_urm_simulators_as_evaluators():
+    """oracle restatement of URM / URM_P / URM_P_MR.forward against the reference's outputs (golden G10)"""
+    g = load("response_urm")
+    m = g.meta
+    s, u = g.t("s"), g.t("u")
+    close(orc.urm_forward(g.sd, s, u, m["S"]), g.t("p_urm"))
+    close(orc.urm_forward(g.sd, s, u, m["S"], g.t("posBias"), g.t("posDependentBias")), g.t("p_urm_p"))
+    close(orc.urm_forward(g.sd, s, u, m["S"], g.t("posBias"), g.t("posDependentBias"), m["mr_factor"]), g.t("p_urm_p_mr"))
+    # the three models differ (the golden is not vacuous), and the positional view is NOT a transpose
+    assert (g.t("p_urm") - g.t("p_urm_p")).abs().max() > 1e-2 and (g.t("p_urm_p") - g.t("p_urm_p_mr")).abs().max() > 1e-2
+    wrong = orc.urm_forward(g.sd, s, u, m["S"], g.t("posBias"), g.t("posDependentBias").t().contiguous().view(m["S"], m["D"]))
+    assert (wrong - g.t("p_urm_p")).abs().max() > 1e-3
+
+
+def test_g11_candidate_rule():
+    """the first-hit / overwrite rule of data_loader.py:46-58 on the reference's own recorded draw (golden G11)"""
+    g = load("candidate_sets")
+    cand, tgt = orc.candidate_targets(g.t("slates"), g.t("raw"))
+    assert torch.equal(cand, g.t("candidates")) and torch.equal(tgt, g.t("targets"))
+    assert int((g.t("targets") > 0).sum()) >= 5      # hits beyond column 0 are exercised
+    rows = torch.arange(cand.shape[0])[:, None].expand(-1, cand.shape[1])
+    cols = torch.arange(cand.shape[1])[None, :].expand(cand.shape[0], -1)
+    assert torch.equal(cand[rows, cols, tgt], g.t("slates"))
+
+
 def test_g8_response_training_steps():
     """pretrain_env.py:76-92 restated: logits, BCE loss, every gradient (the user table's is exactly zero: the reference
     normalises the [B, 1, D] user lookup over its singleton axis: zero up to rounding), parameters after 1 and 3 Adam(weight_decay) steps."""
