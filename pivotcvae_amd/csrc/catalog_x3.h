@@ -22,10 +22,15 @@
 //
 // Schedule (one wave per SIMD, CT = 2 column tiles of 16 rows per wave, every MFMA / LDS read / VALU op an inline-asm statement
 // in schedule order - see catalog_ce_bf16_pipe_kernel for the method and for what hipcc may not place in these loops):
-//   slot t:  L(t)    logits chain of subtile t (48 MFMAs)  ||  lo halves of subtile t-1's numerators (5 cheap VALU ops per pair)
-//            G(t-1)  row sums + gradient chain of subtile t-1 (52 MFMAs)  ||  exponentials + hi halves of subtile t (3 ops per
-//                    pair), the seam (counted vmcnt + s_barrier + refill of the ring) and the first A fragments of L(t+1) in
-//                    the middle of the chain.
+//   slot t:  L(t)    logits chain of subtile t (48 MFMAs)  ||  hi / lo split of subtile t-1's numerators (6 cheap VALU ops per pair)
+//            G(t-1)  row sums + gradient chain of subtile t-1 (52 MFMAs)  ||  the exponentials of subtile t, the seam (counted
+//                    vmcnt + s_barrier + refill of the ring) and the first A fragments of L(t+1) in the middle of the chain.
+// The slot is bound by VECTOR ISSUE, not by the MFMA pipe alone: an MFMA holds the issue port for 8 of its 16 cycles, a v_exp_f32
+// for 8, a conversion / LDS read / s_waitcnt for 4-5, and a gap runs max(16, the sum) (MI355X_MICROARCH.md, issue-cost row).  So
+// the statement order gives every MFMA gap at most 8 cycles of other work: a step is  wait | MFMA | LDS reads of a later step |
+// MFMA | op | MFMA | op | MFMA ..., the 16 exponentials sit one per gap in the two middle gaps of the eight hi tiles of G, the 48
+// split ops two per gap in the hi steps of L (the uniform spread this replaced put an exponential, two reads and a wait into one
+// gap: 0.75 -> see DESIGN.md for the measured MFMA-pipe utilisation).
 // A single accumulation chain of v_mfma_f32_16x16x32_bf16 issues back to back at full rate (MI355X_MICROARCH.md, cycle
 // constants), so the two or three MFMAs that update one accumulator need no interleaving.
 // Max-free like the bf16 fast kernels (row blocks whose Cauchy-Schwarz logit bound exceeds 90 are flagged by
@@ -33,10 +38,38 @@
 #pragma once
 
 #ifndef X3_AD
-#define X3_AD 2      // logits chain: A fragments requested ahead (the first X3_AD of a slot are issued at the previous seam)
+#define X3_AD 3      // logits chain: A fragments requested ahead (the first X3_AD of a slot are issued at the previous seam)
 #endif
 #ifndef X3_TD
-#define X3_TD 2      // gradient chain: d tiles requested ahead (two transposed reads each)
+#define X3_TD 3      // gradient chain: d tiles requested ahead (two transposed reads each)
+#endif
+// Timing probes (tools/build_variant.sh ... -DX3_PROBE=<mask>; results are garbage, only the time means something): drop from the
+// steady-state slots 1: the numerator VALU ops, 2: the A-fragment reads, 4: the transposed reads, 8: the seam (wait + barrier +
+// refill), 16: the LDS waits
+#ifndef X3_PROBE
+#define X3_PROBE 0
+#endif
+#ifndef X3_NOP_BEFORE
+#define X3_NOP_BEFORE
+#endif
+#ifndef X3_NOP_AFTER
+#define X3_NOP_AFTER
+#endif
+#ifndef X3_L_AFTER_COND
+#define X3_L_AFTER_COND true     // steps whose A request sits behind an MFMA of the step (the others: in front of MFMA 0)
+#endif
+#ifndef X3_L_ISSUE_AT
+#define X3_L_ISSUE_AT 0     // the A fragment of step I + X3_AD is requested behind this MFMA of step I (-1: in front of MFMA 0)
+#endif
+#ifdef X3_OLD_READS_L
+#define X3_OLD_L 1
+#else
+#define X3_OLD_L 0
+#endif
+#ifdef X3_OLD_READS_G
+#define X3_OLD_G 1
+#else
+#define X3_OLD_G 0
 #endif
 
 template <int D, int CT>
@@ -44,7 +77,7 @@ struct X3Geo {
     static constexpr int DL = 2 * D;                       // table / LDS row width in bf16 elements: hi | lo
     using GL = FastGeo<DL>;
     static_assert(D == 128, "bf16x3 is built for D = 128: a 512-byte table row, one 32-item subtile per 16 KB ring chunk");
-    static_assert(GL::SUB == 1 && GL::KS == 8 && GL::NDT == 16, "layout of FastGeo<256>");
+    static_assert(GL::SUB == 1 && GL::KS == 8 && GL::NDT == 16, "layout of FastGeo<256> (X3Regs holds 16 transposed tiles)");
     static constexpr int KSH = D / 32;                     // k-steps per half
     static constexpr int NI = 2 * GL::KS;                  // steps of the logits chain: (k-step, row tile)
     static constexpr int NDT = D / 16;                     // 16-wide d tiles of U
@@ -52,88 +85,119 @@ struct X3Geo {
     static constexpr int ML = 2 * KSH * 2 * CT + 2 * KSH * CT;          // MFMAs of L
     static constexpr int MG = 2 * CT + NDT * 2 * CT + NDT * CT;         // MFMAs of G (row sums first)
     static constexpr int P = 4 * CT;                       // numerator pairs per slot: (row tile, column tile, half)
-    static constexpr int GOPS = 3 * P;                     // during G: 2 exponentials + 1 packed conversion (hi) per pair
-    static constexpr int LOPS = 5 * P;                     // during the next L: shift, mask, 2 subtractions, packed conversion (lo)
+    static constexpr int GOPS = 2 * P;                     // during G: the 2 exponentials of every pair
+    static constexpr int LOPS = 6 * P;                     // during the next L: hi conversion, shift, mask, 2 subtractions, lo conversion
     static constexpr int ROWS = 4 * 16 * CT;               // rows per workgroup (4 waves)
     static constexpr int NB = 6, PF = 3, TR = NB;          // ring buffers, chunks requested ahead, slots per steady-state trip
-    // VALU ops behind MFMA position m of G: [gfirst(m), gfirst(m + 1)); none behind the first two MFMAs (the accumulators the
-    // first exponentials read were written by the last MFMAs of L)
+    // MFMA positions of a phase <-> (step, j-th MFMA of the step).  Statement order inside a step:
+    //     wait(this step's LDS data) | MFMA 0 | LDS reads of a later step | MFMA 1 | ops | ... | MFMA last | ops
+    // ---- G: row sums (2 CT), hi tiles (2 CT MFMAs each), lo tiles (CT each).  One exponential behind the MIDDLE MFMAs of a hi
+    // tile: the gap behind MFMA 0 carries the two transposed reads (8 cycles), the one behind the last MFMA the next step's wait
+    static constexpr int gcap(int m) {
+        if (m < 2 * CT || m >= 2 * CT + NDT * 2 * CT) return 0;
+        const int j = (m - 2 * CT) % (2 * CT);
+        return (j == 0 || j == 2 * CT - 1) ? 0 : 1;
+    }
     static constexpr int gfirst(int m) {
+#ifdef X3_UNIFORM_OPS
         if (m <= 2) return 0;
         const int v = ((m - 2) * GOPS + (MG - 3)) / (MG - 2);
         return v > GOPS ? GOPS : v;
+#else
+        int n = 0;
+        for (int i = 0; i < m && i < MG; ++i) n += gcap(i);
+        return n > GOPS ? GOPS : n;
+#endif
     }
-    // ... of L: [lfirst(m), lfirst(m + 1)); the last two gaps stay free (the packed lo numerators are MFMA operands right after L)
+    // ---- L: hi steps (2 CT MFMAs), lo steps (CT).  Cheap ops (4-5 cycles): one next to the A-fragment read behind MFMA 0, one in
+    // front of the next step's wait behind the last MFMA, two in the gaps between; none in the last two gaps of L (the packed
+    // numerators are MFMA operands right after it)
+    static constexpr int lcap(int m) {
+        // nothing behind the MFMAs of step 0: the first split op overwrites the hi numerators (r.wh) that the LAST MFMAs of the
+        // gradient chain in front of this L read as their B operand.  hipcc sees those operands dead and the in-order issue would
+        // seem to protect them, but a VALU write two MFMAs behind such a read corrupted it (column tile 0 - the first pair
+        // written - NaN, depending on where an unrelated ds_read sat: tools/dbg_x3.py): MFMAs queue in front of the
+        // matrix pipe and read their operands when they start, not when they issue.  A whole step (2 CT MFMAs) of distance.
+        if (m < 2 * CT || m >= ML - 2) return 0;
+        const int nh = 2 * KSH * 2 * CT;
+        const int len = m < nh ? 2 * CT : CT, j = m < nh ? m % (2 * CT) : (m - nh) % CT;
+        return (j == 0 || j == len - 1) ? 1 : 2;
+    }
     static constexpr int lfirst(int m) {
+#ifdef X3_UNIFORM_OPS
         const int v = (m * LOPS + (ML - 3)) / (ML - 2);
         return v > LOPS ? LOPS : v;
+#else
+        int n = 0;
+        for (int i = 0; i < m && i < ML; ++i) n += lcap(i);
+        return n > LOPS ? LOPS : n;
+#endif
     }
 };
 
 template <int CT>
 struct X3Regs {
     f32x4 acc[2][CT];          // logits of the current subtile [row tile][column tile] (log2 domain)
-    unsigned wh[2][CT][4];     // [slot parity][ct][2 rt + h]: bf16 pair of hi halves (read by G one slot after it is written)
-    unsigned wl[CT][4];        // lo halves (written during L, read by the G right behind it)
-    float e[4 * CT][2];        // the fp32 numerators between the two conversions
-    float tmp[2];
+    unsigned wh[CT][4];        // [ct][2 rt + h]: bf16 pair of hi halves; written during L, read by the G right behind it
+    unsigned wl[CT][4];        // lo halves, likewise
+    float e[4 * CT][2];        // the fp32 numerators: written during G (exponentials), split during the next L
+    float tmp[2][2];
+    // MFMA operands that must outlive their last MFMA (see x3_keep): the packed numerators and the transposed tiles of the
+    // gradient chain, held here so that the NEXT slot's logits chain can still name them
+    bf16x8 pbh[CT], pbl[CT];
+    s16x4 tl[16], th[16];      // (X3Geo::NDTL tiles)
 };
 
-// G-phase op V: v = 0, 1: exponentials of pair 0; then for pair j >= 1: exp, exp, hi conversion of pair j - 1 (a transcendental
-// result needs an independent instruction before its VALU consumer); last: hi conversion of pair P - 1
+// G-phase op V: exponential `V & 1` of pair V / 2 (pair k <-> row tile k / (2 CT), column tile (k / 2) % CT, half k & 1)
 template <int CT, int V>
-__device__ __forceinline__ void x3_gop(X3Regs<CT>& r, unsigned (&wh)[CT][4]) {
-    constexpr int P = 4 * CT, VOPS = 3 * P;
-    if constexpr (V < 2 || (V < VOPS - 1 && (V + 1) % 3 != 2)) {
-        constexpr int k = V < 2 ? 0 : (V + 1) / 3, which = V < 2 ? V : (V + 1) % 3;
-        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
-        asm volatile("v_exp_f32 %0, %1" : "=v"(r.e[k][which]) : "v"(r.acc[rt][ct][2 * h + which]));
-    } else {
-        constexpr int k = V == VOPS - 1 ? P - 1 : (V + 1) / 3 - 1;
-        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
-        asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(wh[ct][2 * rt + h]) : "v"(r.e[k][0]), "v"(r.e[k][1]));
-    }
-}
-// L-phase op V (pair k = V / 5): the lo half of pair k = RNE bf16(e - float(hi)) - the difference is exact in fp32
-template <int CT, int V>
-__device__ __forceinline__ void x3_lop(X3Regs<CT>& r, const unsigned (&wh)[CT][4]) {
-    constexpr int k = V / 5, j = V % 5;
+__device__ __forceinline__ void x3_gop(X3Regs<CT>& r) {
+    constexpr int k = V / 2, which = V % 2;
     constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
-    if constexpr (j == 0) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r.tmp[0]) : "v"(wh[ct][2 * rt + h]));
-    else if constexpr (j == 1) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r.tmp[1]) : "v"(wh[ct][2 * rt + h]));
-    else if constexpr (j == 2) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r.tmp[0]) : "v"(r.e[k][0]));
-    else if constexpr (j == 3) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r.tmp[1]) : "v"(r.e[k][1]));
-    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r.wl[ct][2 * rt + h]) : "v"(r.tmp[0]), "v"(r.tmp[1]));
+    asm volatile("v_exp_f32 %0, %1" : "=v"(r.e[k][which]) : "v"(r.acc[rt][ct][2 * h + which]));
+}
+// L-phase op V: the split of the numerators into bf16 hi + lo halves, two pairs (a, b) interleaved so that no op reads the result
+// of the op right in front of it:  hi = RNE bf16(e);  lo = RNE bf16(e - float(hi))  (the difference is exact in fp32)
+//   block of 12 ops: cvt a, cvt b, shl a, shl b, and a, and b, sub0 a, sub0 b, sub1 a, sub1 b, cvt-lo a, cvt-lo b
+template <int CT, int V>
+__device__ __forceinline__ void x3_lop(X3Regs<CT>& r) {
+    constexpr int blk = V / 12, j = (V % 12) / 2, ab = V & 1, k = 2 * blk + ab;
+    constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+    if constexpr (j == 0) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r.wh[ct][2 * rt + h]) : "v"(r.e[k][0]), "v"(r.e[k][1]));
+    else if constexpr (j == 1) asm volatile("v_lshlrev_b32 %0, 16, %1" : "=v"(r.tmp[ab][0]) : "v"(r.wh[ct][2 * rt + h]));
+    else if constexpr (j == 2) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(r.tmp[ab][1]) : "v"(r.wh[ct][2 * rt + h]));
+    else if constexpr (j == 3) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r.tmp[ab][0]) : "v"(r.e[k][0]));
+    else if constexpr (j == 4) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(r.tmp[ab][1]) : "v"(r.e[k][1]));
+    else asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r.wl[ct][2 * rt + h]) : "v"(r.tmp[ab][0]), "v"(r.tmp[ab][1]));
 }
 template <int D, int CT, int M, int V = X3Geo<D, CT>::gfirst(M)>
-__device__ __forceinline__ void x3_gops(X3Regs<CT>& r, unsigned (&wh)[CT][4]) {
+__device__ __forceinline__ void x3_gops(X3Regs<CT>& r) {
     using XG = X3Geo<D, CT>;
     if constexpr (M < XG::MG && V < XG::gfirst(M + 1)) {
-        x3_gop<CT, V>(r, wh);
-        x3_gops<D, CT, M, V + 1>(r, wh);
+        x3_gop<CT, V>(r);
+        x3_gops<D, CT, M, V + 1>(r);
     }
 }
 template <int D, int CT, int M, int V = X3Geo<D, CT>::lfirst(M)>
-__device__ __forceinline__ void x3_lops(X3Regs<CT>& r, const unsigned (&wh)[CT][4]) {
+__device__ __forceinline__ void x3_lops(X3Regs<CT>& r) {
     using XG = X3Geo<D, CT>;
     if constexpr (M < XG::ML && V < XG::lfirst(M + 1)) {
-        x3_lop<CT, V>(r, wh);
-        x3_lops<D, CT, M, V + 1>(r, wh);
+        x3_lop<CT, V>(r);
+        x3_lops<D, CT, M, V + 1>(r);
     }
 }
-// all ops of one phase back to back (fill slot, drain: no MFMAs to hide them under)
-template <int D, int CT, int M = 0>
-__device__ __forceinline__ void x3_all_gops(X3Regs<CT>& r, unsigned (&wh)[CT][4]) {
-    if constexpr (M < X3Geo<D, CT>::MG) {
-        x3_gops<D, CT, M>(r, wh);
-        x3_all_gops<D, CT, M + 1>(r, wh);
+// all ops of one phase back to back (fill slot, drain, fenced slots: no MFMAs to hide them under)
+template <int D, int CT, int V = 0>
+__device__ __forceinline__ void x3_all_gops(X3Regs<CT>& r) {
+    if constexpr (V < X3Geo<D, CT>::GOPS) {
+        x3_gop<CT, V>(r);
+        x3_all_gops<D, CT, V + 1>(r);
     }
 }
-template <int D, int CT, int M = 0>
-__device__ __forceinline__ void x3_all_lops(X3Regs<CT>& r, const unsigned (&wh)[CT][4]) {
-    if constexpr (M < X3Geo<D, CT>::ML) {
-        x3_lops<D, CT, M>(r, wh);
-        x3_all_lops<D, CT, M + 1>(r, wh);
+template <int D, int CT, int V = 0>
+__device__ __forceinline__ void x3_all_lops(X3Regs<CT>& r) {
+    if constexpr (V < X3Geo<D, CT>::LOPS) {
+        x3_lop<CT, V>(r);
+        x3_all_lops<D, CT, V + 1>(r);
     }
 }
 
@@ -147,6 +211,22 @@ __device__ __forceinline__ void x3_pack(const unsigned (&w)[CT][4], bf16x8 (&pb)
     }
 }
 
+// ---- operand lifetimes hipcc cannot know about.  The SIMD issues an MFMA every 8 cycles but the matrix pipe starts one every 16:
+// in MFMA-dense stretches (the lo tiles at the end of G: two MFMAs per step and little else) MFMAs queue up in front of the pipe,
+// and an MFMA reads its A / B operands when it STARTS, not when it issues.  hipcc sees an operand dead right behind its last MFMA
+// and hands the register to the next asm result - e.g. the destination of a ds_read issued two MFMAs later, whose data then lands
+// (LDS latency ~64+ cycles) BEFORE the queued MFMA has read the old value.  Observed: the first A-fragment request of L(t+1)
+// was given the registers of pbh[0], the B operand of the third-last MFMA of G: column tile 0 NaN (tools/dbg_x3.py).  An empty
+// asm use keeps an operand reserved for at least a whole step (>= 2 CT MFMAs) behind its last MFMA: fragments and tiles two
+// steps, the operands of a chain's tail until the next chain's second step.
+template <int CT>
+__device__ __forceinline__ void x3_keep_pb(const bf16x8 (&pbh)[CT], const bf16x8 (&pbl)[CT]) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) asm volatile("" ::"v"(pbh[ct]), "v"(pbl[ct]));
+}
+__device__ __forceinline__ void x3_keep(const bf16x8& a) { asm volatile("" ::"v"(a)); }
+__device__ __forceinline__ void x3_keep(const s16x4& a, const s16x4& b) { asm volatile("" ::"v"(a), "v"(b)); }
+
 // first MFMA position of logits step I: steps 0 .. 2 KSH - 1 are hi steps (2 CT MFMAs), the rest lo steps (CT MFMAs)
 template <int D, int CT>
 __host__ __device__ constexpr int x3_lpos(int I) {
@@ -154,15 +234,25 @@ __host__ __device__ constexpr int x3_lpos(int I) {
     return I < NH ? I * 2 * CT : NH * 2 * CT + (I - NH) * CT;
 }
 
-// L(t): logits chain into r.acc with the lo halves of the PREVIOUS subtile's numerators (wh_prev -> r.wl) in its gaps
+// L(t): logits chain into r.acc with the hi / lo split of the PREVIOUS subtile's numerators (r.e -> r.wh, r.wl) in its gaps.
+// A fragment I + X3_AD is requested behind the first MFMA of step I, so X3_AD - 1 younger fragments are in flight at step I's wait.
 template <int D, int CT, int OFF, int I, bool HAS_PREV, bool COLD>
 __device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf16x8 (&af)[X3Geo<D, CT>::NI],
                                           const bf16x8 (&xh)[CT][X3Geo<D, CT>::KSH], const bf16x8 (&xl)[CT][X3Geo<D, CT>::KSH],
-                                          X3Regs<CT>& r, const unsigned (&wh_prev)[CT][4]) {
+                                          X3Regs<CT>& r) {
     using XG = X3Geo<D, CT>;
     if constexpr (I < XG::NI) {
+#if X3_OLD_L
         if constexpr (I + X3_AD < XG::NI) pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);
         lgkm_wait<(I + X3_AD < XG::NI ? X3_AD : XG::NI - 1 - I)>();
+#else
+        if constexpr (COLD || !(X3_PROBE & (2 | 16))) lgkm_wait<(I + X3_AD - 1 < XG::NI ? X3_AD - 1 : XG::NI - 1 - I)>();
+#if X3_L_ISSUE_AT < 0
+        if constexpr (I + X3_AD < XG::NI) pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);
+#else
+        if constexpr (I + X3_AD < XG::NI && !(X3_L_AFTER_COND)) pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);
+#endif
+#endif
         constexpr int s = I >> 1, rt = I & 1;
         constexpr int M0 = x3_lpos<D, CT>(I);
 #define PCVAE_X3_L(POS, INIT, XB)                                                                          \
@@ -170,7 +260,19 @@ __device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf
             constexpr int cti_ = (POS) % CT;                                                               \
             if constexpr (INIT) mfma_v0<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);              \
             else mfma_v<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);                              \
-            if constexpr (HAS_PREV && !COLD) x3_lops<D, CT, M0 + (POS)>(r, wh_prev);                       \
+            if constexpr (!X3_OLD_L && (POS) == X3_L_ISSUE_AT && I + X3_AD < XG::NI && (X3_L_AFTER_COND)) { \
+                X3_NOP_BEFORE                                                                              \
+                pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);                            \
+                X3_NOP_AFTER                                                                               \
+            }                                                                                              \
+            if constexpr ((POS) == 1 && I > 1) x3_keep(af[I - 2]);                                         \
+            if constexpr ((POS) == 1 && I == 2 && HAS_PREV) {   /* the tail operands of the gradient chain in front of this L */ \
+                x3_keep_pb<CT>(r.pbh, r.pbl);                                                              \
+                x3_keep(r.tl[XG::NDTL - 1], r.th[XG::NDTL - 1]);                                           \
+                x3_keep(r.tl[XG::NDTL - 2], r.th[XG::NDTL - 2]);                                           \
+                x3_keep(r.tl[XG::NDTL - 3], r.th[XG::NDTL - 3]);                                           \
+            }                                                                                              \
+            if constexpr (HAS_PREV && !COLD && !(X3_PROBE & 1)) x3_lops<D, CT, M0 + (POS)>(r);             \
         }
         if constexpr (s < XG::KSH) {
             PCVAE_X3_L(0, s == 0, xh)
@@ -182,7 +284,7 @@ __device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf
             if constexpr (CT > 1) PCVAE_X3_L(1, false, xh)
         }
 #undef PCVAE_X3_L
-        x3_logits<D, CT, OFF, I + 1, HAS_PREV, COLD>(lbase, a0, af, xh, xl, r, wh_prev);
+        x3_logits<D, CT, OFF, I + 1, HAS_PREV, COLD>(lbase, a0, af, xh, xl, r);
     }
 }
 
@@ -201,12 +303,13 @@ __host__ __device__ constexpr int x3_gpos(int DT) {
     return 2 * CT + (DT < NDT ? DT * 2 * CT : NDT * 2 * CT + (DT - NDT) * CT);
 }
 
-// G(t-1): gradient chain of the previous subtile (numerators pbh / pbl) with the exponentials + hi halves of subtile t
-// (r.acc -> r.e, wh_cur) in its gaps; in the middle: the seam and the first A fragments of the next slot
+// G(t-1): gradient chain of the previous subtile (numerators pbh / pbl) with the exponentials of subtile t (r.acc -> r.e) in its
+// gaps; in the middle: the seam and the first A fragments of the next slot.  The transposed reads of tile DT + X3_TD are requested
+// behind the first MFMA of step DT, so 2 (X3_TD - 1) younger reads are in flight at step DT's wait.
 template <int D, int CT, int OFFG, int OFFL_NEXT, int DT, bool HAS_G, int VM, bool COLD>
-__device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[X3Geo<D, CT>::NDTL],
-                                        s16x4 (&th)[X3Geo<D, CT>::NDTL], const bf16x8 (&pbh)[CT], const bf16x8 (&pbl)[CT],
-                                        X3Regs<CT>& r, unsigned (&wh_cur)[CT][4], f32x4 (&U)[X3Geo<D, CT>::NDT][CT],
+__device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s16x4 (&tl)[16], s16x4 (&th)[16],
+                                        const bf16x8 (&pbh)[CT], const bf16x8 (&pbl)[CT],
+                                        X3Regs<CT>& r, f32x4 (&U)[X3Geo<D, CT>::NDT][CT],
                                         const X3Seam& sm, const int wave_u, const int (&lane_off)[4], const int a0,
                                         bf16x8 (&af)[X3Geo<D, CT>::NI]) {
     using XG = X3Geo<D, CT>;
@@ -218,16 +321,24 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
                 asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
                 if (sm.n_stage >= 0) fast_stage<XG::DL, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
                 pipe_fence();
-            } else {
+            } else if constexpr (!(X3_PROBE & 8)) {
                 asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
                 pipe_stage<XG::DL>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
             }
-            pipe_a_prologue<XG::DL, OFFL_NEXT, X3_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
+            if constexpr (COLD || !(X3_PROBE & 2))
+                pipe_a_prologue<XG::DL, OFFL_NEXT, X3_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
         }
         if constexpr (HAS_G) {
-            constexpr int extra = (DT >= SEAM_AT && DT < SEAM_AT + X3_TD) ? X3_AD : 0;
+            // younger than tile DT's reads: tiles DT + 1 .. DT + X3_TD - 1, and the next slot's first A fragments once they are out
+            constexpr int young = (DT + X3_TD - 1 < NDTL ? X3_TD - 1 : NDTL - 1 - DT);
+            constexpr int extra = (DT >= SEAM_AT && DT - SEAM_AT < X3_TD) ? X3_AD : 0;   // issued behind a read that is still awaited
+#if X3_OLD_G
+            constexpr int extra_o = (DT >= SEAM_AT && DT < SEAM_AT + X3_TD) ? X3_AD : 0;
             if constexpr (DT + X3_TD < NDTL) tr_issue<XG::DL, OFFG, DT + X3_TD>(lbase_g, t0, tl[DT + X3_TD], th[DT + X3_TD]);
-            lgkm_wait<2 * ((DT + X3_TD < NDTL ? DT + X3_TD : NDTL - 1) - DT) + extra>();
+            lgkm_wait<2 * ((DT + X3_TD < NDTL ? DT + X3_TD : NDTL - 1) - DT) + extra_o>();
+#else
+            if constexpr (COLD || !(X3_PROBE & (2 | 4 | 16))) lgkm_wait<2 * young + extra>();
+#endif
         }
         const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
@@ -236,7 +347,13 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
 #define PCVAE_X3_G(POS, PB)                                                                                \
         {                                                                                                  \
             if constexpr (HAS_G) mfma_a<COLD>(U[UD][(POS) % CT], a, PB[(POS) % CT]);                       \
-            if constexpr (!COLD) x3_gops<D, CT, M0 + (POS)>(r, wh_cur);                                    \
+            if constexpr (!X3_OLD_G && HAS_G && (POS) == 0 && DT + X3_TD < NDTL && (COLD || !(X3_PROBE & 4)))     \
+                tr_issue<XG::DL, OFFG, DT + X3_TD>(lbase_g, t0, tl[DT + X3_TD], th[DT + X3_TD]);           \
+            if constexpr (HAS_G && (POS) == 1 && DT > 1) x3_keep(tl[DT - 2], th[DT - 2]);                  \
+            if constexpr (HAS_G && (POS) == 1 && DT == 1) {   /* the last fragments of the logits chain in front of this G */ \
+                x3_keep(af[XG::NI - 1]); x3_keep(af[XG::NI - 2]); x3_keep(af[XG::NI - 3]);                  \
+            }                                                                                              \
+            if constexpr (!COLD && !(X3_PROBE & 1)) x3_gops<D, CT, M0 + (POS)>(r);                         \
         }
         if constexpr (DT < XG::NDT) {
             PCVAE_X3_G(0, pbh)
@@ -248,51 +365,44 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
             if constexpr (CT > 1) PCVAE_X3_G(1, pbh)
         }
 #undef PCVAE_X3_G
-        x3_grad<D, CT, OFFG, OFFL_NEXT, DT + 1, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pbh, pbl, r, wh_cur, U, sm, wave_u, lane_off,
-                                                                  a0, af);
-    } else if constexpr (COLD) {
-        pipe_fence();
+        x3_grad<D, CT, OFFG, OFFL_NEXT, DT + 1, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pbh, pbl, r, U, sm, wave_u, lane_off, a0, af);
+    } else {
+        if constexpr (HAS_G) x3_keep_pb<CT>(pbh, pbl);   // (and on into the next logits chain: x3_logits, step 2)
+        if constexpr (COLD) pipe_fence();
     }
 }
 
-// one slot.  PAR = parity of slot t: the hi numerators of subtile t go to r.wh[PAR], G(t-1) reads r.wh[PAR ^ 1]
-template <int D, int CT, int PAR, int OFFL, int OFFG, int OFFL_NEXT, bool HAS_G, int VM, bool COLD>
+// one slot: L(t) || split of subtile t-1's numerators, then G(t-1) || exponentials of subtile t
+template <int D, int CT, int OFFL, int OFFG, int OFFL_NEXT, bool HAS_G, int VM, bool COLD>
 __device__ __forceinline__ void x3_slot(const unsigned lbase_l, const unsigned lbase_g, const FastLane& L,
                                         const bf16x8 (&xh)[CT][X3Geo<D, CT>::KSH], const bf16x8 (&xl)[CT][X3Geo<D, CT>::KSH],
                                         bf16x8 (&af)[X3Geo<D, CT>::NI], X3Regs<CT>& r, f32x4 (&U)[X3Geo<D, CT>::NDT][CT],
                                         f32x4 (&lsum)[CT], const X3Seam& sm, const int wave_u, const int (&lane_off)[4]) {
     using XG = X3Geo<D, CT>;
     if constexpr (COLD) pipe_fence();
-    x3_logits<D, CT, OFFL, 0, HAS_G, COLD>(lbase_l, L.a0, af, xh, xl, r, r.wh[PAR ^ 1]);
-    if constexpr (COLD && HAS_G) {      // fenced slots: nothing overlapped - the lo halves of the previous subtile now
+    x3_logits<D, CT, OFFL, 0, HAS_G, COLD>(lbase_l, L.a0, af, xh, xl, r);
+    if constexpr (COLD && HAS_G) {      // fenced slots: nothing overlapped - the split of the previous subtile's numerators now
         pipe_fence();
-        x3_all_lops<D, CT>(r, r.wh[PAR ^ 1]);
+        x3_all_lops<D, CT>(r);
         asm volatile("s_nop 1" ::: "memory");
     }
-    bf16x8 pbh[CT], pbl[CT];
-    x3_pack<CT>(r.wh[PAR ^ 1], pbh);
-    x3_pack<CT>(r.wl, pbl);
-    s16x4 tl[XG::NDTL], th[XG::NDTL];
+    x3_pack<CT>(r.wh, r.pbh);
+    x3_pack<CT>(r.wl, r.pbl);
     if constexpr (HAS_G) {
-        pipe_tr_prologue<XG::DL, OFFG, X3_TD>(lbase_g, L.t0, tl, th);
-#define PCVAE_X3_ONES(POS, PB)                                                                             \
-        {                                                                                                  \
-            mfma_a<COLD>(lsum[(POS) % CT], L.ones, PB[(POS) % CT]);                                        \
-            if constexpr (!COLD) x3_gops<D, CT, (POS)>(r, r.wh[PAR]);                                      \
-        }
-        PCVAE_X3_ONES(0, pbh)
-        if constexpr (CT > 1) PCVAE_X3_ONES(1, pbh)
-        PCVAE_X3_ONES(CT, pbl)
-        if constexpr (CT > 1) PCVAE_X3_ONES(CT + 1, pbl)
+        if constexpr (COLD || !(X3_PROBE & 4)) pipe_tr_prologue<XG::DL, OFFG, X3_TD>(lbase_g, L.t0, r.tl, r.th);
+#define PCVAE_X3_ONES(POS, PB) mfma_a<COLD>(lsum[(POS) % CT], L.ones, PB[(POS) % CT]);
+        PCVAE_X3_ONES(0, r.pbh)
+        if constexpr (CT > 1) PCVAE_X3_ONES(1, r.pbh)
+        PCVAE_X3_ONES(CT, r.pbl)
+        if constexpr (CT > 1) PCVAE_X3_ONES(CT + 1, r.pbl)
 #undef PCVAE_X3_ONES
     }
-    if constexpr (COLD) {               // exponentials + hi halves of this subtile, nothing overlapped
+    if constexpr (COLD) {               // exponentials of this subtile, nothing overlapped
         pipe_fence();
-        x3_all_gops<D, CT>(r, r.wh[PAR]);
+        x3_all_gops<D, CT>(r);
         asm volatile("s_nop 1" ::: "memory");
     }
-    x3_grad<D, CT, OFFG, OFFL_NEXT, 0, HAS_G, VM, COLD>(lbase_g, L.t0, tl, th, pbh, pbl, r, r.wh[PAR], U, sm, wave_u, lane_off,
-                                                        L.a0, af);
+    x3_grad<D, CT, OFFG, OFFL_NEXT, 0, HAS_G, VM, COLD>(lbase_g, L.t0, r.tl, r.th, r.pbh, r.pbl, r, U, sm, wave_u, lane_off, L.a0, af);
 }
 
 // ---- fenced gradient of one subtile (drain, ragged tail): nothing overlapped
@@ -414,8 +524,9 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
     using XG = X3Geo<D, CT>;
     using GL = typename XG::GL;
     constexpr int CB = 16384, NW = 4, ROWS = XG::ROWS, TR = XG::TR, NB = XG::NB, PF = XG::PF, DL = XG::DL;
-    static_assert(TR % 2 == 0, "the numerator parity must repeat every trip");
-    static_assert(XG::gfirst(XG::MG) == XG::GOPS && XG::lfirst(XG::ML - 2) == XG::LOPS, "every numerator op has a gap");
+    static_assert(XG::gfirst(XG::MG) == XG::GOPS && XG::gfirst(XG::MG - 1) == XG::GOPS, "every exponential has a gap");
+    static_assert(XG::lfirst(XG::ML - 2) == XG::LOPS, "every split op has a gap, the last two gaps of L stay free");
+    static_assert(XG::gfirst(2 * CT + 1) == 0, "no exponential before the row-sum MFMAs are out: the accumulators are fresh");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -485,7 +596,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
         {   // slot 0: nothing to drain yet
             X3Seam sm = seam_of(0);
             sm.next_lbase = lds_of(T > 1 ? 1 : 0);
-            x3_slot<D, CT, 0, 0, 0, 0, false, 0, true>(lds0, lds0, L, xh, xl, af, r, U, lsum, sm, wave_u, lane_off);
+            x3_slot<D, CT, 0, 0, 0, false, 0, true>(lds0, lds0, L, xh, xl, af, r, U, lsum, sm, wave_u, lane_off);
         }
         t = 1;
         // steady state: TR slots per trip, every LDS offset an immediate
@@ -496,8 +607,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
                 constexpr int OL = (TL % NB) * CB, OG = (TG % NB) * CB, ON = (TN % NB) * CB;                              \
                 X3Seam s2 = seam_of(t + UU);                                                                              \
                 s2.stage_lds = lds0 + ((TL + 1 + PF) % NB) * CB;   /* t = 1 (mod TR): a constant */                       \
-                x3_slot<D, CT, TL & 1, OL, OG, ON, true, (PF - 1) * 4, false>(lds0, lds0, L, xh, xl, af, r, U, lsum, s2, wave_u, \
-                                                                           lane_off);                                     \
+                x3_slot<D, CT, OL, OG, ON, true, (PF - 1) * 4, false>(lds0, lds0, L, xh, xl, af, r, U, lsum, s2, wave_u, lane_off); \
             }
             PCVAE_X3S(0) PCVAE_X3S(1) PCVAE_X3S(2) PCVAE_X3S(3) PCVAE_X3S(4) PCVAE_X3S(5)
 #undef PCVAE_X3S
@@ -507,14 +617,13 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
         for (; t < T; ++t) {
             X3Seam s2 = seam_of(t);
             s2.next_lbase = lds_of(t + 1 < T ? t + 1 : t);
-            if (t & 1) x3_slot<D, CT, 1, 0, 0, 0, true, 0, true>(lds_of(t), lds_of(t - 1), L, xh, xl, af, r, U, lsum, s2, wave_u, lane_off);
-            else x3_slot<D, CT, 0, 0, 0, 0, true, 0, true>(lds_of(t), lds_of(t - 1), L, xh, xl, af, r, U, lsum, s2, wave_u, lane_off);
+            x3_slot<D, CT, 0, 0, 0, true, 0, true>(lds_of(t), lds_of(t - 1), L, xh, xl, af, r, U, lsum, s2, wave_u, lane_off);
         }
         {   // drain: the lo halves of the last subtile's numerators, then its gradient chain
             bf16x8 pbh[CT], pbl[CT];
             pipe_fence();
-            if ((T - 1) & 1) { x3_all_lops<D, CT>(r, r.wh[1]); x3_pack<CT>(r.wh[1], pbh); }
-            else { x3_all_lops<D, CT>(r, r.wh[0]); x3_pack<CT>(r.wh[0], pbh); }
+            x3_all_lops<D, CT>(r);
+            x3_pack<CT>(r.wh, pbh);
             x3_pack<CT>(r.wl, pbl);
             asm volatile("s_nop 1" ::: "memory");
             x3_cold_gradient<D, CT>(lds_of(T - 1), L, pbh, pbl, U, lsum);

@@ -50,6 +50,38 @@ def forbidden_in(loop, no_mov=False):
     return bad
 
 
+def queued_operand_clobbers(loop, depth=4):
+    """LDS reads / VALU ops whose DESTINATION is a VGPR that one of the last `depth` MFMAs in front of them reads as A or B operand.
+
+    The SIMD issues an MFMA every 8 cycles, the matrix pipe starts one every 16: in MFMA-dense stretches MFMAs queue up and read
+    their operands when they START.  hipcc (which sees those operands dead behind their last MFMA) may hand the register to the
+    next asm result; data of a ds_read issued two MFMAs behind such a read has been seen to land before the queued MFMA consumed
+    the old value (catalog_x3.h, x3_keep).  The loop is walked twice so that the back edge is covered."""
+    seq = loop + loop
+    n = len(loop)
+    recent = []   # operand register sets of the last MFMAs
+    bad = []
+    for i, l in enumerate(seq):
+        op = l.split()[0]
+        args = [a.strip().split(" ")[0] for a in l[len(op):].split(",")] if " " in l else []
+        if op.startswith("v_mfma"):
+            srcs = set()
+            for a in args[1:3]:
+                k, r = _regs(a)
+                if k == "v":
+                    srcs |= r
+            recent.append(srcs)
+            recent = recent[-depth:]
+            continue
+        if i < n:
+            continue   # report on the second pass only (the first one warms `recent` up across the back edge)
+        if op.startswith("ds_read") or (op.startswith("v_") and not op.startswith("v_cmp")):
+            k, dst = _regs(args[0]) if args else (None, set())
+            if k == "v" and any(dst & r for r in recent):
+                bad.append(l)
+    return bad
+
+
 def forbidden(line):   # kept for callers that test single lines: the conservative form
     return line.startswith(FORBIDDEN)
 
@@ -95,10 +127,14 @@ def main():
         for loop in loops:
             c = collections.Counter(l.split()[0] for l in loop)
             bad = forbidden_in(loop, no_mov="catalog_ce_" in name)
-            print(f"{name[:70]}: unfenced loop of {len(loop)} instructions, {c['v_mfma_f32_16x16x32_bf16']} MFMA, {len(bad)} forbidden")
-            for b in bad[:10]:
+            clob = queued_operand_clobbers(loop)
+            print(f"{name[:70]}: unfenced loop of {len(loop)} instructions, {c['v_mfma_f32_16x16x32_bf16']} MFMA, {len(bad)} forbidden, "
+                  f"{len(clob)} writes into operands of the last 4 MFMAs")
+            for b in (bad + (clob if "x3" in name else []))[:10]:
                 print("   ", b)
-            ok = ok and not bad
+            # enforced for the bf16x3 kernel, whose schedule has MFMA-dense stretches where the hazard was observed; the round-1
+            # kernels (parity-tested on hardware at every size) are reported only
+            ok = ok and not bad and not (clob and "x3" in name)
     return 0 if ok else 1
 
 

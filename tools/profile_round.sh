@@ -1,10 +1,11 @@
 #!/bin/bash
 # profile_round.sh <tag>: the evidence behind bench.py's roofline block, for one round (run on the GPU box).
-#   1. bench.py (config 4, bf16) plain                                   -> gpurun_out/prof_<tag>/bench.json
-#   2. the same command under rocprofv3 --kernel-trace --stats            -> kernel_stats.csv, bench_under_rocprof.json
-#   3. separate --pmc passes (kernel-trace only) for HBM traffic and SQ    -> pmc_<set>.csv (per-kernel means)
-#   4. kernel stats of config 3 and config 5
-TAG=${1:-r01}
+#   1. bench.py (config 4, headline arithmetic = bf16x3, variants included)  -> gpurun_out/prof_<tag>/bench.json
+#   2. the headline alone under rocprofv3 --kernel-trace --stats              -> x3_config4_kernel_stats.csv (+ the bench line)
+#      and the other arithmetics / modes the same way                         -> f32_, bf16_, nneg_ _config4_kernel_stats.csv
+#   3. separate --pmc passes (kernel-trace only) for HBM traffic and SQ        -> x3_config4_pmc_<set>.csv (per-kernel means)
+#   4. kernel stats of config 3 and config 5 (their stated arithmetic: bf16)
+TAG=${1:-r02}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -20,12 +21,15 @@ stats() {  # stats <name> <bench args...>
   rm -rf $OUT/trace_$name
   echo "[stats] $name done" | tee -a $OUT/progress.log
 }
-stats config4 --steps 5 --warmup 2
+stats x3_config4 --steps 5 --warmup 2 --no-variants
+stats f32_config4 --dtype f32 --steps 5 --warmup 2 --no-variants --no-extras --no-cpu-baseline
+stats bf16_config4 --dtype bf16 --steps 5 --warmup 2 --no-variants --no-extras --no-cpu-baseline
+stats nneg_config4 --n_neg 1000 --steps 5 --warmup 2 --no-variants --no-extras --no-cpu-baseline
 pmc() {  # pmc <name> "<counters>"
   local name=$1
   rm -rf $OUT/pmc_$name
-  timeout -k 10 600 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_$name.log 2>&1
-  python3 $ROOT/tools/summarize_pmc.py $OUT/pmc_$name > $OUT/config4_pmc_$name.csv
+  timeout -k 10 600 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-variants > $OUT/pmc_$name.log 2>&1
+  python3 $ROOT/tools/summarize_pmc.py $OUT/pmc_$name > $OUT/x3_config4_pmc_$name.csv
   rm -rf $OUT/pmc_$name
   echo "[pmc] $name done" | tee -a $OUT/progress.log
 }
@@ -33,6 +37,6 @@ pmc FETCH_SIZE "FETCH_SIZE"
 pmc WRITE_SIZE "WRITE_SIZE"
 pmc SQ1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 pmc SQ2 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"
-stats config3 --config 3 --steps 5 --warmup 2
-stats config5 --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras
+stats bf16_config3 --config 3 --steps 5 --warmup 2 --no-variants
+stats bf16_config5 --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-variants
 ls -la $OUT
