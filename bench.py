@@ -453,6 +453,10 @@ def main():
     use_dist = world > 1 or os.environ.get("PCVAE_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL group: exercises the N>1 code on one GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # PCVAE_BENCH_FORCE_DIST without a launcher: a 1-rank RCCL group
+            os.environ.setdefault("MASTER_PORT", "29541")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     cfg = dict(CONFIGS[args.config])

@@ -255,3 +255,48 @@ def test_bf16_ce_random_shapes_every_kernel_choice(ops, monkeypatch):
             assert (dx.cpu() - wd).abs().max() < 1e-3 * wd.abs().max() + 1e-6, msg
             outs.append((lse, dx))
         torch.testing.assert_close(outs[0][0], outs[1][0], rtol=2e-5, atol=3e-5)
+
+
+def _train_curve(prec, steps=60):
+    """`steps` optimisation steps of a mid-size model (N = 20 000, S = 5, D = 64, B = 256) from a fixed init, with a fixed batch
+    sequence and the in-kernel Philox eps stream (same seed and offsets for every arithmetic) -> (losses, final parameters)"""
+    import pivotcvae_amd as pa
+    from pivotcvae_amd.train_generative import Trainer
+    S, D, Z, N, NU, B, H, HP = 5, 64, 8, 20000, 100, 256, 128, 64
+    C = S + 1
+    torch.manual_seed(0)
+    e_raw, u_raw = orc.synthetic_tables(N, NU, D, seed=0)
+    st = dict(enc=[S * D + C + D, H, H], psm=[Z + C + D, H, H, D], scm=[Z + C + 2 * D, H, H, (S - 1) * D], prior=[C + D, HP, HP])
+    m = pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"](torch.nn.Embedding.from_pretrained(e_raw), torch.nn.Embedding.from_pretrained(u_raw),
+                                              S, D, Z, C, st["enc"], st["psm"], st["scm"], st["prior"], False, DEV)
+    m.set_catalog_precision(prec)
+    tr = Trainer(m, lr=1e-3, beta=0.001)
+    g = torch.Generator().manual_seed(1)
+    losses = []
+    for _ in range(steps):
+        s = torch.randint(0, N, (B, S), generator=g).to(DEV)
+        u = torch.randint(0, NU, (B, 1), generator=g).to(DEV)
+        r = (torch.rand(B, S, generator=g) < 0.5).float().to(DEV)
+        loss, rec, kld = tr.step(s, r, u)
+        losses.append([loss.item(), rec.item(), kld.item()])
+    return np.array(losses), {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_bf16_training_tracks_f32_training():
+    """bf16 is a reported variant of the headline, so it has to TRAIN like the reference arithmetic, not just agree on one step:
+    60 Adam steps (lr 1e-3: the KL term falls from 56 to 2.4, the loss by 0.1 nat) from the same init, batches and eps in f32
+    and in bf16 catalog arithmetic.  Stated bounds: loss and reconstruction term of EVERY step within 1e-4 relative - the
+    north_star's ELBO tolerance - (measured 2.2e-5), the KL term within 5e-3 (measured 1.2e-3: it is a sum of small per-slate
+    terms that the noisy gradients move around), final parameters within 6 % of the distance training moved them (measured
+    3.3 %).  The same run in bf16x3 stays within 1e-6 / 1e-4 / 0.2 %."""
+    lf, pf = _train_curve("f32")
+    _, p0 = _train_curve("f32", steps=0)
+    assert lf[-1, 0] < lf[0, 0] - 0.05 and lf[-1, 2] < 0.1 * lf[0, 2]       # the run trains
+    dist = sum(float((pf[k] - p0[k]).pow(2).sum()) for k in pf) ** 0.5
+    for prec, tol_loss, tol_kld, tol_param in (("bf16", 1e-4, 5e-3, 0.06), ("bf16x3", 1e-6, 1e-4, 0.002)):
+        lb, pb = _train_curve(prec)
+        rel = np.abs(lb - lf) / np.abs(lf)
+        assert rel[:, :2].max() < tol_loss, (prec, rel[:, :2].max())
+        assert rel[:, 2].max() < tol_kld, (prec, rel[:, 2].max())
+        moved = sum(float((pf[k] - pb[k]).pow(2).sum()) for k in pf) ** 0.5
+        assert moved < tol_param * dist, (prec, moved, dist)
