@@ -318,21 +318,28 @@ __device__ __forceinline__ float block_sum_1024(float v) {
     return t;  // valid in wave 0
 }
 
+// Deterministic in (n, grid) - a fixed slice per block, partials combined in block order by whichever block finishes last - and
+// spread over up to 64 CUs: one block streaming the four [B, Z] arrays alone (2 MB at B = 8192) took 45 us, a latency-bound
+// 46 GB/s.  The partials live in a small device-global scratch: calls on different streams must not overlap (the trainer issues
+// everything on one stream).
+constexpr int KLD_MAX_BLOCKS = 64;
+__device__ float g_kld_partial[KLD_MAX_BLOCKS];
+__device__ unsigned int g_kld_done = 0;
+
 __global__ void __launch_bounds__(1024) kld_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
                                                        const float* __restrict__ pmu, const float* __restrict__ plv,
                                                        int64_t n, float* __restrict__ out) {
-    // one block (deterministic order); 16-byte loads and four independent chains per thread keep enough loads in flight for a
-    // single CU to stream the four arrays (B = 8192, Z = 16: 2 MB)
-    float acc = 0.f;
     const int64_t n4 = ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(lv) | reinterpret_cast<uintptr_t>(pmu) |
                          reinterpret_cast<uintptr_t>(plv)) & 15) == 0 ? n / 4 : 0;
     const float4* mu4 = reinterpret_cast<const float4*>(mu);
     const float4* lv4 = reinterpret_cast<const float4*>(lv);
     const float4* pmu4 = reinterpret_cast<const float4*>(pmu);
     const float4* plv4 = reinterpret_cast<const float4*>(plv);
+    // block b owns float4 elements [b * per, (b + 1) * per); the scalar tail belongs to the last block
+    const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n4 ? lo + per : n4;
     float a4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int64_t i = threadIdx.x; i < n4; i += blockDim.x) {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const float4 m = mu4[i], l = lv4[i], pm = pmu4[i], pl = plv4[i];
         const float d0 = m.x - pm.x, d1 = m.y - pm.y, d2 = m.z - pm.z, d3 = m.w - pm.w;
         a4[0] += 1.f + l.x - pl.x - (expf(l.x) + d0 * d0) / expf(pl.x);
@@ -340,19 +347,34 @@ __global__ void __launch_bounds__(1024) kld_fwd_kernel(const float* __restrict__
         a4[2] += 1.f + l.z - pl.z - (expf(l.z) + d2 * d2) / expf(pl.z);
         a4[3] += 1.f + l.w - pl.w - (expf(l.w) + d3 * d3) / expf(pl.w);
     }
-    acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-    for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
-        const float d = mu[i] - pmu[i];
-        acc += 1.f + lv[i] - plv[i] - (expf(lv[i]) + d * d) / expf(plv[i]);
-    }
+    float acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    if (blockIdx.x == gridDim.x - 1)
+        for (int64_t i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) {
+            const float d = mu[i] - pmu[i];
+            acc += 1.f + lv[i] - plv[i] - (expf(lv[i]) + d * d) / expf(plv[i]);
+        }
     const float t = block_sum_1024(acc);
-    if (threadIdx.x == 0) out[0] = -0.5f * t;
+    __shared__ bool last;
+    if (threadIdx.x == 0) {
+        g_kld_partial[blockIdx.x] = t;
+        __threadfence();
+        last = atomicAdd(&g_kld_done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        float tot = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += __builtin_nontemporal_load(&g_kld_partial[b]);   // block order: deterministic
+        out[0] = -0.5f * tot;
+        g_kld_done = 0;
+    }
 }
 
 extern "C" int pcvae_kld_fwd(const float* mu, const float* lv, const float* pmu, const float* plv, int64_t n,
                              float* kld_out, pcvae_stream_t stream) {
     PCVAE_REQUIRE(mu && lv && pmu && plv && kld_out && n >= 0, "kld_fwd: bad arguments");
-    hipLaunchKernelGGL(kld_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), mu, lv, pmu, plv, n, kld_out);
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(KLD_MAX_BLOCKS, cdiv(n / 4, 1024)));
+    hipLaunchKernelGGL(kld_fwd_kernel, dim3((unsigned)blocks), dim3(1024), 0, as_stream(stream), mu, lv, pmu, plv, n, kld_out);
     return check_launch("kld_fwd");
 }
 
