@@ -1,43 +1,48 @@
 #!/usr/bin/env python3
-"""install_profiles.py <tag>: copy the summaries tools/profile_round.sh left under gpurun_out/prof_<tag>/ into profiles/
-(the tracked, judged copies) and rebuild profiles/traffic.json (HBM traffic of the dominant kernel from the PMC passes, with
-the gfx950 FETCH_SIZE x2 correction) that bench.py reports as roofline.traffic."""
+"""install_profiles.py <tag> [<round>]: copy the summaries tools/profile_round.sh left under gpurun_out/prof_<tag>/ into profiles/
+(the tracked, judged copies, named r<round>_<arithmetic>_config<k>_*) and rebuild profiles/traffic.json: HBM traffic of the
+headline kernel from the PMC passes (with the gfx950 FETCH_SIZE x2 correction) that bench.py reports as roofline.traffic."""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
 src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles")
-names = {"bench.json": "r01_bf16_config4_bench.json", "config4_bench_under_rocprof.json": "r01_bf16_config4_bench_under_rocprof.json",
-         "config4_kernel_stats.csv": "r01_bf16_config4_kernel_stats.csv", "config3_kernel_stats.csv": "r01_bf16_config3_kernel_stats.csv",
-         "config3_bench_under_rocprof.json": "r01_bf16_config3_bench_under_rocprof.json",
-         "config5_kernel_stats.csv": "r01_bf16_config5_kernel_stats.csv", "config5_bench_under_rocprof.json": "r01_bf16_config5_bench_under_rocprof.json"}
+names = {"bench.json": f"{rnd}_config4_bench.json"}
+for a in ("x3_config4", "f32_config4", "bf16_config4", "nneg_config4", "bf16_config3", "bf16_config5"):
+    names[f"{a}_kernel_stats.csv"] = f"{rnd}_{a}_kernel_stats.csv"
+    names[f"{a}_bench_under_rocprof.json"] = f"{rnd}_{a}_bench_under_rocprof.json"
 for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ1", "SQ2"):
-    names[f"config4_pmc_{n}.csv"] = f"r01_bf16_config4_pmc_{n}.csv"
+    names[f"x3_config4_pmc_{n}.csv"] = f"{rnd}_x3_config4_pmc_{n}.csv"
 for a, b in names.items():
-    shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+    if os.path.exists(os.path.join(src, a)):
+        shutil.copy(os.path.join(src, a), os.path.join(dst, b))
+    else:
+        print("missing", a)
 bench = json.load(open(os.path.join(src, "bench.json")))
 kernel = bench["roofline"]["kernel"].split(" (")[0]
 key = kernel.split("<")[0]
 c = {}
 for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ1", "SQ2"):
-    for r in csv.DictReader(open(os.path.join(src, f"config4_pmc_{n}.csv"))):
+    for r in csv.DictReader(open(os.path.join(src, f"x3_config4_pmc_{n}.csv"))):
         if key in r["kernel"]:
             c[r["counter"]] = float(r["mean_per_dispatch"])
 avg_ns = None
-for r in csv.DictReader(open(os.path.join(src, "config4_kernel_stats.csv"))):
+for r in csv.DictReader(open(os.path.join(src, "x3_config4_kernel_stats.csv"))):
     if key in r["Name"]:
         avg_ns = float(r["AverageNs"])
 fetch, write = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024
 cycles = c["GRBM_GUI_ACTIVE"] / 8
 tpath = os.path.join(dst, "traffic.json")
 t = json.load(open(tpath)) if os.path.exists(tpath) else {}
-t["config4_bf16_gpus1"] = fetch + write
+t.setdefault("_round1", t.pop("_source", None))
+t["config4_bf16x3_gpus1"] = fetch + write
 t["_source"] = {
-    "round": 1, "kernel": kernel, "FETCH_SIZE_KB_mean": c["FETCH_SIZE"], "WRITE_SIZE_KB_mean": c["WRITE_SIZE"],
+    "round": rnd, "kernel": kernel, "FETCH_SIZE_KB_mean": c["FETCH_SIZE"], "WRITE_SIZE_KB_mean": c["WRITE_SIZE"],
     "fetch_correction": "x2 (gfx950: 128-B requests tallied at 64 B for 16 B/lane streaming reads; MI355X_MICROARCH.md HBM section)",
     "collected_with": "tools/profile_round.sh: rocprofv3 --pmc <set> --kernel-trace (one pass per set) -- python3 bench.py --steps 2 "
-                      "--warmup 1 --no-cpu-baseline --no-extras",
-    "note": "algorithmic minimum is ~0.47 GB (bf16 table 256 MB once + rx 42 MB + 170 MB of split partials); measured HBM-side traffic "
-            "%.2f GB per launch = %.0f GB/s over the %.1f ms launch: the kernel is MFMA-bound, not HBM-bound"
+                      "--warmup 1 --no-cpu-baseline --no-extras --no-variants",
+    "note": "algorithmic minimum is ~0.73 GB (bf16 hi|lo table image 512 MB once + rx 42 MB + ~170 MB of split partials); measured "
+            "HBM-side traffic %.2f GB per launch = %.0f GB/s over the %.1f ms launch: the kernel is MFMA-bound, not HBM-bound"
             % ((fetch + write) / 1e9, (fetch + write) / avg_ns, avg_ns / 1e6),
     "kernel_trace_avg_ms": avg_ns / 1e6,
     "SQ": {k: c[k] for k in ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY",
@@ -45,4 +50,4 @@ t["_source"] = {
     "derived": {"gpu_cycles_per_launch": cycles, "clock_GHz_under_load": cycles / avg_ns, "mfma_issued": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 16,
                 "mfma_pipe_utilisation": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)}}
 json.dump(t, open(tpath, "w"), indent=1)
-print(json.dumps(t["_source"]["derived"], indent=1), t["config4_bf16_gpus1"])
+print(json.dumps(t["_source"]["derived"], indent=1), t["config4_bf16x3_gpus1"])

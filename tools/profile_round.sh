@@ -21,7 +21,7 @@ stats() {  # stats <name> <bench args...>
   rm -rf $OUT/trace_$name
   echo "[stats] $name done" | tee -a $OUT/progress.log
 }
-stats x3_config4 --steps 5 --warmup 2 --no-variants
+stats x3_config4 --steps 5 --warmup 2 --no-variants --no-extras --no-cpu-baseline
 stats f32_config4 --dtype f32 --steps 5 --warmup 2 --no-variants --no-extras --no-cpu-baseline
 stats bf16_config4 --dtype bf16 --steps 5 --warmup 2 --no-variants --no-extras --no-cpu-baseline
 stats nneg_config4 --n_neg 1000 --steps 5 --warmup 2 --no-variants --no-extras --no-cpu-baseline
