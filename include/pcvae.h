@@ -182,6 +182,26 @@ int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo
 int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
                          float e_max_norm, int64_t* idx, float* best, void* ws, size_t ws_bytes, pcvae_stream_t stream);
 
+/* K1 + K2 + torch.cat in one launch                    models/pivotcvae.py:250-258 (condition, docEmbed, userEmbed), :166,201,213,231
+ *     (the concatenations), :194 (ground-truth pivot row): writes the item rows, the one-hot click count, the user row and the
+ *     pivot row straight into the three stack inputs and slot 0 of rx:
+ *       enc_in = [items (S D) | cond (S + 1) | user (D)], prior_in = [cond | user], scm_in = [z: untouched (Z) | cond | pivot | user],
+ *       rx[:, :D] = pivot.  U = u = NULL: the no-user model (the user windows do not exist).                         */
+int pcvae_assemble_inputs(const float* E, int64_t n_items, const float* U, int64_t n_users, const int64_t* s, const float* r,
+                          const int64_t* u, int64_t B, int S, int D, int ncols, int Z, float* enc_in, int64_t ld_enc,
+                          float* prior_in, int64_t ld_prior, float* scm_in, int64_t ld_scm, float* rx, int64_t ld_rx,
+                          pcvae_stream_t stream);
+
+/* K4 + K7 on PACKED head outputs y_enc = [mu | logvar], y_prior = [pmu | plogvar] ([B, 2 Z], leading dimension ld): what one
+ * N = 2 Z GEMM per stack produces when the two heads' weights are adjacent.  Forward: z (window, ldz), eps, KL sum; backward: the
+ * packed gradients g_enc = [dmu | dlogvar], g_prior = [dpmu | dplogvar].  models/cvae.py:79-83 + train_generative.py:61.       */
+int pcvae_latent_fwd_packed(const float* y_enc, const float* y_prior, int64_t ld, const float* eps_in, uint64_t seed,
+                            uint64_t offset, float* z, int64_t ldz, float* eps_out, float* kld_out, int64_t B, int Z,
+                            pcvae_stream_t stream);
+int pcvae_latent_bwd_packed(const float* dz, int64_t lddz, const float* eps, const float* y_enc, const float* y_prior,
+                            int64_t ld, const float* dkld_dev, float dkld_host, float* g_enc, float* g_prior, int64_t ldg,
+                            int64_t B, int Z, pcvae_stream_t stream);
+
 /* K5, sparse form for n_neg << N                        train_generative.py:36-44,59 (downsample(pred, slates, 1000) + CE)
  *     Same result as pcvae_catalog_ce with keep_prob < 1, but only the KEPT items of a row are touched: masked-out logits are
  *     the constant 0 (exp(0) = 1 each in the denominator, no gradient), so the kernel enumerates the kept set of a row

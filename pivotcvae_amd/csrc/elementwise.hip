@@ -326,6 +326,24 @@ constexpr int KLD_MAX_BLOCKS = 64;
 __device__ float g_kld_partial[KLD_MAX_BLOCKS];
 __device__ unsigned int g_kld_done = 0;
 
+// block partial t (valid in thread 0) -> out[0] = -0.5 * sum over blocks, combined in block order by the block that finishes last
+__device__ __forceinline__ void kld_combine(const float t, float* __restrict__ out) {
+    __shared__ bool last;
+    if (threadIdx.x == 0) {
+        g_kld_partial[blockIdx.x] = t;
+        __threadfence();
+        last = atomicAdd(&g_kld_done, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        float tot = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += __builtin_nontemporal_load(&g_kld_partial[b]);   // block order: deterministic
+        out[0] = -0.5f * tot;
+        g_kld_done = 0;
+    }
+}
+
 __global__ void __launch_bounds__(1024) kld_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
                                                        const float* __restrict__ pmu, const float* __restrict__ plv,
                                                        int64_t n, float* __restrict__ out) {
@@ -353,21 +371,7 @@ __global__ void __launch_bounds__(1024) kld_fwd_kernel(const float* __restrict__
             const float d = mu[i] - pmu[i];
             acc += 1.f + lv[i] - plv[i] - (expf(lv[i]) + d * d) / expf(plv[i]);
         }
-    const float t = block_sum_1024(acc);
-    __shared__ bool last;
-    if (threadIdx.x == 0) {
-        g_kld_partial[blockIdx.x] = t;
-        __threadfence();
-        last = atomicAdd(&g_kld_done, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-        __threadfence();
-        float tot = 0.f;
-        for (unsigned b = 0; b < gridDim.x; ++b) tot += __builtin_nontemporal_load(&g_kld_partial[b]);   // block order: deterministic
-        out[0] = -0.5f * tot;
-        g_kld_done = 0;
-    }
+    kld_combine(block_sum_1024(acc), out);
 }
 
 extern "C" int pcvae_kld_fwd(const float* mu, const float* lv, const float* pmu, const float* plv, int64_t n,
@@ -438,6 +442,142 @@ extern "C" int pcvae_latent_bwd(const float* dz, int64_t lddz, const float* eps,
     hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dz, lddz, eps, mu, lv, pmu,
                        plv, dkld_dev, dkld_host, dmu, dlv, dpmu, dplv, B, Z);
     return check_launch("latent_bwd");
+}
+
+// ---- the same two operations on PACKED head outputs: y_enc = [mu | logvar], y_prior = [pmu | plogvar], both [B, 2 Z] with leading
+// dimension ld - what ONE N = 2 Z GEMM per stack produces when the two heads' weights are adjacent (models/pivotcvae.py:
+// 170-173, 236-239 are two nn.Linear each).  Forward: z (into a column window of the slate-completion input) + eps + the KL sum in
+// one launch; backward: the packed gradients [dmu | dlogvar], [dpmu | dplogvar] in one launch.
+__global__ void __launch_bounds__(1024) latent_fwd_packed_kernel(const float* __restrict__ y_enc, const float* __restrict__ y_prior,
+                                                                 int64_t ld, const float* __restrict__ eps_in, uint64_t seed,
+                                                                 uint64_t offset, float* __restrict__ z, int64_t ldz,
+                                                                 float* __restrict__ eps_out, float* __restrict__ kld_out,
+                                                                 int64_t B, int Z) {
+    const int64_t n = B * Z;
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    float acc = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const int64_t b = i / Z;
+        const int k = (int)(i - b * Z);
+        const float mu = y_enc[b * ld + k], lv = y_enc[b * ld + Z + k];
+        const float pmu = y_prior[b * ld + k], plv = y_prior[b * ld + Z + k];
+        const float eps = eps_in ? eps_in[i] : philox_normal(seed, offset + (uint64_t)i);
+        z[b * ldz + k] = eps * expf(0.5f * lv) + mu;
+        eps_out[i] = eps;
+        const float d = mu - pmu;
+        acc += 1.f + lv - plv - (expf(lv) + d * d) / expf(plv);
+    }
+    kld_combine(block_sum_1024(acc), kld_out);
+}
+
+extern "C" int pcvae_latent_fwd_packed(const float* y_enc, const float* y_prior, int64_t ld, const float* eps_in, uint64_t seed,
+                                       uint64_t offset, float* z, int64_t ldz, float* eps_out, float* kld_out, int64_t B, int Z,
+                                       pcvae_stream_t stream) {
+    PCVAE_REQUIRE(y_enc && y_prior && z && eps_out && kld_out && Z > 0 && ld >= 2 * Z && ldz >= Z && B > 0,
+                  "latent_fwd_packed: bad arguments");
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(KLD_MAX_BLOCKS, cdiv(B * Z, 2048)));
+    hipLaunchKernelGGL(latent_fwd_packed_kernel, dim3((unsigned)blocks), dim3(1024), 0, as_stream(stream), y_enc, y_prior, ld, eps_in,
+                       seed, offset, z, ldz, eps_out, kld_out, B, Z);
+    return check_launch("latent_fwd_packed");
+}
+
+__global__ void latent_bwd_packed_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ eps,
+                                         const float* __restrict__ y_enc, const float* __restrict__ y_prior, int64_t ld,
+                                         const float* __restrict__ dkld_dev, float dkld_host, float* __restrict__ g_enc,
+                                         float* __restrict__ g_prior, int64_t ldg, int64_t B, int Z) {
+    const float sc = dkld_host * (dkld_dev ? dkld_dev[0] : 1.f);
+    const int64_t n = B * Z;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / Z;
+        const int k = (int)(i - b * Z);
+        const float mu = y_enc[b * ld + k], lv = y_enc[b * ld + Z + k];
+        const float pmu = y_prior[b * ld + k], plv = y_prior[b * ld + Z + k];
+        const float g = dz ? dz[b * lddz + k] : 0.f;
+        const float ip = expf(-plv), d = mu - pmu, ev = expf(lv);
+        g_enc[b * ldg + k] = g + sc * d * ip;
+        g_enc[b * ldg + Z + k] = g * eps[i] * 0.5f * expf(0.5f * lv) + sc * (-0.5f) * (1.f - ev * ip);
+        g_prior[b * ldg + k] = sc * (-d * ip);
+        g_prior[b * ldg + Z + k] = sc * (-0.5f) * (-1.f + (ev + d * d) * ip);
+    }
+}
+
+extern "C" int pcvae_latent_bwd_packed(const float* dz, int64_t lddz, const float* eps, const float* y_enc, const float* y_prior,
+                                       int64_t ld, const float* dkld_dev, float dkld_host, float* g_enc, float* g_prior,
+                                       int64_t ldg, int64_t B, int Z, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(eps && y_enc && y_prior && g_enc && g_prior && Z > 0 && ld >= 2 * Z && ldg >= 2 * Z && (!dz || lddz >= Z) && B > 0,
+                  "latent_bwd_packed: bad arguments");
+    const int64_t blocks = std::min<int64_t>(cdiv(B * Z, 256), 2048);
+    hipLaunchKernelGGL(latent_bwd_packed_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dz, lddz, eps, y_enc, y_prior,
+                       ld, dkld_dev, dkld_host, g_enc, g_prior, ldg, B, Z);
+    return check_launch("latent_bwd_packed");
+}
+
+// =============================================================================================
+// K1 + K2 + the reference's torch.cat's in one launch: everything the three MLP stacks read that does not depend on a weight
+// (models/pivotcvae.py:250-258 get_condition / docEmbed / userEmbed, :166, :201, :213, :231 the concatenations, :194 the
+// ground-truth pivot row) written straight into the stacks' input buffers - one wave per slate:
+//     enc_in  [B, S D + C (+ D)] = item rows | one-hot click count | user row
+//     prior_in[B, C (+ D)]       =             one-hot click count | user row
+//     scm_in  [B, Z + C + D (+D)]= (z: left for the latent kernel) | click count | pivot row E[s[b, 0]] | user row
+//     rx      [B, S D]           = pivot row | (slate-completion output: written by that stack's last GEMM)
+// replaces condition + two gathers + four concat launches and the copies they make.
+// =============================================================================================
+__global__ void __launch_bounds__(256) assemble_inputs_kernel(const float* __restrict__ E, const float* __restrict__ U,
+                                                              const int64_t* __restrict__ s, const float* __restrict__ r,
+                                                              const int64_t* __restrict__ u, int64_t B, int S, int D, int ncols, int Z,
+                                                              float* __restrict__ enc_in, int64_t ld_enc, float* __restrict__ prior_in,
+                                                              int64_t ld_prior, float* __restrict__ scm_in, int64_t ld_scm,
+                                                              float* __restrict__ rx, int64_t ld_rx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int C = S + 1;
+    float cnt = 0.f;
+    for (int j = 0; j < ncols; ++j) cnt += r[b * ncols + j];
+    const int c1 = (int)cnt;   // torch: sum(r).to(long) truncates
+    float* enc = enc_in + b * ld_enc;
+    float* pri = prior_in + b * ld_prior;
+    float* scm = scm_in + b * ld_scm;
+    for (int j = 0; j < S; ++j) {
+        const float* src = E + s[b * S + j] * (int64_t)D;
+        for (int d = lane; d < D; d += 64) {
+            const float v = src[d];
+            enc[j * D + d] = v;
+            if (j == 0) { scm[Z + C + d] = v; rx[b * ld_rx + d] = v; }
+        }
+    }
+    if (lane < C) {
+        const float v = lane == c1 ? 1.f : 0.f;
+        enc[S * D + lane] = v;
+        pri[lane] = v;
+        scm[Z + lane] = v;
+    }
+    if (U) {
+        const float* src = U + u[b] * (int64_t)D;
+        for (int d = lane; d < D; d += 64) {
+            const float v = src[d];
+            enc[S * D + C + d] = v;
+            pri[C + d] = v;
+            scm[Z + C + D + d] = v;
+        }
+    }
+}
+
+extern "C" int pcvae_assemble_inputs(const float* E, int64_t n_items, const float* U, int64_t n_users, const int64_t* s, const float* r,
+                                     const int64_t* u, int64_t B, int S, int D, int ncols, int Z, float* enc_in, int64_t ld_enc,
+                                     float* prior_in, int64_t ld_prior, float* scm_in, int64_t ld_scm, float* rx, int64_t ld_rx,
+                                     pcvae_stream_t stream) {
+    PCVAE_REQUIRE(E && s && r && enc_in && prior_in && scm_in && rx && (!U || u), "assemble_inputs: null pointer");
+    const int C = S + 1, ud = U ? D : 0;
+    PCVAE_REQUIRE(B >= 0 && S > 0 && S < 64 && D > 0 && ncols > 0 && Z > 0 && n_items > 0 && (!U || n_users > 0),
+                  "assemble_inputs: bad shape B=%lld S=%d D=%d", (long long)B, S, D);
+    PCVAE_REQUIRE(ld_enc >= (int64_t)S * D + C + ud && ld_prior >= C + ud && ld_scm >= (int64_t)Z + C + D + ud && ld_rx >= (int64_t)S * D,
+                  "assemble_inputs: a leading dimension is narrower than its row");
+    if (B == 0) return PCVAE_OK;
+    hipLaunchKernelGGL(assemble_inputs_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), E, U, s, r, u, B, S, D, ncols,
+                       Z, enc_in, ld_enc, prior_in, ld_prior, scm_in, ld_scm, rx, ld_rx);
+    return check_launch("assemble_inputs");
 }
 
 __global__ void __launch_bounds__(1024) sum_kernel(const float* __restrict__ x, int64_t n, float scale,

@@ -50,6 +50,12 @@ class UserPivotCVAE(BaseCVAE):
         self.last_pivot = None      # pivot item ids chosen by the most recent decode()
         self.to(self.device)
 
+    def flat_param_groups(self):
+        """parameters that want to be adjacent in the optimiser's flat buffer: the two heads of the encoder and of the prior (their
+        weights back to back are one [2 Z, K] operand: mu and logvar out of ONE GEMM, ops.mlp_heads_packed)"""
+        return [[self.encmu.weight, self.enclogvar.weight], [self.encmu.bias, self.enclogvar.bias],
+                [self.priorMu.weight, self.priorLogvar.weight], [self.priorMu.bias, self.priorLogvar.bias]]
+
     def params_without_grad(self):
         """trainable parameters that never receive a gradient under ANY pivot rule: the PSM stack (its output is
         either ignored or feeds a non-differentiable argmax / sample).  torch.optim.Adam skips them (grad is None)."""
@@ -139,6 +145,9 @@ class UserPivotCVAE(BaseCVAE):
         """
         B, S = s.shape
         N = self.docEmbed.weight.shape[0]
+        if self.TRAIN_RULE == "gt" and self.FUSED_TRAIN_PATH and r.shape[1] == S and \
+                ops.heads_adjacent(self.encmu, self.enclogvar) and ops.heads_adjacent(self.priorMu, self.priorLogvar):
+            return self._loss_fused(s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only)
         cond = self.get_condition(r)
         emb = ops.gather_rows(self.docEmbed.weight, s.reshape(-1), group=S)
         u_emb = self._user_rows(u, B)
@@ -163,6 +172,37 @@ class UserPivotCVAE(BaseCVAE):
         rec = ops.catalog_ce(rx.reshape(-1, self.feature_size), self.catalog_table(), s.reshape(-1), keep_prob,
                              mask_seed, row_offset * S, keep_mask, self.catalog_precision, inv_count)
         if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
+            return None, rec, k
+        return rec + beta * k, rec, k
+
+    FUSED_TRAIN_PATH = True   # tests switch it off to compare the two routes
+
+    def _loss_fused(self, s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only):
+        """loss() for the ground-truth pivot rule with a trainer's flat parameter buffer attached: the same arithmetic in fewer,
+        larger launches - one kernel assembles the three stack inputs (condition, gathers, concatenations), each stack's two heads
+        are one N = 2 Z GEMM, reparametrize + KL are one kernel that writes z straight into the slate-completion input, and that
+        stack's last GEMM writes slots 1.. of rx next to the pivot row."""
+        B, S = s.shape
+        D, Z = self.feature_size, self.latent_size
+        N = self.docEmbed.weight.shape[0]
+        enc_in, prior_in, scm_in, rx = ops.assemble_inputs(self.docEmbed.weight, None if self.noUser else self.userEmbed.weight,
+                                                           s, r, u, Z)
+        y_prior = ops.mlp_heads_packed(prior_in, self._mlp_layers("prior", self._n_prior), self._head("priorMu")[0],
+                                       self._head("priorLogvar")[0])
+        y_enc = ops.mlp_heads_packed(enc_in, self._mlp_layers("enc", self._n_enc), self._head("encmu")[0], self._head("enclogvar")[0])
+        if eps is None:
+            off = self._next_offset(B * Z) if eps_offset is None else int(eps_offset)
+            scm_x, self._last_eps, k = ops.latent_packed(y_enc, y_prior, scm_in, None, seed=self.rng_seed, offset=off, Z=Z)
+        else:
+            scm_x, self._last_eps, k = ops.latent_packed(y_enc, y_prior, scm_in, eps, Z=Z)
+        self.last_pivot = s[:, 0]
+        rx = ops.mlp_into(scm_x, self._mlp_layers("scm", self._n_scm), rx, D)
+        keep_prob = 1.0 if n_neg is None else float(n_neg) / N
+        if keep_prob > 1.0:
+            raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
+        rec = ops.catalog_ce(rx.reshape(-1, D), self.catalog_table(), s.reshape(-1), keep_prob, mask_seed, row_offset * S, keep_mask,
+                             self.catalog_precision, inv_count)
+        if terms_only:
             return None, rec, k
         return rec + beta * k, rec, k
 

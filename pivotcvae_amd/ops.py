@@ -310,6 +310,209 @@ def mlp_heads(x, trunk, head_a, head_b):
     return _MLPHeads.apply(x, len(trunk), *flat)
 
 
+# ---------------------------------------------------------------- fused training-path operators (fewer, larger launches)
+def assemble_inputs(E, U, s, r, u, Z):
+    """condition + item / user / pivot gathers + the reference's concatenations in ONE launch (pcvae_assemble_inputs).
+    -> (enc_in [B, S D + C (+D)], prior_in [B, C (+D)], scm_in [B, Z + C + D (+D)] with its z window unwritten, rx [B, S D] with
+    slot 0 = the ground-truth pivot's row)."""
+    require_device(E, U, s, r, u)
+    B, S = s.shape
+    D, C = E.shape[1], S + 1
+    ud = 0 if U is None else D
+    dev = E.device
+    s = s.to(torch.int64).contiguous()
+    r = r.to(F32).contiguous()
+    uu = None if U is None else u.reshape(-1).to(torch.int64).contiguous()
+    enc_in = torch.empty(B, S * D + C + ud, dtype=F32, device=dev)
+    prior_in = torch.empty(B, C + ud, dtype=F32, device=dev)
+    scm_in = torch.empty(B, Z + C + D + ud, dtype=F32, device=dev)
+    rx = torch.empty(B, S * D, dtype=F32, device=dev)
+    check(lib().pcvae_assemble_inputs(ptr(E, F32), E.shape[0], ptr(U, F32) if U is not None else None,
+                                      U.shape[0] if U is not None else 0, ptr(s), ptr(r, F32), ptr(uu), B, S, D, r.shape[1], Z,
+                                      ptr(enc_in, F32), _ld(enc_in), ptr(prior_in, F32), _ld(prior_in), ptr(scm_in, F32), _ld(scm_in),
+                                      ptr(rx, F32), _ld(rx), stream()), "assemble_inputs")
+    return enc_in, prior_in, scm_in, rx
+
+
+def heads_adjacent(head_a, head_b):
+    """can the two heads run as ONE N = 2 Z GEMM?  Their weights (and biases, and the gradient buffers attached to all four) must
+    be back to back in memory - what FlatAdam arranges for the groups a model lists in flat_param_groups()."""
+    Wa, ba, Wb, bb = head_a.weight, head_a.bias, head_b.weight, head_b.bias
+    if Wa.shape != Wb.shape or ba.shape != bb.shape or not (Wa.is_contiguous() and Wb.is_contiguous()):
+        return False
+
+    def back_to_back(x, y):
+        return x is not None and y is not None and x.is_cuda and x.is_contiguous() and y.is_contiguous() and \
+            y.data_ptr() == x.data_ptr() + x.numel() * 4
+
+    return back_to_back(Wa.data, Wb.data) and back_to_back(ba.data, bb.data) and back_to_back(Wa.grad, Wb.grad) and \
+        back_to_back(ba.grad, bb.grad)
+
+
+def _cat2(a, b):
+    """[a ; b] as one view: a and b are back to back in memory (heads_adjacent)"""
+    shape = (2 * a.shape[0],) + tuple(a.shape[1:])
+    return torch.as_strided(a, shape, a.stride())
+
+
+class _MLPHeadsPacked(torch.autograd.Function):
+    """LeakyReLU trunk + the two linear heads as ONE GEMM with N = 2 Z (models/pivotcvae.py:167-173, 232-239): the output is the
+    packed [mu | logvar].  Needs heads_adjacent(); gradients accumulate straight into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, n_trunk, *params):
+        require_device(x, *params)
+        x = _c2d(x)
+        acts = [x]
+        h = x
+        for i in range(n_trunk):
+            h = linear_fwd_raw(h, params[2 * i], params[2 * i + 1], ACT_LEAKY)
+            acts.append(h)
+        Wa, ba, Wb, bb = params[2 * n_trunk:2 * n_trunk + 4]
+        y = linear_fwd_raw(h, _cat2(Wa, Wb), _cat2(ba, bb), ACT_NONE)
+        ctx.n = n_trunk
+        ctx.direct = [p.grad for p in params]   # views of the flat gradient buffer: accumulated into in place
+        if any(g is None for g in ctx.direct):
+            raise RuntimeError("mlp_heads_packed needs gradient buffers attached to every parameter (FlatAdam)")
+        ctx.save_for_backward(*acts, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, params = saved[: n + 1], saved[n + 1:]
+        Wa, ba, Wb, bb = params[2 * n:2 * n + 4]
+        dWa, dba, dWb, dbb = ctx.direct[2 * n:2 * n + 4]
+        g = _c2d(g)
+        h = acts[n]
+        linear_bwd_weight_raw(g, h, _cat2(dWa, dWb), _cat2(dba, dbb))
+        grads = [None] * len(params)
+        if n == 0 and not ctx.needs_input_grad[0]:
+            return (None, None) + tuple(grads)
+        g = linear_bwd_input_raw(g, _cat2(Wa, Wb), xact=h if n > 0 else None)
+        for i in range(n - 1, -1, -1):
+            W, b = params[2 * i], params[2 * i + 1]
+            linear_bwd_weight_raw(g, acts[i], ctx.direct[2 * i], ctx.direct[2 * i + 1])
+            if i > 0:
+                g = linear_bwd_input_raw(g, W, xact=acts[i])
+            elif ctx.needs_input_grad[0]:
+                g = linear_bwd_input_raw(g, W, xact=None)
+            else:
+                g = None
+        return (g, None) + tuple(grads)
+
+
+def mlp_heads_packed(x, trunk, head_a, head_b):
+    """-> [head_a(trunk(x)) | head_b(trunk(x))] as one [B, 2 Z] tensor (heads_adjacent(head_a, head_b) must hold)"""
+    flat = []
+    for W, b in list(trunk) + [head_a, head_b]:
+        flat += [W, b]
+    return _MLPHeadsPacked.apply(x, len(trunk), *flat)
+
+
+class _LatentPacked(torch.autograd.Function):
+    """reparametrize + KLD on packed head outputs; z is written into the first Z columns of the slate-completion input, which is
+    returned (the reference's torch.cat([z, cond, pivot, user]) never happens)."""
+
+    @staticmethod
+    def forward(ctx, y_enc, y_prior, scm_in, eps, seed, offset, Z):
+        require_device(y_enc, y_prior, scm_in, eps)
+        y_enc, y_prior = _c2d(y_enc), _c2d(y_prior)
+        B = y_enc.shape[0]
+        if eps is not None:
+            eps = eps.to(F32).contiguous()
+        eps_used = torch.empty(B, Z, dtype=F32, device=y_enc.device)
+        k = torch.empty((), dtype=F32, device=y_enc.device)
+        if _ld(y_enc) != _ld(y_prior):
+            raise RuntimeError("latent_packed: the two packed inputs must share a leading dimension")
+        check(lib().pcvae_latent_fwd_packed(ptr(y_enc, F32), ptr(y_prior, F32), _ld(y_enc), ptr(eps, F32) if eps is not None else None,
+                                            seed, offset, ptr(scm_in, F32), _ld(scm_in), ptr(eps_used, F32), ptr(k, F32), B, Z,
+                                            stream()), "latent_fwd_packed")
+        ctx.Z = Z
+        ctx.save_for_backward(eps_used, y_enc, y_prior)
+        ctx.mark_dirty(scm_in)
+        ctx.mark_non_differentiable(eps_used)
+        ctx.set_materialize_grads(False)
+        return scm_in, eps_used, k
+
+    @staticmethod
+    def backward(ctx, g_scm, _geps, gk):
+        eps, y_enc, y_prior = ctx.saved_tensors
+        B, Z = eps.shape
+        g_enc = torch.empty(B, 2 * Z, dtype=F32, device=eps.device)
+        g_prior = torch.empty(B, 2 * Z, dtype=F32, device=eps.device)
+        if g_scm is not None:
+            g_scm = _c2d(g_scm)
+        gk_ptr, gk_host = (ptr(gk.contiguous(), F32), 1.0) if gk is not None else (None, 0.0)
+        check(lib().pcvae_latent_bwd_packed(ptr(g_scm, F32) if g_scm is not None else None, _ld(g_scm) if g_scm is not None else 0,
+                                            ptr(eps, F32), ptr(y_enc, F32), ptr(y_prior, F32), _ld(y_enc), gk_ptr, gk_host,
+                                            ptr(g_enc, F32), ptr(g_prior, F32), 2 * Z, B, Z, stream()), "latent_bwd_packed")
+        return g_enc, g_prior, None, None, None, None, None
+
+
+def latent_packed(y_enc, y_prior, scm_in, eps=None, seed=0, offset=0, Z=None):
+    """-> (scm_in with z in its first Z columns, eps_used, kld)"""
+    return _LatentPacked.apply(y_enc, y_prior, scm_in, eps, int(seed), int(offset), int(Z if Z is not None else y_enc.shape[1] // 2))
+
+
+class _MLPInto(torch.autograd.Function):
+    """_MLP (last layer linear) whose last layer writes into the column window [col0, col0 + out) of a prepared buffer, which is
+    returned whole: the slate-completion stack fills slots 1.. of rx next to the pivot row (models/pivotcvae.py:222-226's
+    reshape + cat never happens).  The columns in front of col0 are constants for autograd."""
+
+    @staticmethod
+    def forward(ctx, x, out_buf, col0, *params):
+        require_device(x, out_buf, *params)
+        n = len(params) // 2
+        x = _c2d(x)
+        acts = [x]
+        h = x
+        for i in range(n - 1):
+            h = linear_fwd_raw(h, params[2 * i], params[2 * i + 1], ACT_LEAKY)
+            acts.append(h)
+        width = params[2 * n - 2].shape[0]
+        linear_fwd_raw(h, params[2 * n - 2], params[2 * n - 1], ACT_NONE, out=out_buf[:, col0:col0 + width])
+        ctx.n, ctx.col0, ctx.width = n, col0, width
+        ctx.direct = [p.grad if (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_cuda
+                                 and p.grad.shape == p.shape and p.grad.is_contiguous()) else None for p in params]
+        ctx.save_for_backward(*acts, *params)
+        ctx.mark_dirty(out_buf)
+        return out_buf
+
+    @staticmethod
+    def backward(ctx, g):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        acts, params = saved[:n], saved[n:]
+        g = _c2d(g)[:, ctx.col0:ctx.col0 + ctx.width]
+        grads = [None] * (2 * n)
+        for i in range(n - 1, -1, -1):
+            W, b = params[2 * i], params[2 * i + 1]
+            if ctx.needs_input_grad[3 + 2 * i] or ctx.needs_input_grad[4 + 2 * i]:
+                dW, db = ctx.direct[2 * i], ctx.direct[2 * i + 1]
+                if dW is not None and db is not None:
+                    linear_bwd_weight_raw(g, acts[i], dW, db)
+                else:
+                    dW, db = torch.zeros_like(W), torch.zeros_like(b)
+                    linear_bwd_weight_raw(g, acts[i], dW, db)
+                    grads[2 * i], grads[2 * i + 1] = dW, db
+            if i > 0:
+                g = linear_bwd_input_raw(g, W, xact=acts[i])
+            elif ctx.needs_input_grad[0]:
+                g = linear_bwd_input_raw(g, W, xact=None)
+            else:
+                g = None
+        return (g, None, None) + tuple(grads)
+
+
+def mlp_into(x, layers, out_buf, col0):
+    flat = []
+    for W, b in layers:
+        flat += [W, b]
+    return _MLPInto.apply(x, out_buf, int(col0), *flat)
+
+
 def mlp(x, layers, last_linear):
     """layers: list of (weight [out,in], bias [out])."""
     flat = []

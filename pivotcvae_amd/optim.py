@@ -21,9 +21,19 @@ class FlatAdam:
     def __init__(self, model, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         # weight_decay: torch.optim.Adam's L2 term (pretrain_env.py:59); train_generative.py:103 passes none
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        if not self.params:
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
             raise ValueError("no trainable parameters")
+        # parameters the model wants ADJACENT in the flat buffer (the two heads of a stack: their weights back to back are one
+        # [2 Z, K] operand, so mu and logvar come out of ONE GEMM - models' flat_param_groups()); everything else in module order
+        groups = [[q for q in g if q.requires_grad] for g in getattr(model, "flat_param_groups", lambda: [])()]
+        first = {id(g[0]): g for g in groups if g}
+        placed, self.params = set(), []
+        for p in params:
+            for q in first.get(id(p), [p]):
+                if id(q) not in placed:
+                    placed.add(id(q))
+                    self.params.append(q)
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)

@@ -481,3 +481,35 @@ def test_train_on_dataset_on_the_hip_path(tmp_path, candidate):
     assert best.device == "cpu" and best.candidateFlag == candidate
     assert not torch.equal(best.state_dict()["scm_1.weight"], g.sd["scm_1.weight"])
     assert torch.equal(best.state_dict()["psm_1.weight"], g.sd["psm_1.weight"])       # the PSM never trains
+
+
+@pytest.mark.parametrize("name", ["pivotcvae_gt_pi_user", "pivotcvae_gt_pi_nouser", "pivotcvae_gt_pi_s10", "pivotcvae_gt_spi_user"])
+def test_fused_train_path_equals_the_operator_by_operator_path(name):
+    """With a trainer's flat buffers attached, loss() of the ground-truth pivot rule runs one assemble kernel, one N = 2 Z GEMM per
+    pair of heads, one latent kernel and writes the slate-completion output straight into rx (models/pivotcvae.py:_loss_fused).
+    Same numbers as the operator-by-operator route (FUSED_TRAIN_PATH = False): ELBO terms, every gradient, and the goldens."""
+    from pivotcvae_amd import ops
+    from pivotcvae_amd.optim import FlatAdam
+    g = load(name)
+    s, r, eps = dev(g.t("s")), dev(g.t("r")), dev(g.t("full/eps"))
+    u = None if g.meta["no_user"] else dev(g.t("u"))
+    res = {}
+    for fused in (True, False):
+        m = build_from_golden(g)
+        opt = FlatAdam(m, g.meta["lr"])
+        assert ops.heads_adjacent(m.encmu, m.enclogvar) and ops.heads_adjacent(m.priorMu, m.priorLogvar)
+        m.FUSED_TRAIN_PATH = fused
+        opt.zero_grad()
+        loss, rec, kld = m.loss(s, r, u, g.meta["beta"], eps=eps)
+        loss.backward()
+        res[fused] = ([loss.item(), rec.item(), kld.item()], {k: p.grad.clone() for k, p in m.named_parameters() if p.requires_grad})
+        # FlatAdam re-homed the parameters (heads adjacent): names, shapes and values are untouched
+        for k, v in m.state_dict().items():
+            assert torch.equal(v.cpu(), g.sd[k]), k
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-6)
+    np.testing.assert_allclose(res[True][0], g.a["full/loss"], rtol=1e-4)
+    want = g.sub("grad")
+    for k, gf in res[False][1].items():
+        close(res[True][1][k], gf, rtol=1e-5, atol=1e-8)
+        if k in want:
+            close(res[True][1][k], want[k], rtol=2e-4, atol=2e-6)
