@@ -213,6 +213,15 @@ int pcvae_latent_bwd_packed(const float* dz, int64_t lddz, const float* eps, con
 int pcvae_catalog_ce_sparse(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                             float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
                             pcvae_stream_t stream);
+/* the same two calls writing dx * dx_scale: the 1 / (rows * world_size) of CrossEntropyLoss's mean folded into the kernel, so that
+ * the backward of the mean-reduced loss needs no scaling launch when the upstream gradient is 1 (train_generative.py:59,133)  */
+int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
+                                   float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
+                                   float dx_scale, pcvae_stream_t stream);
+int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
+                            float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
+                            const uint8_t* keep_mask, float* nll, float* lse, float* dx, float dx_scale, void* ws,
+                            size_t ws_bytes, pcvae_stream_t stream);
 
 /* K10 sampled pivot                                     models/pivotcvae.py:349-351, 371-373
  *     idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) over the whole catalog, drawn with the Gumbel-max trick

@@ -51,6 +51,8 @@ SIGNATURES = {
     "pcvae_catalog_ce_variant": [_L, _L, _I, _I],
     "pcvae_catalog_ce": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _F, _U64, _U64, _P, _P, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_ce_sparse": [_P, _L, _P, _L, _I, _P, _F, _U64, _U64, _P, _P, _P, _P],
+    "pcvae_catalog_ce_sparse_scaled": [_P, _L, _P, _L, _I, _P, _F, _U64, _U64, _P, _P, _P, _F, _P],
+    "pcvae_catalog_ce_scaled": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _F, _U64, _U64, _P, _P, _P, _P, _F, _P, _SZ, _P],
     "pcvae_catalog_argmax": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_sample": [_P, _L, _P, _P, _L, _I, _I, _U64, _U64, _P, _P, _SZ, _P],
     "pcvae_split_bf16": [_P, _L, _P, _P, _P],

@@ -40,6 +40,14 @@ extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const
                                 int prec, float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed,
                                 uint64_t row_offset, const uint8_t* keep_mask, float* nll, float* lse, float* dx,
                                 void* ws, size_t ws_bytes, pcvae_stream_t stream) {
+    return pcvae_catalog_ce_scaled(rx, R, E, E_lo, N, D, prec, e_max_norm, target, keep_prob, seed, row_offset, keep_mask, nll, lse,
+                                   dx, 1.0f, ws, ws_bytes, stream);
+}
+
+extern "C" int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
+                                       int prec, float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed,
+                                       uint64_t row_offset, const uint8_t* keep_mask, float* nll, float* lse, float* dx,
+                                       float dx_scale, void* ws, size_t ws_bytes, pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && target && nll && ws, "catalog_ce: null pointer");
     PCVAE_REQUIRE(R > 0 && N > 0, "catalog_ce: empty problem R=%lld N=%lld", (long long)R, (long long)N);
     PCVAE_REQUIRE(supported_d(D), "catalog_ce: unsupported D=%d (16, 32, 64, 128, 256)", D);
@@ -55,12 +63,12 @@ extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const
         (void)E_lo;
         (void)e_max_norm;
         return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E), N, D, target, keep_prob, seed, row_offset,
-                              keep_mask, nll, lse, dx, ws, as_stream(stream));
+                              keep_mask, nll, lse, dx, dx_scale, ws, as_stream(stream));
     }
     if (prec == PCVAE_PREC_BF16) {
         (void)E_lo;
         return catalog_ce_bf16(rx, R, reinterpret_cast<const uint16_t*>(E), N, D, e_max_norm, target, keep_prob, seed,
-                               row_offset, keep_mask, nll, lse, dx, ws, as_stream(stream));
+                               row_offset, keep_mask, nll, lse, dx, dx_scale, ws, as_stream(stream));
     }
     if (prec == PCVAE_PREC_BF16X3) {
         // E = the [N, 2 D] bf16 hi | lo image (pcvae_split_bf16x2), E_lo = the fp32 table itself (exact target logit / target
@@ -69,9 +77,9 @@ extern "C" int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const
                       "catalog_ce(bf16x3): needs D = 128, the fp32 table in E_lo and e_max_norm > 0");
         if (keep_mask || keep_prob < 1.0f)
             return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E_lo), N, D, target, keep_prob, seed, row_offset,
-                                  keep_mask, nll, lse, dx, ws, as_stream(stream));
+                                  keep_mask, nll, lse, dx, dx_scale, ws, as_stream(stream));
         return catalog_ce_x3(rx, R, reinterpret_cast<const uint16_t*>(E), reinterpret_cast<const float*>(E_lo), N, D,
-                             e_max_norm, target, nll, lse, dx, ws, as_stream(stream));
+                             e_max_norm, target, nll, lse, dx, dx_scale, ws, as_stream(stream));
     }
     set_error("catalog_ce: precision mode %d not available in this build", prec);
     return PCVAE_EINVAL;

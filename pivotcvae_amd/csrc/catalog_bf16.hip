@@ -64,6 +64,7 @@ struct CatParamsB {
     float* pU;              // [nsplit][R][D]
     const uint8_t* safe_flags;  // [nrb] or null: 1 = this row block needs the lazy-max kernel (large |rx|)
     int run_if_flag;        // this launch handles the row blocks whose flag equals this value
+    float dx_scale;         // merge kernels: dx is written times this (the 1 / (R W) of the mean reduction)
     int rem_mode;           // fast kernel only: G > 0 = handle what the pipelined kernel of this shape leaves over of every range
                             // (its last tiles, see pipe_slots_of) and ADD the result into that kernel's partials (both are
                             // max-free: pm = 0, so partials simply add up).  The grid is then nrb x G: a workgroup walks the
@@ -1392,7 +1393,7 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_bf16_kernel(CatParamsB p
                 for (int q = 0; q < 8; ++q) u = fmaf(v[q], __shfl(sj, j + q, 64), u);
             }
             for (; j < p.nsplit; ++j) u = fmaf(p.pU[((int64_t)j * p.R + r) * D + d], __shfl(sj, j, 64), u);
-            dx[r * D + d] = t_ok ? u * invL - bf16_to_f32(p.E[t * D + d]) : NAN;
+            dx[r * D + d] = t_ok ? (u * invL - bf16_to_f32(p.E[t * D + d])) * p.dx_scale : NAN;
         }
     }
 }
@@ -2037,7 +2038,7 @@ __global__ void catalog_screen_decode_kernel(ScreenParams p, int64_t* __restrict
 namespace pcvae {
 
 int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
-                  const int64_t* target, float* nll, float* lse, float* dx, void* ws, hipStream_t st) {
+                  const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
     if (D != 128) {
         set_error("catalog_ce(bf16x3): D=%d (the kernel exists for D = 128)", D);
         return PCVAE_EINVAL;
@@ -2046,7 +2047,7 @@ int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* E
     using XG = X3Geo<128, CT>;
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16X3);
     CatParamsB p{};
-    p.rx = rx; p.E = Ex; p.target = target; p.R = R; p.N = N;
+    p.rx = rx; p.E = Ex; p.target = target; p.R = R; p.N = N; p.dx_scale = dx_scale;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
     const int64_t ns = pl.nsplit;
     p.pm = reinterpret_cast<float*>(ws);
@@ -2072,14 +2073,15 @@ int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* E
     if (rc != PCVAE_OK) return rc;
     // flagged row blocks (normally none): the exact f32 kernel on its own partials behind the flags, rows of flag 1 only
     char* ws2 = reinterpret_cast<char*>(flags) + ((p.nrb + 255) / 256) * 256;
-    return catalog_ce_f32_flagged(rx, R, Ef, N, D, target, nll, lse, dx, ws2, flags, st);
+    return catalog_ce_f32_flagged(rx, R, Ef, N, D, target, nll, lse, dx, dx_scale, ws2, flags, st);
 }
 
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
-                    const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, hipStream_t st) {
+                    const uint8_t* keep_mask, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16);
     CatParamsB p{};
+    p.dx_scale = dx_scale;
     p.rx = rx; p.E = E; p.target = target; p.keep = keep_mask;
     p.seed = seed; p.row_offset = row_offset; p.R = R; p.N = N;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;

@@ -44,6 +44,7 @@ struct CatParams {
     float* pU;            // [nsplit][R][D] numerator vector   (CE with dx only)
     int64_t* pn;          // [nsplit][R]   argmax index
     const uint8_t* flags; // CE only, or null: one byte per 256-row block; only blocks whose flag is 1 are computed / written
+    float dx_scale;       // CE: dx is written times this (the 1 / (R W) of the mean reduction: no separate scaling launch)
 };
 
 template <int D>
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_f32_kernel(CatParams p, 
             float u = 0.f;
             for (int j = 0; j < p.nsplit; ++j)
                 u += p.pU[((int64_t)j * p.R + r) * D + d] * __expf(p.pm[(int64_t)j * p.R + r] - M);
-            dx[r * D + d] = t_ok ? u * invL - p.E[t * D + d] : NAN;
+            dx[r * D + d] = t_ok ? (u * invL - p.E[t * D + d]) * p.dx_scale : NAN;
         }
     }
 }
@@ -429,10 +430,10 @@ int launch_argmax(const CatParams& p, bool sample, int64_t* idx, float* best, hi
 namespace pcvae {
 
 int catalog_ce_f32_flagged(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target, float* nll,
-                           float* lse, float* dx, void* ws, const uint8_t* flags, hipStream_t st) {
+                           float* lse, float* dx, float dx_scale, void* ws, const uint8_t* flags, hipStream_t st) {
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);
     CatParams p{};
-    p.rx = rx; p.E = E; p.target = target; p.R = R; p.N = N; p.flags = flags;
+    p.rx = rx; p.E = E; p.target = target; p.R = R; p.N = N; p.flags = flags; p.dx_scale = dx_scale;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
     p.pm = reinterpret_cast<float*>(ws);
     p.pl = p.pm + (int64_t)pl.nsplit * R;
@@ -444,9 +445,10 @@ int catalog_ce_f32_flagged(const float* rx, int64_t R, const float* E, int64_t N
 
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,
-                   float* lse, float* dx, void* ws, hipStream_t st) {
+                   float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);
     CatParams p{};
+    p.dx_scale = dx_scale;
     p.rx = rx; p.E = E; p.target = target; p.keep = keep_mask;
     p.seed = seed; p.row_offset = row_offset; p.R = R; p.N = N;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;

@@ -75,15 +75,15 @@ static inline bool catalog_bf16_pipelined(int D, int tiles_per_split) {
 
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                    float keep_prob, uint64_t seed, uint64_t row_offset, const uint8_t* keep_mask, float* nll,
-                   float* lse, float* dx, void* ws, hipStream_t st);
+                   float* lse, float* dx, float dx_scale, void* ws, hipStream_t st);
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
-                    const uint8_t* keep_mask, float* nll, float* lse, float* dx, void* ws, hipStream_t st);
+                    const uint8_t* keep_mask, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st);
 int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
-                  const int64_t* target, float* nll, float* lse, float* dx, void* ws, hipStream_t st);
+                  const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st);
 // the exact f32 kernel restricted to the 256-row blocks whose flag is 1 (the fallback of the max-free bf16x3 kernel)
 int catalog_ce_f32_flagged(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target, float* nll,
-                           float* lse, float* dx, void* ws, const uint8_t* flags, hipStream_t st);
+                           float* lse, float* dx, float dx_scale, void* ws, const uint8_t* flags, hipStream_t st);
 size_t catalog_x3_ws_bytes(int64_t R, int64_t N, int D);
 int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const float* Ef, int64_t N, int D, float e_max_norm,
                             int64_t* idx, float* best, void* ws, hipStream_t st);

@@ -35,6 +35,7 @@ struct SparseParams {
     float* nll;             // [R]
     float* lse;             // [R] or null
     float* dx;              // [R, D] or null
+    float dx_scale;         // dx is written times this
 };
 
 // gap of the Bernoulli(p) process from 52 random bits: floor(ln U * inv_log_q), U = (2 u + 1) / 2^53 in (0, 1)
@@ -184,13 +185,14 @@ __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) 
         if (p.lse) p.lse[r] = lse_r;
     }
     if (WANT_DX && grp == 0) {
-        const float w = sk / L;
+        const float w = sk / L * p.dx_scale;
         float4 ta = make_float4(NAN, NAN, NAN, NAN), tb = ta;
         if (t_ok) {
             const float4 a = *reinterpret_cast<const float4*>(p.E + tgt * D + 4 * j);
             const float4 b = *reinterpret_cast<const float4*>(p.E + tgt * D + D / 2 + 4 * j);
-            ta = make_float4(ua.x * w - a.x, ua.y * w - a.y, ua.z * w - a.z, ua.w * w - a.w);
-            tb = make_float4(ub.x * w - b.x, ub.y * w - b.y, ub.z * w - b.z, ub.w * w - b.w);
+            const float q = p.dx_scale;
+            ta = make_float4(ua.x * w - a.x * q, ua.y * w - a.y * q, ua.z * w - a.z * q, ua.w * w - a.w * q);
+            tb = make_float4(ub.x * w - b.x * q, ub.y * w - b.y * q, ub.z * w - b.z * q, ub.w * w - b.w * q);
         }
         *reinterpret_cast<float4*>(p.dx + r * D + 4 * j) = ta;
         *reinterpret_cast<float4*>(p.dx + r * D + D / 2 + 4 * j) = tb;
@@ -210,13 +212,19 @@ int launch_sparse(const SparseParams& p, hipStream_t st) {
 extern "C" int pcvae_catalog_ce_sparse(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                                        float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
                                        pcvae_stream_t stream) {
+    return pcvae_catalog_ce_sparse_scaled(rx, R, E, N, D, target, keep_prob, seed, row_offset, nll, lse, dx, 1.0f, stream);
+}
+
+extern "C" int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
+                                              float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse,
+                                              float* dx, float dx_scale, pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && target && nll, "catalog_ce_sparse: null pointer");
     PCVAE_REQUIRE(R > 0 && N > 0 && N < 2147483647LL, "catalog_ce_sparse: bad problem R=%lld N=%lld", (long long)R, (long long)N);
     PCVAE_REQUIRE(keep_prob > 0.f && keep_prob < 1.f, "catalog_ce_sparse: keep_prob must be in (0, 1)");
     PCVAE_REQUIRE(((uintptr_t)rx % 16 == 0) && ((uintptr_t)E % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0),
                   "catalog_ce_sparse: rx/E/dx must be 16-byte aligned");
     PCVAE_REQUIRE(cdiv(R, 4) <= 2147483647LL, "catalog_ce_sparse: R too large");
-    SparseParams p{rx, E, target, R, N, seed, row_offset, 1.0 / log1p(-(double)keep_prob), nll, lse, dx};
+    SparseParams p{rx, E, target, R, N, seed, row_offset, 1.0 / log1p(-(double)keep_prob), nll, lse, dx, dx_scale};
     switch (D) {
         case 16: return launch_sparse<16>(p, as_stream(stream));
         case 32: return launch_sparse<32>(p, as_stream(stream));

@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_x3_kernel(CatParamsB p, 
         for (int d = lane; d < D; d += 64) {
             float u = 0.f;
             for (int j = 0; j < p.nsplit; ++j) u += p.pU[((int64_t)j * p.R + r) * D + d];
-            dx[r * D + d] = t_ok ? u * invL - Ef[t * D + d] : NAN;
+            dx[r * D + d] = t_ok ? (u * invL - Ef[t * D + d]) * p.dx_scale : NAN;
         }
     }
 }

@@ -88,7 +88,8 @@ class UserListCVAEWithPrior(BaseCVAE):
         if keep_prob > 1.0:
             raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
         rec = ops.catalog_ce(rx.reshape(-1, self.feature_size), self.catalog_table(), s.reshape(-1), keep_prob,
-                             mask_seed, row_offset * s.shape[1], keep_mask, self.catalog_precision, inv_count)
+                             mask_seed, row_offset * s.shape[1], keep_mask, self.catalog_precision, inv_count,
+                             unit_upstream=terms_only)
         if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
             return None, rec, k
         return rec + beta * k, rec, k

@@ -781,7 +781,7 @@ def sparse_ce_applies(keep_prob, N):
     return 0.0 < keep_prob <= SPARSE_MAX_KEEP_PROB and N < 2 ** 31 - 1
 
 
-def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, want_dx=True):
+def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, want_dx=True, dx_scale=1.0):
     """catalog_ce_raw for keep_prob << 1: only the kept rows of the fp32 table are read (pcvae_catalog_ce_sparse).
     -> (nll [R], lse [R], dx [R, D] or None).  Exact fp32 whatever the table's precision mode is."""
     table = _as_table(table)
@@ -799,8 +799,9 @@ def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, wa
     dx = torch.empty(R, D, dtype=F32, device=rx.device) if want_dx else None
     timing = CATALOG_CE_TIMING
     tok = timing[0]() if timing else None
-    check(lib().pcvae_catalog_ce_sparse(ptr(rx, F32), R, ptr(E, F32), N, D, ptr(target), float(keep_prob), int(seed),
-                                        int(row_offset), ptr(nll, F32), ptr(lse, F32), ptr(dx), stream()), "catalog_ce_sparse")
+    check(lib().pcvae_catalog_ce_sparse_scaled(ptr(rx, F32), R, ptr(E, F32), N, D, ptr(target), float(keep_prob), int(seed),
+                                               int(row_offset), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), stream()),
+          "catalog_ce_sparse")
     if timing:
         timing[1](tok)
     if dx is not None and D != D0:
@@ -828,8 +829,8 @@ def _pad_cols(x, Dp):
 
 
 def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32,
-                   want_dx=True):
-    """-> (nll [R], lse [R], dx [R, D] or None); see pcvae_catalog_ce in include/pcvae.h."""
+                   want_dx=True, dx_scale=1.0):
+    """-> (nll [R], lse [R], dx [R, D] * dx_scale or None); see pcvae_catalog_ce in include/pcvae.h."""
     table = _as_table(table)
     require_device(rx, table.weight, target, keep_mask)
     rx = _c2d(rx).contiguous()
@@ -844,7 +845,7 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
             raise ValueError("catalog_ce: keep_mask must be [R, N]")
     prec = effective_precision(prec, D0)
     if keep_mask is None and keep_prob < 1.0 and sparse_ce_applies(keep_prob, N):
-        return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx)
+        return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx, dx_scale)
     if keep_mask is not None or keep_prob < 1.0:
         prec = PREC_F32 if prec == PREC_BF16X3 else prec   # masked calls: the x3 kernel is max-free / mask-free
     E, E_lo = table.operands(prec)
@@ -857,10 +858,9 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     ws = _workspace(rx.device, nbytes)
     timing = CATALOG_CE_TIMING
     tok = timing[0]() if timing else None
-    check(lib().pcvae_catalog_ce(ptr(rx, F32), R, ptr(E), ptr(E_lo), N, D, prec, table.e_max_norm(prec), ptr(target),
-                                 float(keep_prob),
-                                 int(seed), int(row_offset), ptr(keep_mask), ptr(nll, F32), ptr(lse, F32), ptr(dx),
-                                 ptr(ws), ws.numel(), stream()), "catalog_ce")
+    check(lib().pcvae_catalog_ce_scaled(ptr(rx, F32), R, ptr(E), ptr(E_lo), N, D, prec, table.e_max_norm(prec), ptr(target),
+                                        float(keep_prob), int(seed), int(row_offset), ptr(keep_mask), ptr(nll, F32), ptr(lse, F32),
+                                        ptr(dx), float(dx_scale), ptr(ws), ws.numel(), stream()), "catalog_ce")
     if timing:
         timing[1](tok)
     if dx is not None and D != D0:
@@ -869,15 +869,19 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
 
 
 class _CatalogCE(torch.autograd.Function):
-    """mean-reduced (times ``inv_count``) full-catalog softmax CE; backward = saved direction * upstream."""
+    """mean-reduced (times ``inv_count``) full-catalog softmax CE; backward = saved direction * upstream.
+    ``unit_upstream``: the caller promises to seed the backward of this loss with exactly 1 (Trainer does: it seeds (rec, KLD) with
+    (1, beta)); the kernel then writes the direction times inv_count and backward hands it on without a scaling launch."""
 
     @staticmethod
-    def forward(ctx, rx, table, target, keep_prob, seed, row_offset, keep_mask, prec, inv_count):
+    def forward(ctx, rx, table, target, keep_prob, seed, row_offset, keep_mask, prec, inv_count, unit_upstream):
         want_dx = rx.requires_grad
-        nll, _lse, dx = catalog_ce_raw(rx.detach(), table, target, keep_prob, seed, row_offset, keep_mask, prec, want_dx)
+        nll, _lse, dx = catalog_ce_raw(rx.detach(), table, target, keep_prob, seed, row_offset, keep_mask, prec, want_dx,
+                                       dx_scale=float(inv_count) if unit_upstream else 1.0)
         out = torch.empty((), dtype=F32, device=rx.device)
         check(lib().pcvae_sum(ptr(nll, F32), nll.numel(), float(inv_count), ptr(out, F32), stream()), "sum")
         ctx.inv_count = float(inv_count)
+        ctx.unit = bool(unit_upstream)
         if want_dx:
             ctx.save_for_backward(dx)
         return out
@@ -885,21 +889,24 @@ class _CatalogCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
+        if ctx.unit:
+            return (dx,) + (None,) * 9
         g = g.contiguous()
         out = torch.empty_like(dx)
         check(lib().pcvae_scale_rows(ptr(dx, F32), _ld(dx), ptr(out, F32), _ld(out), dx.shape[0], dx.shape[1],
                                      ptr(g, F32), ctx.inv_count, stream()), "scale_rows")
-        return (out,) + (None,) * 8
+        return (out,) + (None,) * 9
 
 
-def catalog_ce(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32, inv_count=None):
+def catalog_ce(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32, inv_count=None,
+               unit_upstream=False):
     """CrossEntropyLoss(downsample(rx @ E^T), target) without the [R, N] logits (train_generative.py:59).
 
     ``inv_count`` defaults to 1/R (the 'mean'); data-parallel ranks pass 1/(R_local * world_size).
     """
     R = rx.shape[0]
     return _CatalogCE.apply(rx, _as_table(table), target, keep_prob, seed, row_offset, keep_mask, prec,
-                            (1.0 / R) if inv_count is None else inv_count)
+                            (1.0 / R) if inv_count is None else inv_count, unit_upstream)
 
 
 # exact argmax through bf16 screening pays off once the catalog is large; below this the plain f32 kernel is used
