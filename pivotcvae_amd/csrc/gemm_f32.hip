@@ -166,11 +166,24 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
                 load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, vb);
             }
         }
+        // operands of k-steps s + PRE .. are read from LDS while the MFMAs of step s run: hipcc's own schedule of the plain loop
+        // was read, read, s_waitcnt lgkmcnt(0), mfma, mfma - a fully exposed LDS latency (~100 cycles) per 128 cycles of MFMA
+        constexpr int PRE = 4, NS = BK / 2;
+        float ar[NS], br[NS];
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            const float a = As[(2 * s + h) * LDT + wm * 32 + li];
-            const float b = Bs[(2 * s + h) * LDT + wn * 32 + li];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        for (int s = 0; s < PRE; ++s) {
+            ar[s] = As[(2 * s + h) * LDT + wm * 32 + li];
+            br[s] = Bs[(2 * s + h) * LDT + wn * 32 + li];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + PRE < NS) {
+                ar[s + PRE] = As[(2 * (s + PRE) + h) * LDT + wm * 32 + li];
+                br[s + PRE] = Bs[(2 * (s + PRE) + h) * LDT + wn * 32 + li];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s], br[s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
         }
     }
 
@@ -307,10 +320,26 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
                 load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, p.K, vb);
             }
         }
+        {   // operand reads run ahead of the MFMAs (see gemm_f32_kernel)
+            constexpr int NS = BK / 8, PRE = 4;
+            float ar[NS], br[NS];
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            const int k = wave * (BK / 4) + 2 * s + h;
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * SLD + li], Bs[k * SLD + li], acc, 0, 0, 0);
+            for (int s = 0; s < PRE && s < NS; ++s) {
+                const int k = wave * (BK / 4) + 2 * s + h;
+                ar[s] = As[k * SLD + li];
+                br[s] = Bs[k * SLD + li];
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s + PRE < NS) {
+                    const int k = wave * (BK / 4) + 2 * (s + PRE) + h;
+                    ar[s + PRE] = As[k * SLD + li];
+                    br[s + PRE] = Bs[k * SLD + li];
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s], br[s], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
         }
     }
     // partial tiles -> LDS as [wave][row][col]
@@ -336,7 +365,10 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
 }
 
 // 64 x 64 tiles once they fill the chip, else 32 x 32 tiles with the K chunk split over the waves
-static inline bool use_small_tiles(int64_t M, int64_t N) { return cdiv(M, BM) * cdiv(N, BN) < 256; }
+static inline bool use_small_tiles(int64_t M, int64_t N) {
+    static const int64_t below = [] { const char* e = getenv("PCVAE_GEMM_SMALL_BELOW"); return e ? atoll(e) : 256LL; }();
+    return cdiv(M, BM) * cdiv(N, BN) < below;
+}
 
 }  // namespace
 
