@@ -49,28 +49,6 @@
 #ifndef X3_PROBE
 #define X3_PROBE 0
 #endif
-#ifndef X3_NOP_BEFORE
-#define X3_NOP_BEFORE
-#endif
-#ifndef X3_NOP_AFTER
-#define X3_NOP_AFTER
-#endif
-#ifndef X3_L_AFTER_COND
-#define X3_L_AFTER_COND true     // steps whose A request sits behind an MFMA of the step (the others: in front of MFMA 0)
-#endif
-#ifndef X3_L_ISSUE_AT
-#define X3_L_ISSUE_AT 0     // the A fragment of step I + X3_AD is requested behind this MFMA of step I (-1: in front of MFMA 0)
-#endif
-#ifdef X3_OLD_READS_L
-#define X3_OLD_L 1
-#else
-#define X3_OLD_L 0
-#endif
-#ifdef X3_OLD_READS_G
-#define X3_OLD_G 1
-#else
-#define X3_OLD_G 0
-#endif
 
 template <int D, int CT>
 struct X3Geo {
@@ -99,15 +77,9 @@ struct X3Geo {
         return (j == 0 || j == 2 * CT - 1) ? 0 : 1;
     }
     static constexpr int gfirst(int m) {
-#ifdef X3_UNIFORM_OPS
-        if (m <= 2) return 0;
-        const int v = ((m - 2) * GOPS + (MG - 3)) / (MG - 2);
-        return v > GOPS ? GOPS : v;
-#else
         int n = 0;
         for (int i = 0; i < m && i < MG; ++i) n += gcap(i);
         return n > GOPS ? GOPS : n;
-#endif
     }
     // ---- L: hi steps (2 CT MFMAs), lo steps (CT).  Cheap ops (4-5 cycles): one next to the A-fragment read behind MFMA 0, one in
     // front of the next step's wait behind the last MFMA, two in the gaps between; none in the last two gaps of L (the packed
@@ -124,14 +96,9 @@ struct X3Geo {
         return (j == 0 || j == len - 1) ? 1 : 2;
     }
     static constexpr int lfirst(int m) {
-#ifdef X3_UNIFORM_OPS
-        const int v = (m * LOPS + (ML - 3)) / (ML - 2);
-        return v > LOPS ? LOPS : v;
-#else
         int n = 0;
         for (int i = 0; i < m && i < ML; ++i) n += lcap(i);
         return n > LOPS ? LOPS : n;
-#endif
     }
 };
 
@@ -242,17 +209,7 @@ __device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf
                                           X3Regs<CT>& r) {
     using XG = X3Geo<D, CT>;
     if constexpr (I < XG::NI) {
-#if X3_OLD_L
-        if constexpr (I + X3_AD < XG::NI) pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);
-        lgkm_wait<(I + X3_AD < XG::NI ? X3_AD : XG::NI - 1 - I)>();
-#else
         if constexpr (COLD || !(X3_PROBE & (2 | 16))) lgkm_wait<(I + X3_AD - 1 < XG::NI ? X3_AD - 1 : XG::NI - 1 - I)>();
-#if X3_L_ISSUE_AT < 0
-        if constexpr (I + X3_AD < XG::NI) pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);
-#else
-        if constexpr (I + X3_AD < XG::NI && !(X3_L_AFTER_COND)) pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);
-#endif
-#endif
         constexpr int s = I >> 1, rt = I & 1;
         constexpr int M0 = x3_lpos<D, CT>(I);
 #define PCVAE_X3_L(POS, INIT, XB)                                                                          \
@@ -260,11 +217,8 @@ __device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf
             constexpr int cti_ = (POS) % CT;                                                               \
             if constexpr (INIT) mfma_v0<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);              \
             else mfma_v<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);                              \
-            if constexpr (!X3_OLD_L && (POS) == X3_L_ISSUE_AT && I + X3_AD < XG::NI && (X3_L_AFTER_COND)) { \
-                X3_NOP_BEFORE                                                                              \
+            if constexpr ((POS) == 0 && I + X3_AD < XG::NI && (COLD || !(X3_PROBE & 2)))                   \
                 pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);                            \
-                X3_NOP_AFTER                                                                               \
-            }                                                                                              \
             if constexpr ((POS) == 1 && I > 1) x3_keep(af[I - 2]);                                         \
             if constexpr ((POS) == 1 && I == 2 && HAS_PREV) {   /* the tail operands of the gradient chain in front of this L */ \
                 x3_keep_pb<CT>(r.pbh, r.pbl);                                                              \
@@ -332,13 +286,7 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
             // younger than tile DT's reads: tiles DT + 1 .. DT + X3_TD - 1, and the next slot's first A fragments once they are out
             constexpr int young = (DT + X3_TD - 1 < NDTL ? X3_TD - 1 : NDTL - 1 - DT);
             constexpr int extra = (DT >= SEAM_AT && DT - SEAM_AT < X3_TD) ? X3_AD : 0;   // issued behind a read that is still awaited
-#if X3_OLD_G
-            constexpr int extra_o = (DT >= SEAM_AT && DT < SEAM_AT + X3_TD) ? X3_AD : 0;
-            if constexpr (DT + X3_TD < NDTL) tr_issue<XG::DL, OFFG, DT + X3_TD>(lbase_g, t0, tl[DT + X3_TD], th[DT + X3_TD]);
-            lgkm_wait<2 * ((DT + X3_TD < NDTL ? DT + X3_TD : NDTL - 1) - DT) + extra_o>();
-#else
             if constexpr (COLD || !(X3_PROBE & (2 | 4 | 16))) lgkm_wait<2 * young + extra>();
-#endif
         }
         const s16x8 a16 = __builtin_shufflevector(tl[DT], th[DT], 0, 1, 2, 3, 4, 5, 6, 7);
         const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
@@ -347,7 +295,7 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
 #define PCVAE_X3_G(POS, PB)                                                                                \
         {                                                                                                  \
             if constexpr (HAS_G) mfma_a<COLD>(U[UD][(POS) % CT], a, PB[(POS) % CT]);                       \
-            if constexpr (!X3_OLD_G && HAS_G && (POS) == 0 && DT + X3_TD < NDTL && (COLD || !(X3_PROBE & 4)))     \
+            if constexpr (HAS_G && (POS) == 0 && DT + X3_TD < NDTL && (COLD || !(X3_PROBE & 4)))           \
                 tr_issue<XG::DL, OFFG, DT + X3_TD>(lbase_g, t0, tl[DT + X3_TD], th[DT + X3_TD]);           \
             if constexpr (HAS_G && (POS) == 1 && DT > 1) x3_keep(tl[DT - 2], th[DT - 2]);                  \
             if constexpr (HAS_G && (POS) == 1 && DT == 1) {   /* the last fragments of the logits chain in front of this G */ \
