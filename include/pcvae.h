@@ -202,6 +202,12 @@ int pcvae_latent_bwd_packed(const float* dz, int64_t lddz, const float* eps, con
                             int64_t ld, const float* dkld_dev, float dkld_host, float* g_enc, float* g_prior, int64_t ldg,
                             int64_t B, int Z, pcvae_stream_t stream);
 
+/* downsample on a dense logits tensor                    train_generative.py:36-42
+ *     out[r, n] = pred[r, n] if n == slate[r] or Bernoulli(keep_prob) else 0 (masked-out logits become 0, not -inf);
+ *     the mask stream is the dense masked pcvae_catalog_ce's.  For callers that hold dense logits (small catalogs).   */
+int pcvae_downsample_dense(const float* pred, int64_t ldp, const int64_t* slate, int64_t R, int64_t N, float keep_prob,
+                           uint64_t seed, uint64_t row_offset, float* out, int64_t ldo, pcvae_stream_t stream);
+
 /* K5, sparse form for n_neg << N                        train_generative.py:36-44,59 (downsample(pred, slates, 1000) + CE)
  *     Same result as pcvae_catalog_ce with keep_prob < 1, but only the KEPT items of a row are touched: masked-out logits are
  *     the constant 0 (exp(0) = 1 each in the denominator, no gradient), so the kernel enumerates the kept set of a row

@@ -46,6 +46,7 @@ SIGNATURES = {
     "pcvae_assemble_inputs": [_P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _P, _L, _P, _L, _P, _L, _P, _L, _P],
     "pcvae_latent_fwd_packed": [_P, _P, _L, _P, _U64, _U64, _P, _L, _P, _P, _L, _I, _P],
     "pcvae_latent_bwd_packed": [_P, _L, _P, _P, _P, _L, _P, _F, _P, _P, _L, _L, _I, _P],
+    "pcvae_downsample_dense": [_P, _L, _P, _L, _L, _F, _U64, _U64, _P, _L, _P],
     "pcvae_sum": [_P, _L, _F, _P, _P],
     "pcvae_catalog_ws_bytes": [_L, _L, _I, _I],
     "pcvae_catalog_ce_variant": [_L, _L, _I, _I],

@@ -723,6 +723,45 @@ extern "C" int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* 
 }
 
 // =============================================================================================
+// downsample on a DENSE logits tensor (train_generative.py:36-42) for callers that hold one (small catalogs; the fused losses
+// never form it): out[r, n] = pred[r, n] if n == slate[r] or Bernoulli(keep_prob) else 0.  The Bernoulli stream is the one the
+// dense masked CE kernels draw (Philox4x32-10 keyed by (seed, row_offset + r, n >> 2, "MASK"), word n & 3 < keep_prob * 2^32),
+// restated on the host by tests/philox_ref.keep_mask.
+// =============================================================================================
+__global__ void downsample_dense_kernel(const float* __restrict__ pred, int64_t ldp, const int64_t* __restrict__ slate, int64_t R,
+                                        int64_t N, uint32_t keep_thresh, uint64_t seed, uint64_t row_offset,
+                                        float* __restrict__ out, int64_t ldo) {
+    const int64_t nq = (N + 3) / 4;
+    const int64_t total = R * nq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / nq, q = i - r * nq;
+        const uint64_t grow = row_offset + (uint64_t)r, nb = (uint64_t)q * 4;
+        const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(nb >> 2),
+                                         (uint32_t)(nb >> 34) ^ 0x4D41534Bu /*"MASK"*/, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const uint32_t w[4] = {ph.x, ph.y, ph.z, ph.w};
+        const int64_t t = slate[r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = (int64_t)nb + j;
+            if (n < N) out[r * ldo + n] = (w[j] < keep_thresh || n == t) ? pred[r * ldp + n] : 0.f;
+        }
+    }
+}
+
+extern "C" int pcvae_downsample_dense(const float* pred, int64_t ldp, const int64_t* slate, int64_t R, int64_t N, float keep_prob,
+                                      uint64_t seed, uint64_t row_offset, float* out, int64_t ldo, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(pred && slate && out && R >= 0 && N > 0 && ldp >= N && ldo >= N, "downsample_dense: bad arguments");
+    PCVAE_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, "downsample_dense: keep_prob must be in (0, 1] (n_neg > N raises in the reference too)");
+    if (R == 0) return PCVAE_OK;
+    const double th = (double)keep_prob * 4294967296.0;
+    const uint32_t thresh = th >= 4294967295.0 ? 0xffffffffu : (uint32_t)th;
+    const int64_t blocks = std::min<int64_t>(cdiv(R * ((N + 3) / 4), 256), 4096);
+    hipLaunchKernelGGL(downsample_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), pred, ldp, slate, R, N, thresh,
+                       seed, row_offset, out, ldo);
+    return check_launch("downsample_dense");
+}
+
+// =============================================================================================
 // a13: the simulators' click model as in-loop evaluator - URM / URM_P / URM_P_MR.core_forward
 // (env/response_model.py:129-150, 286-295, 315-323), forward only, one wave per slate:
 //   d_s   = E[slate_s] / max(||E[slate_s]||, 1e-12)                      per-item L2 normalisation

@@ -1033,6 +1033,37 @@ def urm_forward(E, item_bias, U, user_bias, slates, users, pos_bias=None, pos_de
     return out
 
 
+class _DownsampleDense(torch.autograd.Function):
+    """pred * mask with mask = onehot(target) OR Bernoulli(keep_prob) (train_generative.py:36-42), the mask drawn in the kernel."""
+
+    @staticmethod
+    def forward(ctx, pred, slate, keep_prob, seed, row_offset):
+        require_device(pred, slate)
+        pred = _c2d(pred)
+        R, N = pred.shape
+        slate = slate.reshape(-1).to(torch.int64).contiguous()
+        out = torch.empty(R, N, dtype=F32, device=pred.device)
+        check(lib().pcvae_downsample_dense(ptr(pred, F32), _ld(pred), ptr(slate), R, N, float(keep_prob), int(seed), int(row_offset),
+                                           ptr(out, F32), N, stream()), "downsample_dense")
+        ctx.save_for_backward(slate)
+        ctx.args = (float(keep_prob), int(seed), int(row_offset))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):   # the same mask applied to the upstream gradient
+        (slate,) = ctx.saved_tensors
+        g = _c2d(g)
+        R, N = g.shape
+        out = torch.empty(R, N, dtype=F32, device=g.device)
+        check(lib().pcvae_downsample_dense(ptr(g, F32), _ld(g), ptr(slate), R, N, ctx.args[0], ctx.args[1], ctx.args[2], ptr(out, F32), N,
+                                           stream()), "downsample_dense")
+        return out, None, None, None, None
+
+
+def downsample_dense(pred, slate, keep_prob, seed=0, row_offset=0):
+    return _DownsampleDense.apply(pred, slate, keep_prob, seed, row_offset)
+
+
 # ------------------------------------------------------- in-loop evaluation (response model)
 def normalize_rows_(x):
     """x[r, :] /= max(||x[r, :]||, 1e-12) in place (F.normalize(p=2, dim=1))."""

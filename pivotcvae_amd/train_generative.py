@@ -15,17 +15,14 @@ from . import ops
 from .optim import FlatAdam
 
 
-def downsample(pred, slate, n_neg=1000.0):
-    """Reference semantics on a DENSE logits tensor (small catalogs only): mask = onehot(target) OR
-    Bernoulli(n_neg / N); masked-out logits become 0.  Kept for callers that hold a dense ``pred``;
-    the fused path applies the same rule inside the catalog kernel."""
+def downsample(pred, slate, n_neg=1000.0, seed=0, row_offset=0):
+    """Reference semantics on a DENSE logits tensor (small catalogs only; train_generative.py:36-42): mask = onehot(target) OR
+    Bernoulli(n_neg / N); masked-out logits become 0.  Kept for callers that hold a dense ``pred`` (the reference's own
+    get_gen_loss recipe on forward()); one kernel, the mask drawn in it (the dense masked CE kernels' Philox stream) - the fused
+    losses apply the same rule without ever forming ``pred``."""
     if n_neg > pred.shape[1]:
         raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {pred.shape[1]}")
-    mask = torch.zeros_like(pred)
-    mask.scatter_(1, slate.reshape(-1, 1), 1)
-    mask = mask + torch.bernoulli(torch.ones_like(pred) * (n_neg / pred.shape[1]))
-    mask[mask == 2] = 1
-    return pred * mask
+    return ops.downsample_dense(pred, slate.reshape(-1), float(n_neg) / pred.shape[1], seed, row_offset)
 
 
 def _batch_to_device(batch_data, device):
