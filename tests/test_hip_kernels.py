@@ -628,3 +628,80 @@ def test_dense_ce(ops, R, C):
     (got * 0.7).backward()
     np.testing.assert_allclose(got.item(), want.item(), rtol=2e-6)
     torch.testing.assert_close(pd.grad.cpu(), pr.grad, rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------ fused training-path kernels
+@pytest.mark.parametrize("no_user", [False, True])
+@pytest.mark.parametrize("B,S,D,Z,ncols", [(37, 5, 16, 4, 5), (130, 10, 128, 16, 10), (9, 20, 256, 16, 5)])
+def test_assemble_inputs(ops, B, S, D, Z, ncols, no_user):
+    """condition + gathers + the reference's concatenations in one launch == the pieces put together with torch on the host
+    (models/pivotcvae.py:250-258, :166, :201, :213, :231, :194); ncols < S: the in-loop evaluation's 5-column context."""
+    N, NU, C = 500, 40, S + 1
+    E, U = rnd(N, D, seed=1), rnd(NU, D, seed=2)
+    g = torch.Generator().manual_seed(3)
+    s = torch.randint(0, N, (B, S), generator=g)
+    u = torch.randint(0, NU, (B, 1), generator=g)
+    r = (torch.rand(B, ncols, generator=g) < 0.5).float()
+    enc, pri, scm, rx = ops.assemble_inputs(E.to(DEV), None if no_user else U.to(DEV), s.to(DEV), r.to(DEV), None if no_user else u.to(DEV), Z)
+    cond = orc.condition(r, S)
+    assert cond.shape == (B, C)
+    emb = E[s.reshape(-1)].reshape(B, S * D)
+    parts = [emb, cond] + ([] if no_user else [U[u.reshape(-1)]])
+    assert torch.equal(enc.cpu(), torch.cat(parts, 1))
+    assert torch.equal(pri.cpu(), torch.cat(parts[1:], 1))
+    tail = [cond, E[s[:, 0]]] + ([] if no_user else [U[u.reshape(-1)]])
+    assert torch.equal(scm.cpu()[:, Z:], torch.cat(tail, 1))       # the z window [0, Z) is the latent kernel's
+    assert torch.equal(rx.cpu()[:, :D], E[s[:, 0]])
+
+
+def test_latent_packed_equals_the_unpacked_operators(ops):
+    """reparametrize + KL on packed head outputs [mu | logvar], z written into a column window: same values and gradients as
+    ops.latent on the four separate tensors (which the goldens pin)."""
+    B, Z, W = 70, 8, 29
+    ye, yp = rnd(B, 2 * Z, seed=1, scale=0.7), rnd(B, 2 * Z, seed=2, scale=0.7)
+    eps = rnd(B, Z, seed=3)
+    yed, ypd = ye.to(DEV).requires_grad_(True), yp.to(DEV).requires_grad_(True)
+    buf = torch.full((B, W), -3.0, device=DEV)
+    out, e_used, k = ops.latent_packed(yed, ypd, buf, eps.to(DEV), Z=Z)
+    ts = [t.to(DEV).requires_grad_(True) for t in (ye[:, :Z].contiguous(), ye[:, Z:].contiguous(), yp[:, :Z].contiguous(), yp[:, Z:].contiguous())]
+    z2, e2, k2 = ops.latent(*ts, eps.to(DEV))
+    assert out.data_ptr() == buf.data_ptr() and torch.equal(out[:, :Z], z2) and torch.all(out[:, Z:] == -3.0)
+    assert torch.equal(e_used, e2)
+    np.testing.assert_allclose(k.item(), k2.item(), rtol=1e-6)
+    gz = rnd(B, W, seed=4).to(DEV)
+    torch.autograd.backward([out, k], [gz, torch.tensor(0.37, device=DEV)])
+    torch.autograd.backward([z2, k2], [gz[:, :Z].contiguous(), torch.tensor(0.37, device=DEV)])
+    torch.testing.assert_close(yed.grad, torch.cat([ts[0].grad, ts[1].grad], 1), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(ypd.grad, torch.cat([ts[2].grad, ts[3].grad], 1), rtol=1e-6, atol=1e-7)
+    # Philox path: the same stream as ops.reparam / ops.latent
+    o3, e3, _ = ops.latent_packed(ye.to(DEV), yp.to(DEV), torch.zeros(B, W, device=DEV), None, seed=5, offset=32, Z=Z)
+    z4, e4 = ops.reparam(ts[0].detach(), ts[1].detach(), None, seed=5, offset=32)
+    assert torch.equal(e3, e4) and torch.equal(o3[:, :Z], z4)
+    # large B: the KL partials of up to 64 blocks are combined in block order (deterministic)
+    Bb = 20000
+    ye, yp = rnd(Bb, 2 * Z, seed=6, scale=0.5).to(DEV), rnd(Bb, 2 * Z, seed=7, scale=0.5).to(DEV)
+    ks = [ops.latent_packed(ye, yp, torch.zeros(Bb, Z, device=DEV), torch.zeros(Bb, Z, device=DEV), Z=Z)[2].item() for _ in range(3)]
+    assert ks[0] == ks[1] == ks[2]
+    want = orc.kld(ye[:, :Z].cpu(), ye[:, Z:].cpu(), yp[:, :Z].cpu(), yp[:, Z:].cpu()).item()
+    np.testing.assert_allclose(ks[0], want, rtol=1e-5)
+
+
+def test_downsample_dense_is_the_documented_stream(ops):
+    """train_generative.downsample on dense logits (train_generative.py:36-42) as one kernel: exactly pred * (onehot(target) OR mask)
+    with the mask the host restatement of the dense masked CE's Philox stream rebuilds; backward applies the same mask."""
+    from pivotcvae_amd.train_generative import downsample
+    R, N = 23, 1001
+    pred = rnd(R, N, seed=1, scale=3.0)
+    slate = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(2))
+    pd = pred.to(DEV).requires_grad_(True)
+    out = downsample(pd, slate.to(DEV), n_neg=250, seed=77, row_offset=5)
+    keep = torch.from_numpy(philox_ref.keep_mask(R, N, 250.0 / N, 77, 5)).bool()
+    keep[torch.arange(R), slate] = True
+    assert torch.equal(out.cpu(), torch.where(keep, pred, torch.zeros_like(pred)))
+    assert 0.15 < keep.float().mean() < 0.35
+    (out * 2.0).sum().backward()
+    assert torch.equal(pd.grad.cpu(), keep.float() * 2.0)
+    full = downsample(pred.to(DEV), slate.to(DEV), n_neg=N)     # n_neg == N: identity
+    assert torch.equal(full.cpu(), pred)
+    with pytest.raises(RuntimeError):
+        downsample(pred.to(DEV), slate.to(DEV), n_neg=N + 1)
