@@ -2043,7 +2043,7 @@ int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* E
         set_error("catalog_ce(bf16x3): D=%d (the kernel exists for D = 128)", D);
         return PCVAE_EINVAL;
     }
-    constexpr int CT = 2;
+    constexpr int CT = X3_CT;
     using XG = X3Geo<128, CT>;
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16X3);
     CatParamsB p{};

@@ -5,6 +5,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef X3_CT
+#define X3_CT 2   // column tiles of 16 rows per wave of the bf16x3 kernel: 32 rows per wave, 128 per workgroup (3 and 4 spill: DESIGN 3.1b)
+#endif
+
 namespace pcvae {
 
 struct CatalogPlan {
@@ -31,7 +35,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // Ranges stay long enough that the per-range prologue (rx fragments) and epilogue (partials) are amortised.
     const int64_t slots = 256 * (f32 ? 2 : 1);
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
-    const int64_t nblk = (!f32 && (D == 256 || x3)) ? cdiv(R, 128) : p.nrb;
+    const int64_t nblk = x3 ? cdiv(R, 64 * X3_CT) : ((!f32 && D == 256) ? cdiv(R, 128) : p.nrb);
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
     int64_t best_cost = -1;
     for (int64_t ns = 1; ns <= cap; ++ns) {

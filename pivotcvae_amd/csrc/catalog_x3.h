@@ -168,6 +168,14 @@ __device__ __forceinline__ void x3_all_lops(X3Regs<CT>& r) {
     }
 }
 
+// acc (VGPR) += A . B with the B operand in AGPRs: the lo fragments of rx live there (MFMA operands may be ArchVGPRs or AccVGPRs on
+// gfx90a and later), which is what makes 64 rows per wave (CT = 4) fit the 256 architectural VGPRs an asm operand can live in
+template <bool COLD>
+__device__ __forceinline__ void mfma_v_ab(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+v"(acc) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+
 template <int CT>
 __device__ __forceinline__ void x3_pack(const unsigned (&w)[CT][4], bf16x8 (&pb)[CT]) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -212,11 +220,7 @@ __device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf
         if constexpr (COLD || !(X3_PROBE & (2 | 16))) lgkm_wait<(I + X3_AD - 1 < XG::NI ? X3_AD - 1 : XG::NI - 1 - I)>();
         constexpr int s = I >> 1, rt = I & 1;
         constexpr int M0 = x3_lpos<D, CT>(I);
-#define PCVAE_X3_L(POS, INIT, XB)                                                                          \
-        {                                                                                                  \
-            constexpr int cti_ = (POS) % CT;                                                               \
-            if constexpr (INIT) mfma_v0<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);              \
-            else mfma_v<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);                              \
+#define PCVAE_X3_TAIL(POS)                                                                                 \
             if constexpr ((POS) == 0 && I + X3_AD < XG::NI && (COLD || !(X3_PROBE & 2)))                   \
                 pipe_a_issue<XG::DL, OFF, I + X3_AD>(lbase, a0, af[I + X3_AD]);                            \
             if constexpr ((POS) == 1 && I > 1) x3_keep(af[I - 2]);                                         \
@@ -226,17 +230,37 @@ __device__ __forceinline__ void x3_logits(const unsigned lbase, const int a0, bf
                 x3_keep(r.tl[XG::NDTL - 2], r.th[XG::NDTL - 2]);                                           \
                 x3_keep(r.tl[XG::NDTL - 3], r.th[XG::NDTL - 3]);                                           \
             }                                                                                              \
-            if constexpr (HAS_PREV && !COLD && !(X3_PROBE & 1)) x3_lops<D, CT, M0 + (POS)>(r);             \
+            if constexpr (HAS_PREV && !COLD && !(X3_PROBE & 1)) x3_lops<D, CT, M0 + (POS)>(r);
+#define PCVAE_X3_L(POS, INIT, XB)                                                                          \
+        {                                                                                                  \
+            constexpr int cti_ = (POS) % CT;                                                               \
+            if constexpr (INIT) mfma_v0<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);              \
+            else mfma_v<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);                              \
+            PCVAE_X3_TAIL(POS)                                                                             \
+        }
+#define PCVAE_X3_LA(POS, XB)   /* B operand (the lo fragments of rx) lives in AGPRs */                     \
+        {                                                                                                  \
+            constexpr int cti_ = (POS) % CT;                                                               \
+            mfma_v_ab<COLD>(r.acc[rt][cti_], af[I], XB[cti_][s % XG::KSH]);                                \
+            PCVAE_X3_TAIL(POS)                                                                             \
         }
         if constexpr (s < XG::KSH) {
             PCVAE_X3_L(0, s == 0, xh)
             if constexpr (CT > 1) PCVAE_X3_L(1, s == 0, xh)
-            PCVAE_X3_L(CT, false, xl)
-            if constexpr (CT > 1) PCVAE_X3_L(CT + 1, false, xl)
+            if constexpr (CT > 2) PCVAE_X3_L(2, s == 0, xh)
+            if constexpr (CT > 3) PCVAE_X3_L(3, s == 0, xh)
+            PCVAE_X3_LA(CT, xl)
+            if constexpr (CT > 1) PCVAE_X3_LA(CT + 1, xl)
+            if constexpr (CT > 2) PCVAE_X3_LA(CT + 2, xl)
+            if constexpr (CT > 3) PCVAE_X3_LA(CT + 3, xl)
         } else {
             PCVAE_X3_L(0, false, xh)
             if constexpr (CT > 1) PCVAE_X3_L(1, false, xh)
+            if constexpr (CT > 2) PCVAE_X3_L(2, false, xh)
+            if constexpr (CT > 3) PCVAE_X3_L(3, false, xh)
         }
+#undef PCVAE_X3_LA
+#undef PCVAE_X3_TAIL
 #undef PCVAE_X3_L
         x3_logits<D, CT, OFF, I + 1, HAS_PREV, COLD>(lbase, a0, af, xh, xl, r);
     }
@@ -306,11 +330,17 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
         if constexpr (DT < XG::NDT) {
             PCVAE_X3_G(0, pbh)
             if constexpr (CT > 1) PCVAE_X3_G(1, pbh)
+            if constexpr (CT > 2) PCVAE_X3_G(2, pbh)
+            if constexpr (CT > 3) PCVAE_X3_G(3, pbh)
             PCVAE_X3_G(CT, pbl)
             if constexpr (CT > 1) PCVAE_X3_G(CT + 1, pbl)
+            if constexpr (CT > 2) PCVAE_X3_G(CT + 2, pbl)
+            if constexpr (CT > 3) PCVAE_X3_G(CT + 3, pbl)
         } else {
             PCVAE_X3_G(0, pbh)
             if constexpr (CT > 1) PCVAE_X3_G(1, pbh)
+            if constexpr (CT > 2) PCVAE_X3_G(2, pbh)
+            if constexpr (CT > 3) PCVAE_X3_G(3, pbh)
         }
 #undef PCVAE_X3_G
         x3_grad<D, CT, OFFG, OFFL_NEXT, DT + 1, HAS_G, VM, COLD>(lbase_g, t0, tl, th, pbh, pbl, r, U, sm, wave_u, lane_off, a0, af);
@@ -341,8 +371,12 @@ __device__ __forceinline__ void x3_slot(const unsigned lbase_l, const unsigned l
 #define PCVAE_X3_ONES(POS, PB) mfma_a<COLD>(lsum[(POS) % CT], L.ones, PB[(POS) % CT]);
         PCVAE_X3_ONES(0, r.pbh)
         if constexpr (CT > 1) PCVAE_X3_ONES(1, r.pbh)
+        if constexpr (CT > 2) PCVAE_X3_ONES(2, r.pbh)
+        if constexpr (CT > 3) PCVAE_X3_ONES(3, r.pbh)
         PCVAE_X3_ONES(CT, r.pbl)
         if constexpr (CT > 1) PCVAE_X3_ONES(CT + 1, r.pbl)
+        if constexpr (CT > 2) PCVAE_X3_ONES(CT + 2, r.pbl)
+        if constexpr (CT > 3) PCVAE_X3_ONES(CT + 3, r.pbl)
 #undef PCVAE_X3_ONES
     }
     if constexpr (COLD) {               // exponentials of this subtile, nothing overlapped
@@ -403,7 +437,7 @@ __device__ __forceinline__ void x3_cold_logits(const unsigned lbase, const int a
         for (int ct = 0; ct < CT; ++ct) {
             if constexpr (s == 0) mfma_v0<true>(acc[rt][ct], af[I], xh[ct][0]);
             else mfma_v<true>(acc[rt][ct], af[I], xh[ct][s % XG::KSH]);
-            if constexpr (s < XG::KSH) mfma_v<true>(acc[rt][ct], af[I], xl[ct][s]);
+            if constexpr (s < XG::KSH) mfma_v_ab<true>(acc[rt][ct], af[I], xl[ct][s]);
         }
         x3_cold_logits<D, CT, I + 1>(lbase, a0, af, xh, xl, acc);
     }
@@ -502,6 +536,8 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
     for (int ct = 0; ct < CT; ++ct) {
         const int64_t r = rw + 16 * ct + c;
         x3_load_x<D>(p.rx, r < p.R ? r : p.R - 1, g, xh[ct], xl[ct]);
+#pragma unroll
+        for (int s = 0; s < XG::KSH; ++s) asm volatile("" : "+a"(xl[ct][s]));   // the lo fragments live in AGPRs (mfma_v_ab)
     }
     f32x4 U[XG::NDT][CT];
     f32x4 lsum[CT];
