@@ -45,7 +45,7 @@
 #endif
 // Timing probes (tools/build_variant.sh ... -DX3_PROBE=<mask>; results are garbage, only the time means something): drop from the
 // steady-state slots 1: the numerator VALU ops, 2: the A-fragment reads, 4: the transposed reads, 8: the seam (wait + barrier +
-// refill), 16: the LDS waits
+// refill), 16: the LDS waits, 32: only the seam's barrier, 64: only the seam's refill
 #ifndef X3_PROBE
 #define X3_PROBE 0
 #endif
@@ -300,8 +300,9 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
                 if (sm.n_stage >= 0) fast_stage<XG::DL, 4>(sm.E, sm.n_stage, sm.stage_buf, wave_u, lane_off);
                 pipe_fence();
             } else if constexpr (!(X3_PROBE & 8)) {
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
-                pipe_stage<XG::DL>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
+                if constexpr (X3_PROBE & 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");   // probe: no barrier
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+                if constexpr (!(X3_PROBE & 64)) pipe_stage<XG::DL>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);   // probe: no refill
             }
             if constexpr (COLD || !(X3_PROBE & 2))
                 pipe_a_prologue<XG::DL, OFFL_NEXT, X3_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
