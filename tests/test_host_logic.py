@@ -216,3 +216,43 @@ def test_sparse_keep_stream_is_bernoulli():
     assert abs(both - R * (N - 1) * p * p) < 5 * (R * (N - 1) * p * p) ** 0.5
     # row_offset is the global row index: a shard equals the corresponding rows of the whole batch
     assert np.array_equal(philox_ref.sparse_keep_mask(100, N, p, seed=5, row_offset=211), k[200:])
+
+
+def test_flat_adam_places_the_heads_back_to_back():
+    """FlatAdam honours model.flat_param_groups(): the two heads of the encoder / of the prior sit back to back in the flat buffer
+    (weights with weights, biases with biases, and the same for the gradient views), so that [W_mu ; W_logvar] is ONE strided
+    operand; names, shapes, values and state_dict keys are untouched; parameters without a group keep module order."""
+    from pivotcvae_amd.optim import FlatAdam
+    g = load("pivotcvae_gt_pi_user")
+    m, st = g.meta, g.meta["structs"]
+    model = pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"](torch.nn.Embedding.from_pretrained(g.t("raw_doc")),
+                                                  torch.nn.Embedding.from_pretrained(g.t("raw_user")), m["S"], m["D"], m["Z"], m["S"] + 1,
+                                                  st["enc"], st["psm"], st["scm"], st["prior"], False, "cpu")
+    model.load_state_dict(g.sd)
+    opt = FlatAdam(model, 1e-3)
+
+    def back_to_back(a, b):
+        return b.data_ptr() == a.data_ptr() + a.numel() * 4
+
+    for a, b in ((model.encmu, model.enclogvar), (model.priorMu, model.priorLogvar)):
+        assert back_to_back(a.weight.data, b.weight.data) and back_to_back(a.bias.data, b.bias.data)
+        assert back_to_back(a.weight.grad, b.weight.grad) and back_to_back(a.bias.grad, b.bias.grad)
+        cat = torch.as_strided(a.weight.data, (2 * a.weight.shape[0], a.weight.shape[1]), a.weight.stride())
+        assert torch.equal(cat, torch.cat([a.weight.data, b.weight.data]))
+    assert sum(p.numel() for p in opt.params) == opt.flat.numel() and len({id(p) for p in opt.params}) == len(opt.params)
+    assert [id(p) for p in opt.params][:2] == [id(model.enc_1.weight), id(model.enc_1.bias)]
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, g.sd[k]), k
+    # the PSM never receives a gradient: with weight decay on, its range is stepped with decay 0 (torch.optim.Adam skips grad None)
+    m2 = _fresh_model(g)
+    opt2 = FlatAdam(m2, 1e-3, weight_decay=0.1)
+    assert {wd for _, _, wd in opt2.segments} == {0.0, 0.1}
+    assert sum(n for _, n, wd in opt2.segments if wd == 0.0) == sum(p.numel() for p in m2.params_without_grad())
+    assert sum(n for _, n, _ in opt2.segments) == opt2.flat.numel()
+
+
+def _fresh_model(g):
+    m, st = g.meta, g.meta["structs"]
+    return pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"](torch.nn.Embedding.from_pretrained(g.t("raw_doc")),
+                                                 torch.nn.Embedding.from_pretrained(g.t("raw_user")), m["S"], m["D"], m["Z"], m["S"] + 1,
+                                                 st["enc"], st["psm"], st["scm"], st["prior"], False, "cpu")
