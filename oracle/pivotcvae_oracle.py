@@ -23,6 +23,8 @@ Reference citations (relative to /root/reference):
   gen_loss              train_generative.py:44-65
   adam_step             train_generative.py:103,124-134 (torch.optim.Adam defaults, no decay)
   response_mlp          env/response_model.py:76-87
+  urm_forward           env/response_model.py:129-154, 286-295, 315-323   (URM / URM_P / URM_P_MR as evaluators; golden G10)
+  candidate_targets     data_loader.py:46-58          (first-hit / overwrite rule on a recorded draw; golden G11)
 """
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional

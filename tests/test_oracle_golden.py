@@ -1,4 +1,4 @@
-"""Pin the CPU oracle against goldens minted from the real reference.
+"""Pin the CPU oracle against goldens minted from the real reference (G1-G7; G8-G11 added by the build).
 
 The oracle uses the same torch CPU ops in (nearly) the same order as the reference, so the
 agreement is expected at the 1e-6 level; tolerances are stated per check.
