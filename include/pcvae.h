@@ -105,6 +105,32 @@ int pcvae_linear_bwd_input_acc(const float* dY, int64_t lddy, const float* W, in
                                float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K, pcvae_stream_t stream);
 int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int64_t lddw,
                             float* db, int64_t M, int64_t N, int64_t K, pcvae_stream_t stream);
+/* Several INDEPENDENT layer GEMMs as ONE launch (no problem may read another's output; outputs must not overlap): a layer's
+ * weight- and input-gradient, or the same layer of two stacks that do not feed each other (encoder and prior:
+ * models/pivotcvae.py:159-174 and 229-240 share only their inputs).  Field meaning per kind = the arguments of the single-layer
+ * entry points above:
+ *     kind               a, lda     b, ldb    c, ldc     aux, ldaux             aux_out   M, N, K
+ *     PCVAE_GEMM_FWD     X, ldx     W, ldw    Y, ldy     bias (or NULL), -      -         as pcvae_linear_fwd (+ act)
+ *     PCVAE_GEMM_DX      dY, lddy   W, ldw    dX, lddx   Xact (or NULL), ldxa   -         as pcvae_linear_bwd_input
+ *     PCVAE_GEMM_DX_ACC  (the same; dX = (dX + dY.W) * act'(Xact), as pcvae_linear_bwd_input_acc)
+ *     PCVAE_GEMM_DW      dY, lddy   X, ldx    dW, lddw   -                      db / NULL as pcvae_linear_bwd_weight
+ * 1 <= n <= 6.  Problems with M == 0 are skipped. */
+enum { PCVAE_GEMM_FWD = 0, PCVAE_GEMM_DX = 1, PCVAE_GEMM_DX_ACC = 2, PCVAE_GEMM_DW = 3 };
+typedef struct pcvae_gemm_desc {
+    int32_t kind;
+    int32_t act;
+    const float* a;
+    int64_t lda;
+    const float* b;
+    int64_t ldb;
+    float* c;
+    int64_t ldc;
+    const float* aux;
+    int64_t ldaux;
+    float* aux_out;
+    int64_t M, N, K;
+} pcvae_gemm_desc;
+int pcvae_linear_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stream);
 /* in place: g *= (y > 0 ? 1 : 0.01)  - LeakyReLU backward keyed on the activated output */
 int pcvae_leaky_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t rows, int cols,
                     pcvae_stream_t stream);

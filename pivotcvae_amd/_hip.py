@@ -17,8 +17,18 @@ ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_SCREENED = 0, 1, 2, 3
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
+GEMM_FWD, GEMM_DX, GEMM_DX_ACC, GEMM_DW = 0, 1, 2, 3
+GEMM_GROUP_MAX = 6
+
 _c = ctypes
 _P, _I, _L, _U64, _F, _SZ = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_uint64, _c.c_float, _c.c_size_t
+
+
+class GemmDesc(_c.Structure):
+    """pcvae_gemm_desc of include/pcvae.h (one problem of pcvae_linear_group)."""
+    _fields_ = [("kind", _c.c_int32), ("act", _c.c_int32), ("a", _P), ("lda", _L), ("b", _P), ("ldb", _L), ("c", _P), ("ldc", _L),
+                ("aux", _P), ("ldaux", _L), ("aux_out", _P), ("M", _L), ("N", _L), ("K", _L)]
+
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/pcvae.h one to one
 SIGNATURES = {
@@ -36,6 +46,7 @@ SIGNATURES = {
     "pcvae_linear_bwd_input": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P],
     "pcvae_linear_bwd_input_acc": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P],
     "pcvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _P],
+    "pcvae_linear_group": [_P, _I, _P],
     "pcvae_leaky_bwd": [_P, _L, _P, _L, _L, _I, _P],
     "pcvae_reparam_fwd": [_P, _P, _P, _U64, _U64, _P, _L, _P, _L, _I, _P],
     "pcvae_philox_normal": [_P, _L, _U64, _U64, _P],

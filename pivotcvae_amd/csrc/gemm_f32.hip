@@ -1,20 +1,34 @@
-// K3: the MLP stacks of the PivotCVAE (encoder / pivot-selection / slate-completion / prior) as
-// LDS-tiled fp32 MFMA GEMMs on gfx950, with the bias + LeakyReLU epilogue fused (forward), the
-// LeakyReLU derivative fused into the input-gradient GEMM, and a split-K weight-gradient GEMM.
+// K3: the MLP stacks of the PivotCVAE (encoder / pivot-selection / slate-completion / prior; reference
+// models/pivotcvae.py:159-240) as LDS-tiled fp32 MFMA GEMMs on gfx950: bias + LeakyReLU fused into the forward epilogue, the
+// LeakyReLU derivative into the input-gradient GEMM, the bias gradient into the (batch-split) weight-gradient GEMM.
 //
-// Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact fmaf chain), because the
-// parity contract is 1e-4 relative against an fp32 reference.  One 256-thread workgroup = 4 waves
-// (2x2), each wave owns one 32x32 accumulator tile of a 64x64 output tile; K is consumed 64 at a
-// time through K-MAJOR LDS tiles (row stride 65 floats) so both MFMA operands are fetched with
-// conflict-free ds_read_b32 (lane i reads element i of a k-row).  The layers are small (a rank holds
-// 1024 slates, hidden width 256: 64 workgroups), so a GEMM is a chain of dependent global-load ->
-// LDS -> MFMA rounds rather than a throughput problem: the deep K step keeps 32 loads per thread in
-// flight per round and cuts the number of rounds (K = 1419: 23 instead of 89).
+// Arithmetic: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact fmaf chain), because the parity contract is 1e-4
+// relative against an fp32 reference.  One 256-thread workgroup = 4 waves (2 x 2), each wave owns one 32 x 32 accumulator
+// tile of a 64 x 64 output tile.  One kernel body covers the three layouts of a Linear layer:
+//    forward      Y[M,N]  = X[M,K]  . W[N,K]^T    A k-contiguous,   B k-contiguous
+//    input grad   dX[M,K] = dY[M,N] . W[N,K]      A k-contiguous,   B row-contiguous
+//    weight grad  dW[N,K] = dY[M,N]^T . X[M,K]    A row-contiguous, B row-contiguous, split over the batch
 //
-// One kernel template covers the three layouts of a Linear layer:
-//    forward      Y[M,N]  = X[M,K]  . W[N,K]^T    A k-contiguous, B k-contiguous
-//    input grad   dX[M,K] = dY[M,N] . W[N,K]      A k-contiguous, B row-contiguous
-//    weight grad  dW[N,K] = dY[M,N]^T . X[M,K]    A row-contiguous, B row-contiguous, split over M
+// How the operands reach LDS (round 2; the round-1 kernel staged tiles through registers: 32 ds_write_b32 per thread between
+// two barriers per K chunk, and with the global loads removed the [8192 x 256 x 1419] layer still took 57 us of an ideal 38):
+//   * tiles stream global -> LDS by LDS-DMA (global_load_lds_dword: no staging registers, no ds_write, no store phase), two
+//     stages of 32 k, ONE barrier per chunk; 32 KB of LDS and ~110 VGPRs leave four workgroups per CU (a deeper ring was
+//     measured: it costs occupancy and is slower on every layer of the model);
+//   * each lane's DMA source address is free, so the LDS image is whatever the MFMA operand fetch wants, with no padding:
+//       k-contiguous operand  -> image [64 rows][32 k] (128-byte rows), 16-byte chunks XOR-swizzled by (row >> 1) & 7; with the
+//                                k order  k(g, h, j) = 8 g + 4 h + j  (g = 0..3, h = lane >> 5, j = 0..3) a lane's four
+//                                consecutive k-steps are ONE conflict-free ds_read_b128 (any bijection of k is a valid order
+//                                as long as both operands use it);
+//       row-contiguous operand -> image [32 k][64 rows] (256-byte lines), the lines of the h = 1 half (k bit 2) rotated by 32
+//                                rows, so the two lane halves of a ds_read_b32 hit disjoint banks;
+//   * ragged K: the last, partial chunk takes per-lane 64-bit addresses, lanes past the end read a zero page; ragged M / N:
+//     row indices are clamped (those rows are computed and never stored).
+//
+// Grouped launches: INDEPENDENT GEMMs (a layer's weight- and input-gradient; the same layer of the encoder and of the prior
+// stack) are one launch - every kernel boundary costs a drain + ramp of 3-4 us, a 25-GEMM step spent ~100 us there, and the
+// prior's small layers (256 workgroups, half a chip) now ride along with the encoder's.  A group's workgroups are dealt to
+// the XCDs so that each XCD holds a CONTIGUOUS run of every problem's tiles (column tiles of one row block share the A rows
+// in one private L2; all tiles of one batch split of a weight gradient share both operands).
 #include "common.h"
 #include <cstdint>
 #include <cstdlib>
@@ -23,12 +37,18 @@
 using namespace pcvae;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 64, LDT = 65, TPT = BM * BK / 256;  // TPT: tile elements per thread
+constexpr int BM = 64, BN = 64;                                       // output tile of the DMA body
+constexpr int DK = 32, NSTAGE = 2, STAGE_BYTES = 2 * 64 * DK * 4, PCS = 8;   // PCS: 256-byte pieces per wave per operand per chunk
+constexpr int SM = 32, SBK = 64, SLD = 33, STPT = SM * SBK / 256;     // small-tile body (below)
+constexpr int SMALL_LDS = (2 * SBK * SLD + 4 * SM * SM) * 4;
+constexpr int MAXG = 6;
 
 enum { EPI_FWD = 0, EPI_DX = 1, EPI_DW = 2 };
+enum { KIND_FWD = 0, KIND_DX = 1, KIND_DW = 2, KIND_FWD_S = 3, KIND_DX_S = 4 };
 
 struct GemmParams {
     const float* A; int64_t lda;   // logical A(m, k)
@@ -39,188 +59,200 @@ struct GemmParams {
     float* bias_grad;              // EPI_DW: [M of this GEMM = layer outputs] or null: += sum over the reduction index
     const float* aux; int64_t ldaux;  // EPI_DX: activated input [M,N] or null
     int act;
-    int64_t k_per_split;           // EPI_DW: reduction range per blockIdx.z
     int accumulate;                // EPI_DX: C = (C + A.B) * act'(aux) - the second of two layers that share an input
+    int64_t k_per_split;           // EPI_DW: reduction range per z
+    int kind, nx, ny, nz, slots;   // tile grid of this problem; slots = cdiv(nx ny nz, 8): workgroups it takes on each XCD
 };
 
-// Load a 64 x 64 (rows x k) tile of a logical operand P(row, k) into 16 registers per thread; a wave reads 64
-// consecutive floats of one row (KC) or of one k (!KC) per load.
-//   KC  (k contiguous in memory):   P(row, k) = P[row * ld + k]
-//   !KC (row contiguous in memory): P(row, k) = P[k * ld + row]
+struct GroupParams {
+    GemmParams g[MAXG];
+    int n;
+};
+
+__device__ float g_zero_page[64];
+
+// source offset (floats, relative to the tile origin P(row0, k0)) of the 4 bytes that land at LDS position (piece pc, lane)
 template <bool KC>
-__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
-                                          int64_t k0, int64_t kend, float (&v)[TPT]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-        int row, k;
-        if (KC) { k = t & 63; row = (t >> 6) + 4 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
-        const int64_t gr = row0 + row, gk = k0 + k;
-        const bool ok = gr < rows && gk < kend;
-        v[i] = ok ? (KC ? P[gr * ld + gk] : P[gk * ld + gr]) : 0.f;
+__device__ __forceinline__ int64_t dma_src(int pc, int lane, int64_t ld, int rows_left, int* k_of_lane) {
+    if (KC) {   // piece = 2 image rows of 32 k
+        const int row = 2 * pc + (lane >> 5), f = lane & 31;
+        const int k = 4 * ((f >> 2) ^ ((row >> 1) & 7)) + (f & 3);
+        *k_of_lane = k;
+        const int rc = row < rows_left ? row : rows_left - 1;
+        return (int64_t)rc * ld + k;
+    } else {    // piece = one k line of 64 rows
+        const int k = pc, row = lane ^ (((k >> 2) & 1) << 5);
+        *k_of_lane = k;
+        const int rc = row < rows_left ? row : rows_left - 1;
+        return (int64_t)k * ld + rc;
     }
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float* S, const float (&v)[TPT]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < TPT; ++i) {
-        int row, k;
-        if (KC) { k = t & 63; row = (t >> 6) + 4 * i; } else { row = t & 63; k = (t >> 6) + 4 * i; }
-        S[k * LDT + row] = v[i];
+// A wave's 8 pieces of one operand: the instruction's immediate offset steps BOTH the LDS and the global address, so a piece's
+// lane offset is its source offset minus that step (plus a 2 KB bias folded into the scalar base to keep it non-negative).
+// Invisible to hipcc's vmcnt bookkeeping: the loop waits by hand.  (m0 on the clobber list: stated, not assumed - hipcc never
+// keeps a value in M0 across statements.)
+__device__ __forceinline__ void dma8(const float* base, const int (&off)[PCS], unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %9\n\ts_nop 0\n\t"
+                 "global_load_lds_dword %0, %8\n\t"
+                 "global_load_lds_dword %1, %8 offset:256\n\t"
+                 "global_load_lds_dword %2, %8 offset:512\n\t"
+                 "global_load_lds_dword %3, %8 offset:768\n\t"
+                 "global_load_lds_dword %4, %8 offset:1024\n\t"
+                 "global_load_lds_dword %5, %8 offset:1280\n\t"
+                 "global_load_lds_dword %6, %8 offset:1536\n\t"
+                 "global_load_lds_dword %7, %8 offset:1792"
+                 ::"v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]),
+                   "s"(base), "s"(lds_dst)
+                 : "memory", "m0");
+}
+
+__device__ __forceinline__ void dma1_addr(const float* src, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(lds_dst) : "memory", "m0");
+}
+
+template <int EPI>
+__device__ __forceinline__ void store_c(const GemmParams& p, int64_t m, int64_t n, float v, float bias) {
+    if (EPI == EPI_FWD) {
+        v += bias;
+        if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
+        else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
+        p.C[m * p.ldc + n] = v;
+    } else if (EPI == EPI_DX) {
+        if (p.accumulate) v += p.C[m * p.ldc + n];
+        if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
+        p.C[m * p.ldc + n] = v;
+    } else {
+        atomicAdd(&p.C[m * p.ldc + n], v);
     }
 }
 
-// Interior tiles (all 64 rows and all 64 k inside the operand): 16-byte global loads, a quarter of the load instructions and of
-// the address arithmetic of the scalar form.  Register j of load i holds the element (row, k) below; row starts need only be
-// 4-byte aligned (K = 1419: ld is odd), which global_load_dwordx4 accepts.
-//   KC:  a wave-load covers 4 rows x 64 k:   row = 16 i + (t >> 4),  k = 4 (t & 15) + j
-//   !KC: a wave-load covers 4 k x 64 rows:   k = 16 i + (t >> 4),    row = 4 (t & 15) + j
-// LDS stores stay scalar into the K-major image (stride 65): bank = k + row (mod 64), distinct across the lanes of a store.
-template <bool KC>
-__device__ __forceinline__ void load_tile_v4(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t k0, float (&v)[TPT]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < TPT / 4; ++i) {
-        const int major = 16 * i + (t >> 4), minor = 4 * (t & 15);
-        const float* src = KC ? P + (row0 + major) * ld + (k0 + minor) : P + (k0 + major) * ld + (row0 + minor);
-        typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
-        const f32x4u q = *reinterpret_cast<const f32x4u*>(src);
-        v[4 * i] = q[0]; v[4 * i + 1] = q[1]; v[4 * i + 2] = q[2]; v[4 * i + 3] = q[3];
-    }
-}
-
-template <bool KC>
-__device__ __forceinline__ void store_tile_v4(float* S, const float (&v)[TPT]) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < TPT / 4; ++i) {
-        const int major = 16 * i + (t >> 4), minor = 4 * (t & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (KC) S[(minor + j) * LDT + major] = v[4 * i + j];
-            else S[major * LDT + minor + j] = v[4 * i + j];
-        }
-    }
-}
-
+// ---- 64 x 64 tile, LDS-DMA --------------------------------------------------------------------------------------------------
 template <bool A_KC, bool B_KC, int EPI>
-__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmParams p) {
-    __shared__ float As[BK * LDT];
-    __shared__ float Bs[BK * LDT];
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx, const int by, const int bz, char* smem) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
 
     int64_t kbeg = 0, kend = p.K;
     if (EPI == EPI_DW) {
-        kbeg = (int64_t)blockIdx.z * p.k_per_split;
+        kbeg = (int64_t)bz * p.k_per_split;
         kend = kbeg + p.k_per_split < p.K ? kbeg + p.k_per_split : p.K;
     }
+    const int nch = (int)((kend - kbeg + DK - 1) / DK);
+    const bool ragged = ((kend - kbeg) % DK) != 0;
 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-
-    // EPI_DW: A(m, k) = dY[k][m]; the column sums of dY (bias gradient) are the k-sums of the A tiles this block
-    // streams anyway.  Only the blocks of the first output column (blockIdx.x == 0) do it, 64 threads each.
-    const bool do_bias = (EPI == EPI_DW) && p.bias_grad != nullptr && blockIdx.x == 0 && threadIdx.x < BM;
+    // EPI_DW: A(m, k) = dY[k][m]; the column sums of dY (bias gradient) are the k-sums of the A images this workgroup streams
+    // anyway.  Only the workgroups of the first output column do it, 64 threads each.
+    const bool do_bias = (EPI == EPI_DW) && p.bias_grad != nullptr && bx == 0 && threadIdx.x < BM;
     float bsum = 0.f;
 
-    // whole rows of both operands inside (workgroup-uniform): every k chunk but a ragged last one takes the 16-byte path
-    const bool rows_in = m0 + BM <= p.M && n0 + BN <= p.N;
-    float va[TPT], vb[TPT];
-    bool vec = rows_in && kbeg + BK <= kend;   // layout of the tile held in va / vb
-    if (vec) {
-        load_tile_v4<A_KC>(p.A, p.lda, m0, kbeg, va);
-        load_tile_v4<B_KC>(p.B, p.ldb, n0, kbeg, vb);
-    } else {
-        load_tile<A_KC>(p.A, p.lda, m0, p.M, kbeg, kend, va);
-        load_tile<B_KC>(p.B, p.ldb, n0, p.N, kbeg, kend, vb);
+    // tile origins, per-chunk steps (floats) and the lane offsets of this wave's 8 pieces per operand (bytes, + 2048 - 256 i)
+    const int rowsA = (int)(p.M - m0 < BM ? p.M - m0 : BM), rowsB = (int)(p.N - n0 < BN ? p.N - n0 : BN);
+    const float* A0 = A_KC ? p.A + m0 * p.lda + kbeg : p.A + kbeg * p.lda + m0;
+    const float* B0 = B_KC ? p.B + n0 * p.ldb + kbeg : p.B + kbeg * p.ldb + n0;
+    const int64_t stepA = A_KC ? DK : DK * p.lda, stepB = B_KC ? DK : DK * p.ldb;
+    int offA[PCS], offB[PCS];
+#pragma unroll
+    for (int i = 0; i < PCS; ++i) {
+        int kk;
+        offA[i] = (int)(dma_src<A_KC>(wave * PCS + i, lane, p.lda, rowsA, &kk) * 4) + 2048 - 256 * i;
+        offB[i] = (int)(dma_src<B_KC>(wave * PCS + i, lane, p.ldb, rowsB, &kk) * 4) + 2048 - 256 * i;
     }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the ring
 
-    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();  // previous tile fully consumed
-        if (vec) {
-            store_tile_v4<A_KC>(As, va);
-            store_tile_v4<B_KC>(Bs, vb);
+    auto issue = [&](int c) {   // chunk c -> stage c % NSTAGE (A image, then B image); uniform branch on the ragged last chunk
+        const unsigned dstA = lds0 + (unsigned)(c % NSTAGE) * STAGE_BYTES + (unsigned)wave * 2048u, dstB = dstA + 64 * DK * 4;
+        if (c == nch - 1 && ragged) {
+            const int64_t k0 = kbeg + (int64_t)c * DK;
+#pragma unroll
+            for (int i = 0; i < PCS; ++i) {
+                int ka, kb;
+                const int64_t sa = dma_src<A_KC>(wave * PCS + i, lane, p.lda, rowsA, &ka);
+                const int64_t sb = dma_src<B_KC>(wave * PCS + i, lane, p.ldb, rowsB, &kb);
+                const float* pa = k0 + ka < kend ? A0 + (int64_t)c * stepA + sa : g_zero_page + lane;
+                const float* pb = k0 + kb < kend ? B0 + (int64_t)c * stepB + sb : g_zero_page + lane;
+                dma1_addr(pa, dstA + 256u * i);
+                dma1_addr(pb, dstB + 256u * i);
+            }
         } else {
-            store_tile<A_KC>(As, va);
-            store_tile<B_KC>(Bs, vb);
+            dma8(reinterpret_cast<const float*>(reinterpret_cast<const char*>(A0 + (int64_t)c * stepA) - 2048), offA, dstA);
+            dma8(reinterpret_cast<const float*>(reinterpret_cast<const char*>(B0 + (int64_t)c * stepB) - 2048), offB, dstB);
         }
-        __syncthreads();
+    };
+
+    if (nch > 0) issue(0);
+
+    // operand fetch addresses inside a stage (bytes)
+    const int rowA = wm * 32 + li, rowB = wn * 32 + li;
+    const unsigned rdA = A_KC ? (unsigned)(rowA * 128) : (unsigned)((4 * h) * 256 + ((rowA ^ (h << 5)) << 2));
+    const unsigned rdB = B_KC ? (unsigned)(rowB * 128) : (unsigned)((4 * h) * 256 + ((rowB ^ (h << 5)) << 2));
+    const unsigned swA = (unsigned)((rowA >> 1) & 7), swB = (unsigned)((rowB >> 1) & 7);
+
+    for (int c = 0; c < nch; ++c) {
+        // chunk c has landed for this wave, then for every wave; after the barrier nobody still reads the other stage
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 1 < nch) issue(c + 1);
+        const char* sA = smem + (c % NSTAGE) * STAGE_BYTES;
+        const char* sB = sA + 64 * DK * 4;
         if (do_bias) {
 #pragma unroll
-            for (int k = 0; k < BK; ++k) bsum += As[k * LDT + threadIdx.x];
+            for (int k = 0; k < DK; ++k)
+                bsum += *reinterpret_cast<const float*>(sA + k * 256 + ((threadIdx.x ^ (((k >> 2) & 1) << 5)) << 2));
         }
-        if (k0 + BK < kend) {  // prefetch the next tile while this one is multiplied
-            vec = rows_in && k0 + 2 * BK <= kend;
-            if (vec) {
-                load_tile_v4<A_KC>(p.A, p.lda, m0, k0 + BK, va);
-                load_tile_v4<B_KC>(p.B, p.ldb, n0, k0 + BK, vb);
+        float a[4][4], b[4][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (A_KC) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(sA + rdA + ((((unsigned)(2 * g + h)) ^ swA) << 4));
+                a[g][0] = q[0]; a[g][1] = q[1]; a[g][2] = q[2]; a[g][3] = q[3];
             } else {
-                load_tile<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, kend, va);
-                load_tile<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, kend, vb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[g][j] = *reinterpret_cast<const float*>(sA + rdA + (8 * g + j) * 256);
+            }
+            if (B_KC) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(sB + rdB + ((((unsigned)(2 * g + h)) ^ swB) << 4));
+                b[g][0] = q[0]; b[g][1] = q[1]; b[g][2] = q[2]; b[g][3] = q[3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[g][j] = *reinterpret_cast<const float*>(sB + rdB + (8 * g + j) * 256);
             }
         }
-        // operands of k-steps s + PRE .. are read from LDS while the MFMAs of step s run: hipcc's own schedule of the plain loop
-        // was read, read, s_waitcnt lgkmcnt(0), mfma, mfma - a fully exposed LDS latency (~100 cycles) per 128 cycles of MFMA
-        constexpr int PRE = 4, NS = BK / 2;
-        float ar[NS], br[NS];
 #pragma unroll
-        for (int s = 0; s < PRE; ++s) {
-            ar[s] = As[(2 * s + h) * LDT + wm * 32 + li];
-            br[s] = Bs[(2 * s + h) * LDT + wn * 32 + li];
-        }
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (s + PRE < NS) {
-                ar[s + PRE] = As[(2 * (s + PRE) + h) * LDT + wm * 32 + li];
-                br[s + PRE] = Bs[(2 * (s + PRE) + h) * LDT + wn * 32 + li];
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s], br[s], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-        }
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][j], b[g][j], acc, 0, 0, 0);
     }
 
     if (do_bias && m0 + threadIdx.x < p.M) atomicAdd(&p.bias_grad[m0 + threadIdx.x], bsum);
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t n = n0 + wn * 32 + li;
+    const float bias = (EPI == EPI_FWD && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    if (rowsA == BM && rowsB == BN) {   // interior tile (workgroup-uniform): no per-row bounds
+#pragma unroll
+        for (int r = 0; r < 16; ++r) store_c<EPI>(p, m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n, acc[r], bias);
+        return;
+    }
     if (n >= p.N) return;
-    const float bias = (EPI == EPI_FWD && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[r];
-        if (EPI == EPI_FWD) {
-            v += bias;
-            if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
-            else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
-            p.C[m * p.ldc + n] = v;
-        } else if (EPI == EPI_DX) {
-            if (p.accumulate) v += p.C[m * p.ldc + n];
-            if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
-            p.C[m * p.ldc + n] = v;
-        } else {
-            atomicAdd(&p.C[m * p.ldc + n], v);
-        }
+        if (m < p.M) store_c<EPI>(p, m, n, acc[r], bias);
     }
 }
 
-// ---- small-M variant ------------------------------------------------------------------------------------------
+// ---- small-M variant ------------------------------------------------------------------------------------------------------
 // A rank of the data-parallel job holds B/8 = 1024 slates: a [1024 x 256] layer is only 64 tiles of 64 x 64, a quarter
-// of the chip, and each of those workgroups is bound by its own MFMA chain (K = 1419: 23 rounds of 32 MFMAs per wave).
+// of the chip, and each of those workgroups is bound by its own MFMA chain (K = 1419: 45 rounds of 16 MFMAs per wave).
 // Here a workgroup owns a 32 x 32 tile and its four waves split every 64-deep K chunk between them (wave w multiplies
 // k in [16w, 16w + 16)), so the same layer is 256 workgroups with a 4x shorter chain each; the four partial tiles are
-// summed through LDS in a fixed order (wave 0 + 1 + 2 + 3: deterministic).
-constexpr int SM = 32, SLD = 33, STPT = SM * BK / 256;
-
+// summed through LDS in a fixed order (wave 0 + 1 + 2 + 3: deterministic).  Tiles are staged through registers into
+// K-major LDS images (row stride 33 floats: conflict-free ds_read_b32 / ds_write_b32).
 template <bool KC>
 __device__ __forceinline__ void load_tile_s(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t rows,
                                             int64_t k0, int64_t kend, float (&v)[STPT]) {
@@ -246,8 +278,8 @@ __device__ __forceinline__ void store_tile_s(float* S, const float (&v)[STPT]) {
     }
 }
 
-// 16-byte loads for interior tiles (see load_tile_v4):  KC: row = 16 i + (t >> 4), k = 4 (t & 15) + j;
-// !KC: k = 32 i + (t >> 3), row = 4 (t & 7) + j
+// 16-byte loads for interior tiles (row starts need only be 4-byte aligned, which global_load_dwordx4 accepts):
+//   KC: row = 16 i + (t >> 4), k = 4 (t & 15) + j;   !KC: k = 32 i + (t >> 3), row = 4 (t & 7) + j
 template <bool KC>
 __device__ __forceinline__ void load_tile_s_v4(const float* __restrict__ P, int64_t ld, int64_t row0, int64_t k0, float (&v)[STPT]) {
     const int t = threadIdx.x;
@@ -276,15 +308,15 @@ __device__ __forceinline__ void store_tile_s_v4(float* S, const float (&v)[STPT]
 }
 
 template <bool A_KC, bool B_KC, int EPI>
-__global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
+__device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int bx, const int by, char* smem) {
     static_assert(EPI == EPI_FWD || EPI == EPI_DX, "the weight-gradient GEMM is already split over workgroups");
-    __shared__ float As[BK * SLD];
-    __shared__ float Bs[BK * SLD];
-    __shared__ float Red[4 * SM * SM];
+    float* As = reinterpret_cast<float*>(smem);
+    float* Bs = As + SBK * SLD;
+    float* Red = Bs + SBK * SLD;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * SM, n0 = (int64_t)blockIdx.x * SM;
+    const int64_t m0 = (int64_t)by * SM, n0 = (int64_t)bx * SM;
 
     f32x16 acc;
 #pragma unroll
@@ -292,7 +324,7 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
 
     const bool rows_in = m0 + SM <= p.M && n0 + SM <= p.N;   // workgroup-uniform
     float va[STPT], vb[STPT];
-    bool vec = rows_in && BK <= p.K;
+    bool vec = rows_in && SBK <= p.K;
     if (vec) {
         load_tile_s_v4<A_KC>(p.A, p.lda, m0, 0, va);
         load_tile_s_v4<B_KC>(p.B, p.ldb, n0, 0, vb);
@@ -300,7 +332,7 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
         load_tile_s<A_KC>(p.A, p.lda, m0, p.M, 0, p.K, va);
         load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, 0, p.K, vb);
     }
-    for (int64_t k0 = 0; k0 < p.K; k0 += BK) {
+    for (int64_t k0 = 0; k0 < p.K; k0 += SBK) {
         __syncthreads();
         if (vec) {
             store_tile_s_v4<A_KC>(As, va);
@@ -310,29 +342,30 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
             store_tile_s<B_KC>(Bs, vb);
         }
         __syncthreads();
-        if (k0 + BK < p.K) {
-            vec = rows_in && k0 + 2 * BK <= p.K;
+        if (k0 + SBK < p.K) {
+            vec = rows_in && k0 + 2 * SBK <= p.K;
             if (vec) {
-                load_tile_s_v4<A_KC>(p.A, p.lda, m0, k0 + BK, va);
-                load_tile_s_v4<B_KC>(p.B, p.ldb, n0, k0 + BK, vb);
+                load_tile_s_v4<A_KC>(p.A, p.lda, m0, k0 + SBK, va);
+                load_tile_s_v4<B_KC>(p.B, p.ldb, n0, k0 + SBK, vb);
             } else {
-                load_tile_s<A_KC>(p.A, p.lda, m0, p.M, k0 + BK, p.K, va);
-                load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + BK, p.K, vb);
+                load_tile_s<A_KC>(p.A, p.lda, m0, p.M, k0 + SBK, p.K, va);
+                load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + SBK, p.K, vb);
             }
         }
-        {   // operand reads run ahead of the MFMAs (see gemm_f32_kernel)
-            constexpr int NS = BK / 8, PRE = 4;
+        {   // operand reads run PRE k-steps ahead of the MFMAs: hipcc's schedule of the plain loop was read, read,
+            // s_waitcnt lgkmcnt(0), mfma - a fully exposed LDS latency per MFMA
+            constexpr int NS = SBK / 8, PRE = 4;
             float ar[NS], br[NS];
 #pragma unroll
             for (int s = 0; s < PRE && s < NS; ++s) {
-                const int k = wave * (BK / 4) + 2 * s + h;
+                const int k = wave * (SBK / 4) + 2 * s + h;
                 ar[s] = As[k * SLD + li];
                 br[s] = Bs[k * SLD + li];
             }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 if (s + PRE < NS) {
-                    const int k = wave * (BK / 4) + 2 * (s + PRE) + h;
+                    const int k = wave * (SBK / 4) + 2 * (s + PRE) + h;
                     ar[s + PRE] = As[k * SLD + li];
                     br[s + PRE] = Bs[k * SLD + li];
                 }
@@ -351,67 +384,156 @@ __global__ void __launch_bounds__(256) gemm_f32_small_kernel(GemmParams p) {
         const int e = threadIdx.x + 256 * i, row = e >> 5, col = e & 31;
         const int64_t m = m0 + row, n = n0 + col;
         if (m >= p.M || n >= p.N) continue;
-        float v = ((Red[e] + Red[SM * SM + e]) + Red[2 * SM * SM + e]) + Red[3 * SM * SM + e];
-        if (EPI == EPI_FWD) {
-            if (p.bias) v += p.bias[n];
-            if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
-            else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
-        } else {
-            if (p.accumulate) v += p.C[m * p.ldc + n];
-            if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
-        }
-        p.C[m * p.ldc + n] = v;
+        const float v = ((Red[e] + Red[SM * SM + e]) + Red[2 * SM * SM + e]) + Red[3 * SM * SM + e];
+        store_c<EPI>(p, m, n, v, (EPI == EPI_FWD && p.bias) ? p.bias[n] : 0.f);
     }
 }
 
-// 64 x 64 tiles once they fill the chip, else 32 x 32 tiles with the K chunk split over the waves
-static inline bool use_small_tiles(int64_t M, int64_t N) {
+// ---- the kernel: one or several independent problems ---------------------------------------------------------------------
+// Hardware workgroup b runs on XCD b & 7 (round-robin dispatch).  Slot s = b >> 3 of an XCD walks the problems in order; inside
+// problem j (slots_j = cdiv(tiles_j, 8) slots per XCD) XCD x takes the logical tiles [x slots_j, (x + 1) slots_j): contiguous
+// runs, equal shares of every problem on every XCD, the first (largest) problem dispatched first.
+// (Two instantiations - a launch is all 64 x 64 DMA tiles or all small tiles - so that the DMA body's ~110 registers, not
+// the register-staged small body's 150, set the occupancy of the launches that matter.)
+template <bool SMALL>
+__global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int xcd = blockIdx.x & 7;
+    int slot = blockIdx.x >> 3, j = 0;
+    while (j + 1 < gp.n && slot >= gp.g[j].slots) {
+        slot -= gp.g[j].slots;
+        ++j;
+    }
+    const GemmParams p = gp.g[j];
+    const int l = xcd * p.slots + slot;
+    if (l >= p.nx * p.ny * p.nz) return;
+    const int bx = l % p.nx, by = (l / p.nx) % p.ny, bz = l / (p.nx * p.ny);
+    if (SMALL) {
+        if (p.kind == KIND_FWD_S) gemm_tile_small<true, true, EPI_FWD>(p, bx, by, smem);
+        else gemm_tile_small<true, false, EPI_DX>(p, bx, by, smem);
+    } else {
+        switch (p.kind) {
+            case KIND_FWD: gemm_tile_dma<true, true, EPI_FWD>(p, bx, by, bz, smem); break;
+            case KIND_DX: gemm_tile_dma<true, false, EPI_DX>(p, bx, by, bz, smem); break;
+            default: gemm_tile_dma<false, false, EPI_DW>(p, bx, by, bz, smem); break;
+        }
+    }
+}
+
+// 64 x 64 tiles once the launch fills the chip, else 32 x 32 tiles with the K chunk split over the waves
+static inline int64_t small_below() {
     static const int64_t below = [] { const char* e = getenv("PCVAE_GEMM_SMALL_BELOW"); return e ? atoll(e) : 256LL; }();
-    return cdiv(M, BM) * cdiv(N, BN) < below;
+    return below;
+}
+
+static int check_desc(const pcvae_gemm_desc& d) {
+    PCVAE_REQUIRE(d.a && d.b && d.c, "linear: null pointer");
+    PCVAE_REQUIRE(d.M >= 0 && d.N > 0 && d.K > 0, "linear: bad shape M=%lld N=%lld K=%lld", (long long)d.M, (long long)d.N,
+                  (long long)d.K);
+    switch (d.kind) {
+        case PCVAE_GEMM_FWD:
+            PCVAE_REQUIRE(d.lda >= d.K && d.ldb >= d.K && d.ldc >= d.N, "linear_fwd: bad leading dimension");
+            PCVAE_REQUIRE(d.act == PCVAE_ACT_NONE || d.act == PCVAE_ACT_LEAKY || d.act == PCVAE_ACT_RELU,
+                          "linear_fwd: unknown activation %d", d.act);
+            break;
+        case PCVAE_GEMM_DX:
+        case PCVAE_GEMM_DX_ACC:
+            PCVAE_REQUIRE(d.lda >= d.N && d.ldb >= d.K && d.ldc >= d.K && (!d.aux || d.ldaux >= d.K), "linear_bwd_input: bad shape");
+            break;
+        case PCVAE_GEMM_DW:
+            PCVAE_REQUIRE(d.lda >= d.N && d.ldb >= d.K && d.ldc >= d.K, "linear_bwd_weight: bad shape");
+            break;
+        default:
+            PCVAE_REQUIRE(false, "linear: unknown kind %d", d.kind);
+    }
+    return PCVAE_OK;
+}
+
+static int launch_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(descs && n >= 1 && n <= MAXG, "linear_group: 1..%d problems per launch", MAXG);
+    GroupParams gp;
+    gp.n = 0;
+    int64_t tiles64 = 0;
+    for (int i = 0; i < n; ++i) {
+        if (int rc = check_desc(descs[i])) return rc;
+        const pcvae_gemm_desc& d = descs[i];
+        if (d.M == 0) continue;
+        // output tiles of 64 x 64 over the whole launch decide the tile size of the forward / input-gradient problems
+        tiles64 += d.kind == PCVAE_GEMM_FWD ? cdiv(d.M, BM) * cdiv(d.N, BN)
+                 : d.kind == PCVAE_GEMM_DW ? 256 : cdiv(d.M, BM) * cdiv(d.K, BN);
+    }
+    const bool small = tiles64 < small_below();
+    const char* det_env = getenv("PCVAE_DETERMINISTIC");
+    const bool deterministic = det_env && det_env[0] == '1';
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        const pcvae_gemm_desc& d = descs[i];
+        if (d.M == 0) continue;
+        GemmParams& g = gp.g[gp.n];
+        g = GemmParams{};
+        if (d.kind == PCVAE_GEMM_FWD) {
+            g.A = d.a; g.lda = d.lda; g.B = d.b; g.ldb = d.ldb; g.C = d.c; g.ldc = d.ldc;
+            g.M = d.M; g.N = d.N; g.K = d.K; g.bias = d.aux; g.act = d.act;
+            g.kind = small ? KIND_FWD_S : KIND_FWD;
+            g.nx = (int)cdiv(d.N, small ? SM : BN); g.ny = (int)cdiv(d.M, small ? SM : BM); g.nz = 1;
+        } else if (d.kind == PCVAE_GEMM_DX || d.kind == PCVAE_GEMM_DX_ACC) {
+            // C(m, kk) = sum_n dY[m, n] * W[n, kk]:  A = dY (reduction index contiguous), B(kk, n) = W[n * ldw + kk]
+            g.A = d.a; g.lda = d.lda; g.B = d.b; g.ldb = d.ldb; g.C = d.c; g.ldc = d.ldc;
+            g.M = d.M; g.N = d.K; g.K = d.N; g.aux = d.aux; g.ldaux = d.ldaux; g.accumulate = d.kind == PCVAE_GEMM_DX_ACC;
+            g.kind = small ? KIND_DX_S : KIND_DX;
+            g.nx = (int)cdiv(d.K, small ? SM : BN); g.ny = (int)cdiv(d.M, small ? SM : BM); g.nz = 1;
+        } else {
+            // C(n, kk) = sum_m dY[m, n] * X[m, kk]: both operands row-contiguous, reduction over the batch split across z so that
+            // a [256 x 1419] gradient still fills the chip; partials land with fp32 atomics in the (pre-zeroed, accumulating)
+            // gradient buffer.  The split count minimises (waves of workgroups) x (K rounds per workgroup) for ~512 resident
+            // workgroups.  PCVAE_DETERMINISTIC=1 (environment, read per call): one split, so every gradient element receives
+            // exactly one atomic add onto the zeroed buffer - bit-reproducible from run to run, at the price of a mostly idle
+            // chip for the small layers.  (The default sums the partials in arrival order: equal to ~1e-7 relative, not bitwise.)
+            const int64_t tiles = cdiv(d.N, BM) * cdiv(d.K, BN), rounds_total = cdiv(d.M, 64);
+            int64_t splits = 1, best = INT64_MAX;
+            for (int64_t sp = 1; sp <= (deterministic ? 1 : std::min<int64_t>(64, rounds_total)); ++sp) {
+                const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
+                const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp;              // +1: prologue / epilogue
+                if (cost < best) { best = cost; splits = nsp; }
+            }
+            const int64_t kps = cdiv(rounds_total, splits) * 64;
+            g.A = d.a; g.lda = d.lda; g.B = d.b; g.ldb = d.ldb; g.C = d.c; g.ldc = d.ldc;
+            g.M = d.N; g.N = d.K; g.K = d.M; g.bias_grad = d.aux_out; g.k_per_split = kps;
+            g.kind = KIND_DW;
+            g.nx = (int)cdiv(d.K, BN); g.ny = (int)cdiv(d.N, BM); g.nz = (int)cdiv(d.M, kps);
+        }
+        const int64_t wgs = (int64_t)g.nx * g.ny * g.nz;
+        PCVAE_REQUIRE(wgs < (1LL << 28), "linear: problem too large");
+        g.slots = (int)cdiv(wgs, 8);
+        total += g.slots;
+        ++gp.n;
+    }
+    if (gp.n == 0) return PCVAE_OK;
+    PCVAE_REQUIRE(total * 8 < (1LL << 31), "linear_group: launch too large");
+    if (small)
+        hipLaunchKernelGGL(gemm_group_kernel<true>, dim3((unsigned)(total * 8)), dim3(256), SMALL_LDS, as_stream(stream), gp);
+    else
+        hipLaunchKernelGGL(gemm_group_kernel<false>, dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES, as_stream(stream), gp);
+    return check_launch("linear_group");
 }
 
 }  // namespace
 
-extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
-                                int64_t ldy, int64_t M, int64_t N, int64_t K, int act, pcvae_stream_t stream) {
-    PCVAE_REQUIRE(X && W && Y, "linear_fwd: null pointer");
-    PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N, "linear_fwd: bad shape M=%lld N=%lld K=%lld",
-                  (long long)M, (long long)N, (long long)K);
-    PCVAE_REQUIRE(act == PCVAE_ACT_NONE || act == PCVAE_ACT_LEAKY || act == PCVAE_ACT_RELU, "linear_fwd: unknown activation %d", act);
-    if (M == 0) return PCVAE_OK;
-    PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_fwd: M too large");
-    GemmParams p{X, ldx, W, ldw, Y, ldy, M, N, K, bias, nullptr, nullptr, 0, act, 0, 0};
-    if (use_small_tiles(M, N))
-        hipLaunchKernelGGL((gemm_f32_small_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, SM), (unsigned)cdiv(M, SM)),
-                           dim3(256), 0, as_stream(stream), p);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<true, true, EPI_FWD>), dim3((unsigned)cdiv(N, BN), (unsigned)cdiv(M, BM)),
-                           dim3(256), 0, as_stream(stream), p);
-    return check_launch("linear_fwd");
+extern "C" int pcvae_linear_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stream) {
+    return launch_group(descs, n, stream);
 }
 
-static int linear_bwd_input_impl(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact, int64_t ldxa,
-                                 float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K, int accumulate, pcvae_stream_t stream) {
-    PCVAE_REQUIRE(dY && W && dX, "linear_bwd_input: null pointer");
-    PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldw >= K && lddx >= K && (!Xact || ldxa >= K),
-                  "linear_bwd_input: bad shape");
-    if (M == 0) return PCVAE_OK;
-    PCVAE_REQUIRE(cdiv(M, BM) <= 65535, "linear_bwd_input: M too large");
-    // C(m, kk) = sum_n dY[m, n] * W[n, kk]:  A = dY (reduction index contiguous), B(kk, n) = W[n * ldw + kk]
-    GemmParams p{dY, lddy, W, ldw, dX, lddx, M, K, N, nullptr, nullptr, Xact, ldxa, 0, 0, accumulate};
-    if (use_small_tiles(M, K))
-        hipLaunchKernelGGL((gemm_f32_small_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, SM), (unsigned)cdiv(M, SM)),
-                           dim3(256), 0, as_stream(stream), p);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<true, false, EPI_DX>), dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(M, BM)),
-                           dim3(256), 0, as_stream(stream), p);
-    return check_launch("linear_bwd_input");
+extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
+                                int64_t ldy, int64_t M, int64_t N, int64_t K, int act, pcvae_stream_t stream) {
+    const pcvae_gemm_desc d{PCVAE_GEMM_FWD, act, X, ldx, W, ldw, Y, ldy, bias, 0, nullptr, M, N, K};
+    return launch_group(&d, 1, stream);
 }
 
 extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
                                       int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
                                       pcvae_stream_t stream) {
-    return linear_bwd_input_impl(dY, lddy, W, ldw, Xact, ldxa, dX, lddx, M, N, K, 0, stream);
+    const pcvae_gemm_desc d{PCVAE_GEMM_DX, 0, dY, lddy, W, ldw, dX, lddx, Xact, ldxa, nullptr, M, N, K};
+    return launch_group(&d, 1, stream);
 }
 
 // dX = (dX + dY . W) * LeakyReLU'(Xact): the second of two layers fed by the same activated input (the mu / logvar heads of
@@ -419,38 +541,13 @@ extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float
 extern "C" int pcvae_linear_bwd_input_acc(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
                                           int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
                                           pcvae_stream_t stream) {
-    return linear_bwd_input_impl(dY, lddy, W, ldw, Xact, ldxa, dX, lddx, M, N, K, 1, stream);
+    const pcvae_gemm_desc d{PCVAE_GEMM_DX_ACC, 0, dY, lddy, W, ldw, dX, lddx, Xact, ldxa, nullptr, M, N, K};
+    return launch_group(&d, 1, stream);
 }
 
 extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
                                        int64_t lddw, float* db, int64_t M, int64_t N, int64_t K,
                                        pcvae_stream_t stream) {
-    PCVAE_REQUIRE(dY && X && dW, "linear_bwd_weight: null pointer");
-    PCVAE_REQUIRE(M >= 0 && N > 0 && K > 0 && lddy >= N && ldx >= K && lddw >= K, "linear_bwd_weight: bad shape");
-    if (M == 0) return PCVAE_OK;
-    // C(n, kk) = sum_m dY[m, n] * X[m, kk]: both operands row-contiguous, reduction over M split
-    // across blockIdx.z so that a [256 x 1419] gradient still fills the chip; partials land with
-    // fp32 atomics in the (pre-zeroed, accumulating) gradient buffer.
-    // The split count minimises (waves of workgroups) x (K rounds per workgroup): 512 workgroups are resident at once (two
-    // per CU at this kernel's register count), so 1104 workgroups of 11 rounds take three waves where 1012 of 12 take two.
-    // PCVAE_DETERMINISTIC=1 (environment, read per call): one split, so every gradient element receives exactly one atomic add
-    // onto the zeroed buffer - bit-reproducible from run to run, at the price of a mostly idle chip for the small layers.
-    // (The default, split over M with fp32 atomics, sums the partials in arrival order: equal to ~1e-7 relative, not bitwise.)
-    const char* det_env = getenv("PCVAE_DETERMINISTIC");
-    const bool deterministic = det_env && det_env[0] == '1';
-    const int64_t tiles = cdiv(N, BM) * cdiv(K, BN), rounds_total = cdiv(M, BK);
-    int64_t splits = 1, best = INT64_MAX;
-    for (int64_t sp = 1; sp <= (deterministic ? 1 : std::min<int64_t>(64, rounds_total)); ++sp) {
-        const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
-        const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp;              // +1: prologue / epilogue of a workgroup
-        if (cost < best) { best = cost; splits = nsp; }
-    }
-    const int64_t kps = cdiv(rounds_total, splits) * BK;
-    splits = cdiv(M, kps);
-    GemmParams p{dY, lddy, X, ldx, dW, lddw, N, K, M, nullptr, db, nullptr, 0, 0, kps, 0};
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false, EPI_DW>),
-                       dim3((unsigned)cdiv(K, BN), (unsigned)cdiv(N, BM), (unsigned)splits), dim3(256), 0,
-                       as_stream(stream), p);
-    int rc = check_launch("linear_bwd_weight");
-    return rc;
+    const pcvae_gemm_desc d{PCVAE_GEMM_DW, 0, dY, lddy, X, ldx, dW, lddw, nullptr, 0, db, M, N, K};
+    return launch_group(&d, 1, stream);
 }

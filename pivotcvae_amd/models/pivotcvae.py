@@ -187,16 +187,17 @@ class UserPivotCVAE(BaseCVAE):
         N = self.docEmbed.weight.shape[0]
         enc_in, prior_in, scm_in, rx = ops.assemble_inputs(self.docEmbed.weight, None if self.noUser else self.userEmbed.weight,
                                                            s, r, u, Z)
-        y_prior = ops.mlp_heads_packed(prior_in, self._mlp_layers("prior", self._n_prior), self._head("priorMu")[0],
-                                       self._head("priorLogvar")[0])
-        y_enc = ops.mlp_heads_packed(enc_in, self._mlp_layers("enc", self._n_enc), self._head("encmu")[0], self._head("enclogvar")[0])
+        # the encoder and the prior share only their inputs: layer i of both is one grouped launch, forward and backward
+        y_enc, y_prior = ops.mlp_heads_packed_pair(
+            (enc_in, self._mlp_layers("enc", self._n_enc), self._head("encmu")[0], self._head("enclogvar")[0]),
+            (prior_in, self._mlp_layers("prior", self._n_prior), self._head("priorMu")[0], self._head("priorLogvar")[0]))
         if eps is None:
             off = self._next_offset(B * Z) if eps_offset is None else int(eps_offset)
             scm_x, self._last_eps, k = ops.latent_packed(y_enc, y_prior, scm_in, None, seed=self.rng_seed, offset=off, Z=Z)
         else:
             scm_x, self._last_eps, k = ops.latent_packed(y_enc, y_prior, scm_in, eps, Z=Z)
         self.last_pivot = s[:, 0]
-        rx = ops.mlp_into(scm_x, self._mlp_layers("scm", self._n_scm), rx, D)
+        rx = ops.mlp_into(scm_x, self._mlp_layers("scm", self._n_scm), rx, D, grad_cols=Z)   # only z carries a gradient
         keep_prob = 1.0 if n_neg is None else float(n_neg) / N
         if keep_prob > 1.0:
             raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")

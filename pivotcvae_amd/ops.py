@@ -7,8 +7,8 @@ hand-written (they call the backward kernels); nothing here falls back to eager 
 import torch
 
 from . import _hip
-from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, PREC_BF16, PREC_BF16X3, PREC_F32, PREC_SCREENED, check, lib, ptr,
-                   require_device, stream)
+from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, GEMM_DW, GEMM_DX, GEMM_DX_ACC, GEMM_FWD, GEMM_GROUP_MAX, PREC_BF16, PREC_BF16X3,
+                   PREC_F32, PREC_SCREENED, GemmDesc, check, lib, ptr, require_device, stream)
 
 F32 = torch.float32
 
@@ -162,6 +162,60 @@ def linear_bwd_weight_raw(gy, x, dW, db):
         "linear_bwd_weight"))
 
 
+class GemmGroup:
+    """Independent layer GEMMs collected into ONE launch (pcvae_linear_group): a layer's weight- and input-gradient, the same
+    layer of two stacks that do not feed each other.  The methods mirror linear_fwd_raw / linear_bwd_input_raw /
+    linear_bwd_weight_raw; nothing runs before launch()."""
+
+    def __init__(self):
+        self.descs, self.keep, self.flops = [], [], 0.0
+
+    def _add(self, kind, act, a, b, c, aux, aux_out, M, N, K):
+        d = GemmDesc(kind, act, a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), c.data_ptr(), _ld(c),
+                     aux.data_ptr() if aux is not None else None, (_ld(aux) if aux is not None and aux.dim() == 2 else 0),
+                     aux_out.data_ptr() if aux_out is not None else None, M, N, K)
+        for x in (a, b, c, aux, aux_out):
+            if x is not None and x.dtype != F32:
+                raise TypeError(f"expected {F32}, got {x.dtype}")
+        self.descs.append(d)
+        self.keep += [a, b, c, aux, aux_out]
+        self.flops += 2.0 * M * N * K
+
+    def fwd(self, x, W, b, act, out=None):
+        x = _c2d(x)
+        M, K = x.shape
+        N = W.shape[0]
+        if W.shape[1] != K:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({M}x{K} and {W.shape[1]}x{N})")
+        if out is None:
+            out = torch.empty(M, N, dtype=F32, device=x.device)
+        self._add(GEMM_FWD, act, x, W, out, b, None, M, N, K)
+        return out
+
+    def dx(self, gy, W, xact=None, out=None, accumulate=False, cols=None):
+        """out[M, cols] = gy @ W[:, :cols] (* LeakyReLU'(xact)); cols = None: every input column"""
+        gy = _c2d(gy)
+        M, N = gy.shape
+        K = W.shape[1] if cols is None else int(cols)
+        if out is None:
+            out = torch.empty(M, K, dtype=F32, device=gy.device)
+        self._add(GEMM_DX_ACC if accumulate else GEMM_DX, 0, gy, W, out, xact, None, M, N, K)
+        return out
+
+    def dw(self, gy, x, dW, db):
+        gy, x = _c2d(gy), _c2d(x)
+        M, N = gy.shape
+        self._add(GEMM_DW, 0, gy, x, dW, None, db, M, N, x.shape[1])
+
+    def launch(self):
+        for i in range(0, len(self.descs), GEMM_GROUP_MAX):
+            part = self.descs[i:i + GEMM_GROUP_MAX]
+            arr = (GemmDesc * len(part))(*part)
+            flops = sum(2.0 * d.M * d.N * d.K for d in part)
+            _timed_gemm(flops, lambda: check(lib().pcvae_linear_group(arr, len(part), stream()), "linear_group"))
+        self.descs, self.keep = [], []
+
+
 def leaky_bwd_(g, y):
     check(lib().pcvae_leaky_bwd(ptr(g, F32), _ld(g), ptr(y, F32), _ld(y), g.shape[0], g.shape[1], stream()),
           "leaky_bwd")
@@ -206,23 +260,22 @@ class _MLP(torch.autograd.Function):
         if not ctx.last_linear:  # the top layer is activated: apply its LeakyReLU' explicitly
             g = leaky_bwd_(g.clone(), acts[n])
         grads = [None] * (2 * n)
-        for i in range(n - 1, -1, -1):
+        for i in range(n - 1, -1, -1):   # a layer's weight- and input-gradient are independent: one grouped launch
             W, b = params[2 * i], params[2 * i + 1]
+            grp = GemmGroup()
             if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
                 dW, db = ctx.direct[2 * i], ctx.direct[2 * i + 1]
-                if dW is not None and db is not None:
-                    linear_bwd_weight_raw(g, acts[i], dW, db)  # accumulated in place: nothing to hand to autograd
-                else:
-                    dW = torch.zeros_like(W)
-                    db = torch.zeros_like(b)
-                    linear_bwd_weight_raw(g, acts[i], dW, db)
+                if dW is None or db is None:   # else: accumulated in place, nothing to hand to autograd
+                    dW, db = torch.zeros_like(W), torch.zeros_like(b)
                     grads[2 * i], grads[2 * i + 1] = dW, db
+                grp.dw(g, acts[i], dW, db)
             if i > 0:
-                g = linear_bwd_input_raw(g, W, xact=acts[i])  # acts[i] is layer i-1's activated output
+                g = grp.dx(g, W, xact=acts[i])  # acts[i] is layer i-1's activated output
             elif ctx.needs_input_grad[0]:
-                g = linear_bwd_input_raw(g, W, xact=None)
+                g = grp.dx(g, W, xact=None)
             else:
                 g = None
+            grp.launch()
         return (g, None) + tuple(grads)
 
 
@@ -271,33 +324,36 @@ class _MLPHeads(torch.autograd.Function):
         grads = [None] * len(params)
         h = acts[n]
 
-        def weight_grad(k, g, a):   # parameter pair k (weight 2k, bias 2k + 1) from output gradient g and layer input a
+        def weight_grad(grp, k, g, a):   # parameter pair k (weight 2k, bias 2k + 1) from output gradient g and layer input a
             if not (ctx.needs_input_grad[2 + 2 * k] or ctx.needs_input_grad[3 + 2 * k]):
                 return
             dW, db = ctx.direct[2 * k], ctx.direct[2 * k + 1]
-            if dW is not None and db is not None:
-                linear_bwd_weight_raw(g, a, dW, db)   # accumulated in place: nothing to hand to autograd
-            else:
+            if dW is None or db is None:   # else: accumulated in place, nothing to hand to autograd
                 dW, db = torch.zeros_like(params[2 * k]), torch.zeros_like(params[2 * k + 1])
-                linear_bwd_weight_raw(g, a, dW, db)
                 grads[2 * k], grads[2 * k + 1] = dW, db
+            grp.dw(g, a, dW, db)
 
         ga, gb = _c2d(ga), _c2d(gb)
-        weight_grad(n, ga, h)
-        weight_grad(n + 1, gb, h)
+        grp = GemmGroup()   # both heads' weight gradients and the first head's input gradient: independent, one launch
+        weight_grad(grp, n, ga, h)
+        weight_grad(grp, n + 1, gb, h)
         if n == 0 and not ctx.needs_input_grad[0]:
+            grp.launch()
             return (None, None) + tuple(grads)
         # d h = ga Wa + gb Wb, masked with the trunk's top LeakyReLU' in the second GEMM's epilogue
-        g = linear_bwd_input_raw(ga, params[2 * n], xact=None)
+        g = grp.dx(ga, params[2 * n], xact=None)
+        grp.launch()
         g = linear_bwd_input_acc_raw(gb, params[2 * n + 2], h if n > 0 else None, g)
         for i in range(n - 1, -1, -1):
-            weight_grad(i, g, acts[i])
+            grp = GemmGroup()
+            weight_grad(grp, i, g, acts[i])
             if i > 0:
-                g = linear_bwd_input_raw(g, params[2 * i], xact=acts[i])
+                g = grp.dx(g, params[2 * i], xact=acts[i])
             elif ctx.needs_input_grad[0]:
-                g = linear_bwd_input_raw(g, params[0], xact=None)
+                g = grp.dx(g, params[0], xact=None)
             else:
                 g = None
+            grp.launch()
         return (g, None) + tuple(grads)
 
 
@@ -355,60 +411,90 @@ def _cat2(a, b):
     return torch.as_strided(a, shape, a.stride())
 
 
-class _MLPHeadsPacked(torch.autograd.Function):
-    """LeakyReLU trunk + the two linear heads as ONE GEMM with N = 2 Z (models/pivotcvae.py:167-173, 232-239): the output is the
-    packed [mu | logvar].  Needs heads_adjacent(); gradients accumulate straight into the flat gradient buffer."""
+class _StacksPacked(torch.autograd.Function):
+    """One or several INDEPENDENT stacks, each a LeakyReLU trunk + its two linear heads as ONE GEMM with N = 2 Z
+    (models/pivotcvae.py:167-173, 232-239); the output of a stack is the packed [mu | logvar].  Layer i of every stack is one
+    grouped launch (the encoder and the prior share only their inputs), and in backward so are a layer's weight- and
+    input-gradient.  Needs heads_adjacent(); gradients accumulate straight into the flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, x, n_trunk, *params):
-        require_device(x, *params)
-        x = _c2d(x)
-        acts = [x]
-        h = x
-        for i in range(n_trunk):
-            h = linear_fwd_raw(h, params[2 * i], params[2 * i + 1], ACT_LEAKY)
-            acts.append(h)
-        Wa, ba, Wb, bb = params[2 * n_trunk:2 * n_trunk + 4]
-        y = linear_fwd_raw(h, _cat2(Wa, Wb), _cat2(ba, bb), ACT_NONE)
-        ctx.n = n_trunk
-        ctx.direct = [p.grad for p in params]   # views of the flat gradient buffer: accumulated into in place
-        if any(g is None for g in ctx.direct):
+    def forward(ctx, spec, *tensors):
+        S = len(spec)
+        require_device(*tensors)
+        xs = [_c2d(x) for x in tensors[:S]]
+        params, pos = [], S
+        for n in spec:
+            params.append(tensors[pos:pos + 2 * n + 4])
+            pos += 2 * n + 4
+        acts = [[x] for x in xs]
+        ys = [None] * S
+        for lvl in range(max(spec) + 1):
+            grp = GemmGroup()
+            for s, n in enumerate(spec):
+                P = params[s]
+                if lvl < n:
+                    acts[s].append(grp.fwd(acts[s][-1], P[2 * lvl], P[2 * lvl + 1], ACT_LEAKY))
+                elif lvl == n:
+                    Wa, ba, Wb, bb = P[2 * n:2 * n + 4]
+                    ys[s] = grp.fwd(acts[s][-1], _cat2(Wa, Wb), _cat2(ba, bb), ACT_NONE)
+            grp.launch()
+        ctx.spec = spec
+        ctx.direct = [[q.grad for q in P] for P in params]   # views of the flat gradient buffer: accumulated into in place
+        if any(g is None for D in ctx.direct for g in D):
             raise RuntimeError("mlp_heads_packed needs gradient buffers attached to every parameter (FlatAdam)")
-        ctx.save_for_backward(*acts, *params)
-        return y
+        ctx.save_for_backward(*[a for A in acts for a in A], *[q for P in params for q in P])
+        return tuple(ys)
 
     @staticmethod
-    def backward(ctx, g):
-        n = ctx.n
-        saved = ctx.saved_tensors
-        acts, params = saved[: n + 1], saved[n + 1:]
-        Wa, ba, Wb, bb = params[2 * n:2 * n + 4]
-        dWa, dba, dWb, dbb = ctx.direct[2 * n:2 * n + 4]
-        g = _c2d(g)
-        h = acts[n]
-        linear_bwd_weight_raw(g, h, _cat2(dWa, dWb), _cat2(dba, dbb))
-        grads = [None] * len(params)
-        if n == 0 and not ctx.needs_input_grad[0]:
-            return (None, None) + tuple(grads)
-        g = linear_bwd_input_raw(g, _cat2(Wa, Wb), xact=h if n > 0 else None)
-        for i in range(n - 1, -1, -1):
-            W, b = params[2 * i], params[2 * i + 1]
-            linear_bwd_weight_raw(g, acts[i], ctx.direct[2 * i], ctx.direct[2 * i + 1])
-            if i > 0:
-                g = linear_bwd_input_raw(g, W, xact=acts[i])
-            elif ctx.needs_input_grad[0]:
-                g = linear_bwd_input_raw(g, W, xact=None)
-            else:
-                g = None
-        return (g, None) + tuple(grads)
+    def backward(ctx, *gs):
+        spec = ctx.spec
+        S = len(spec)
+        saved = list(ctx.saved_tensors)
+        acts, pos = [], 0
+        for n in spec:
+            acts.append(saved[pos:pos + n + 1])
+            pos += n + 1
+        params = []
+        for n in spec:
+            params.append(saved[pos:pos + 2 * n + 4])
+            pos += 2 * n + 4
+        g = [_c2d(x) for x in gs]
+        for lvl in range(max(spec) + 1):   # level 0 = the heads, level j = trunk layer n - j
+            grp = GemmGroup()
+            for s, n in enumerate(spec):
+                P, D, need_x = params[s], ctx.direct[s], ctx.needs_input_grad[1 + s]
+                if lvl == 0:
+                    Wa, ba, Wb, bb = P[2 * n:2 * n + 4]
+                    dWa, dba, dWb, dbb = D[2 * n:2 * n + 4]
+                    h = acts[s][n]
+                    grp.dw(g[s], h, _cat2(dWa, dWb), _cat2(dba, dbb))
+                    g[s] = grp.dx(g[s], _cat2(Wa, Wb), xact=h if n > 0 else None) if (n > 0 or need_x) else None
+                elif lvl <= n:
+                    i = n - lvl
+                    grp.dw(g[s], acts[s][i], D[2 * i], D[2 * i + 1])
+                    g[s] = grp.dx(g[s], P[2 * i], xact=acts[s][i] if i > 0 else None) if (i > 0 or need_x) else None
+            grp.launch()
+        return (None,) + tuple(g) + (None,) * (len(saved) - sum(n + 1 for n in spec))
+
+
+def _stack_args(x, trunk, head_a, head_b):
+    flat = []
+    for W, b in list(trunk) + [head_a, head_b]:
+        flat += [W, b]
+    return x, flat
 
 
 def mlp_heads_packed(x, trunk, head_a, head_b):
     """-> [head_a(trunk(x)) | head_b(trunk(x))] as one [B, 2 Z] tensor (heads_adjacent(head_a, head_b) must hold)"""
-    flat = []
-    for W, b in list(trunk) + [head_a, head_b]:
-        flat += [W, b]
-    return _MLPHeadsPacked.apply(x, len(trunk), *flat)
+    x, flat = _stack_args(x, trunk, head_a, head_b)
+    return _StacksPacked.apply((len(trunk),), x, *flat)[0]
+
+
+def mlp_heads_packed_pair(stack_a, stack_b):
+    """two independent stacks (x, trunk, head_a, head_b) layer by layer in grouped launches -> (y_a, y_b), each as mlp_heads_packed"""
+    xa, fa = _stack_args(*stack_a)
+    xb, fb = _stack_args(*stack_b)
+    return _StacksPacked.apply((len(stack_a[1]), len(stack_b[1])), xa, xb, *fa, *fb)
 
 
 class _LatentPacked(torch.autograd.Function):
@@ -459,10 +545,13 @@ def latent_packed(y_enc, y_prior, scm_in, eps=None, seed=0, offset=0, Z=None):
 class _MLPInto(torch.autograd.Function):
     """_MLP (last layer linear) whose last layer writes into the column window [col0, col0 + out) of a prepared buffer, which is
     returned whole: the slate-completion stack fills slots 1.. of rx next to the pivot row (models/pivotcvae.py:222-226's
-    reshape + cat never happens).  The columns in front of col0 are constants for autograd."""
+    reshape + cat never happens).  The columns in front of col0 are constants for autograd.  grad_cols: only the first
+    grad_cols columns of x carry a gradient (x = [z | condition | pivot row | user row]: everything behind z comes from frozen
+    tables) - the bottom layer's input-gradient GEMM computes just those, the rest of the returned gradient is UNWRITTEN memory
+    that the producer of x (latent_packed) never reads."""
 
     @staticmethod
-    def forward(ctx, x, out_buf, col0, *params):
+    def forward(ctx, x, out_buf, col0, grad_cols, *params):
         require_device(x, out_buf, *params)
         n = len(params) // 2
         x = _c2d(x)
@@ -473,7 +562,7 @@ class _MLPInto(torch.autograd.Function):
             acts.append(h)
         width = params[2 * n - 2].shape[0]
         linear_fwd_raw(h, params[2 * n - 2], params[2 * n - 1], ACT_NONE, out=out_buf[:, col0:col0 + width])
-        ctx.n, ctx.col0, ctx.width = n, col0, width
+        ctx.n, ctx.col0, ctx.width, ctx.grad_cols = n, col0, width, grad_cols
         ctx.direct = [p.grad if (p.is_leaf and p.requires_grad and p.grad is not None and p.grad.is_cuda
                                  and p.grad.shape == p.shape and p.grad.is_contiguous()) else None for p in params]
         ctx.save_for_backward(*acts, *params)
@@ -487,30 +576,35 @@ class _MLPInto(torch.autograd.Function):
         acts, params = saved[:n], saved[n:]
         g = _c2d(g)[:, ctx.col0:ctx.col0 + ctx.width]
         grads = [None] * (2 * n)
-        for i in range(n - 1, -1, -1):
+        for i in range(n - 1, -1, -1):   # a layer's weight- and input-gradient are independent: one grouped launch
             W, b = params[2 * i], params[2 * i + 1]
-            if ctx.needs_input_grad[3 + 2 * i] or ctx.needs_input_grad[4 + 2 * i]:
+            grp = GemmGroup()
+            if ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i]:
                 dW, db = ctx.direct[2 * i], ctx.direct[2 * i + 1]
-                if dW is not None and db is not None:
-                    linear_bwd_weight_raw(g, acts[i], dW, db)
-                else:
+                if dW is None or db is None:
                     dW, db = torch.zeros_like(W), torch.zeros_like(b)
-                    linear_bwd_weight_raw(g, acts[i], dW, db)
                     grads[2 * i], grads[2 * i + 1] = dW, db
+                grp.dw(g, acts[i], dW, db)
             if i > 0:
-                g = linear_bwd_input_raw(g, W, xact=acts[i])
+                g = grp.dx(g, W, xact=acts[i])
             elif ctx.needs_input_grad[0]:
-                g = linear_bwd_input_raw(g, W, xact=None)
+                if ctx.grad_cols is not None and ctx.grad_cols < W.shape[1]:
+                    full = torch.empty(g.shape[0], W.shape[1], dtype=F32, device=g.device)
+                    grp.dx(g, W, xact=None, out=full[:, :ctx.grad_cols], cols=ctx.grad_cols)
+                    g = full
+                else:
+                    g = grp.dx(g, W, xact=None)
             else:
                 g = None
-        return (g, None, None) + tuple(grads)
+            grp.launch()
+        return (g, None, None, None) + tuple(grads)
 
 
-def mlp_into(x, layers, out_buf, col0):
+def mlp_into(x, layers, out_buf, col0, grad_cols=None):
     flat = []
     for W, b in layers:
         flat += [W, b]
-    return _MLPInto.apply(x, out_buf, int(col0), *flat)
+    return _MLPInto.apply(x, out_buf, int(col0), None if grad_cols is None else int(grad_cols), *flat)
 
 
 def mlp(x, layers, last_linear):
