@@ -169,7 +169,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
         const unsigned dstA = lds0 + (unsigned)(c % NSTAGE) * STAGE_BYTES + (unsigned)wave * 2048u, dstB = dstA + 64 * DK * 4;
         if (c == nch - 1 && ragged) {
             const int64_t k0 = kbeg + (int64_t)c * DK;
-#pragma unroll
+#pragma unroll 1   // once per workgroup: rolled, or its sixteen 64-bit addresses set the register count of the whole kernel
             for (int i = 0; i < PCS; ++i) {
                 int ka, kb;
                 const int64_t sa = dma_src<A_KC>(wave * PCS + i, lane, p.lda, rowsA, &ka);
