@@ -158,6 +158,39 @@ def test_lds_bank_model_of_the_catalog_kernels():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_lds_images_of_the_gemm_kernel():
+    """tools/gemm_lds_check.py: the LDS-DMA lane -> source map of the MLP GEMMs covers both operand images exactly once, lands
+    every element where the MFMA operand reads look for it, and those reads are bank-conflict free."""
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_lds_check.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_gemm_desc_layout_matches_the_header(tmp_path):
+    """the ctypes mirror of pcvae_gemm_desc has the size and field offsets gcc gives the struct in include/pcvae.h"""
+    import subprocess
+    fields = [f for f, _ in _hip.GemmDesc._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pcvae.h"\nint main(void) { printf("%zu", sizeof(pcvae_gemm_desc));\n'
+                   + "".join(f'printf(" %zu", offsetof(pcvae_gemm_desc, {f}));\n' for f in fields) + "return 0; }\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_hip.GemmDesc)
+    assert got[1:] == [getattr(_hip.GemmDesc, f).offset for f in fields]
+
+
+def test_linear_group_argument_checks_need_no_gpu():
+    L = _hip.lib()
+    assert L.pcvae_linear_group(None, 1, None) == -1
+    d = (_hip.GemmDesc * 1)(_hip.GemmDesc(_hip.GEMM_FWD, 0, 8, 4, 8, 4, 8, 4, None, 0, None, 3, 4, 5))   # lda < K
+    assert L.pcvae_linear_group(d, 1, None) == -1 and b"leading" in L.pcvae_last_error()
+    d[0].kind = 9
+    assert L.pcvae_linear_group(d, 1, None) == -1 and b"kind" in L.pcvae_last_error()
+    many = (_hip.GemmDesc * 7)()
+    assert L.pcvae_linear_group(many, 7, None) == -1
+
+
 def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
     """The software-pipelined catalog kernel issues its MFMAs as inline asm; hipcc must not place register copies
     (v_accvgpr_*, v_mov_*, scratch) inside its steady-state loop, where no wait states protect them."""
