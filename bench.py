@@ -154,7 +154,7 @@ def mlp_roofline(trainer, s, r, u, B, lo, steps=3):
     ms = sum(a.elapsed_time(b) for _, a, b in ev)
     flops = sum(f for f, _, _ in ev)
     tf = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "gemm_f32_kernel / gemm_f32_small_kernel (all MLP GEMMs of a train step: fwd, input-grad, weight-grad)",
+    return {"kernel": "gemm_group_kernel (all MLP GEMMs of a train step - fwd, input-grad, weight-grad - as grouped launches of independent layers)",
             "bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["f32"],
             "launches_per_step": len(ev) // steps, "ms_per_step": ms / steps, "flops_per_step": flops / steps,
             "note": "PSM stack skipped in gt training (it never receives a gradient: SURVEY 0.7)"}

@@ -430,6 +430,8 @@ static int check_desc(const pcvae_gemm_desc& d) {
     PCVAE_REQUIRE(d.a && d.b && d.c, "linear: null pointer");
     PCVAE_REQUIRE(d.M >= 0 && d.N > 0 && d.K > 0, "linear: bad shape M=%lld N=%lld K=%lld", (long long)d.M, (long long)d.N,
                   (long long)d.K);
+    // a tile's DMA lane offsets are 32-bit byte offsets from the tile origin: 64 rows (or 32 k lines) of ld floats
+    PCVAE_REQUIRE(d.lda < (1LL << 22) && d.ldb < (1LL << 22), "linear: leading dimension too large");
     switch (d.kind) {
         case PCVAE_GEMM_FWD:
             PCVAE_REQUIRE(d.lda >= d.K && d.ldb >= d.K && d.ldc >= d.N, "linear_fwd: bad leading dimension");

@@ -158,9 +158,9 @@ def test_trunk_with_two_heads_is_one_node(ops, M, K, H, Z, n_trunk, x_grad):
         torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=2e-4)
 
 
-def test_linear_large_shapes_take_the_64x64_kernel_and_its_16_byte_loads(ops):
-    """>= 256 output tiles of 64 x 64: gemm_f32_kernel with 16-byte loads on interior tiles; K = 283 makes every row start
-    4-byte but not 16-byte aligned and leaves a ragged last k chunk; M and N leave ragged edge tiles (scalar path)."""
+def test_linear_large_shapes_take_the_64x64_lds_dma_tiles(ops):
+    """>= 256 output tiles of 64 x 64: the LDS-DMA body of gemm_group_kernel; K = 283 makes every row start 4-byte but not
+    16-byte aligned and leaves a ragged last k chunk (zero-page lanes); M and N leave ragged edge tiles (clamped rows)."""
     M, K, N = 2100, 283, 650
     x, W, b, g = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3), rnd(M, N, seed=4)
     xd, Wd, bd, gd = x.to(DEV), W.to(DEV), b.to(DEV), g.to(DEV)
