@@ -124,21 +124,23 @@ def gather_roofline(model, cfg, device, tables=4):
 
 
 def mlp_roofline(trainer, s, r, u, B, lo, steps=3):
-    """MFMA utilisation of the MLP stacks (K3): every GEMM launch of `steps` eager train steps is bracketed with HIP
-    events on the launch stream; achieved = sum of 2*M*N*K over the launches / sum of their durations, against the
-    dense f32 MFMA peak (the MLPs compute in exact fp32: v_mfma_f32_32x32x2_f32).  The ~2.4 us an event pair costs is
-    inside every duration (launches are 5-90 us), so the figure is a lower bound of what rocprofv3 shows."""
+    """MFMA utilisation of the MLP stacks (K3).  Every pass of a stack - the forward of encoder || prior, the forward of the
+    slate-completion stack, and their two backward passes: runs of dependent GEMM launches with nothing between them - is
+    bracketed with ONE pair of HIP events on the launch stream (ops.gemm_span), `steps` eager train steps;
+    achieved = sum of 2*M*N*K over the launches / sum of the intervals, against the dense f32 MFMA peak (the MLPs compute in exact
+    fp32: v_mfma_f32_32x32x2_f32).  The intervals include the gaps between a pass's launches and the ~2.4 us an event pair costs, so
+    the figure is a lower bound of what the kernel durations in rocprofv3's trace give."""
     from pivotcvae_amd import ops
     ev = []
 
-    def begin(flops):
+    def begin():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        return flops, e0, e1
+        return e0, e1
 
-    def end(tok):
-        tok[2].record()
-        ev.append(tok)
+    def end(tok, flops, launches):
+        tok[1].record()
+        ev.append((flops, launches, tok[0], tok[1]))
 
     was = trainer.capture_graph
     trainer.capture_graph = False
@@ -151,13 +153,16 @@ def mlp_roofline(trainer, s, r, u, B, lo, steps=3):
     finally:
         ops.GEMM_TIMING = None
         trainer.capture_graph = was
-    ms = sum(a.elapsed_time(b) for _, a, b in ev)
-    flops = sum(f for f, _, _ in ev)
+    ms = sum(a.elapsed_time(b) for _, _, a, b in ev)
+    flops = sum(f for f, _, _, _ in ev)
     tf = flops / (ms * 1e-3) / 1e12
     return {"kernel": "gemm_group_kernel (all MLP GEMMs of a train step - fwd, input-grad, weight-grad - as grouped launches of independent layers)",
             "bound": "mfma", "achieved": tf, "peak": PEAK_TFLOPS["f32"], "unit": "TFLOP/s", "frac": tf / PEAK_TFLOPS["f32"],
-            "launches_per_step": len(ev) // steps, "ms_per_step": ms / steps, "flops_per_step": flops / steps,
-            "note": "PSM stack skipped in gt training (it never receives a gradient: SURVEY 0.7)"}
+            "launches_per_step": sum(n for _, n, _, _ in ev) // steps, "timed_intervals_per_step": len(ev) // steps,
+            "ms_per_step": ms / steps, "flops_per_step": flops / steps,
+            "timed_over": "one HIP event pair per stack pass (fwd enc||prior, fwd scm, bwd scm, bwd enc||prior), launch gaps included",
+            "note": "PSM stack skipped in gt training (it never receives a gradient: SURVEY 0.7); the slate-completion stack's bottom "
+                    "input gradient covers the z columns only (the rest of its input comes from frozen tables)"}
 
 
 def eval_throughput(model, cfg, device, bs=1024, trials=2):

@@ -109,18 +109,44 @@ def concat(parts):
 
 
 # ------------------------------------------------------------------------------------------- K3
-# bench.py sets this to (begin(flops) -> token, end(token)) to bracket every MLP GEMM launch with HIP events on the
-# launch stream (MFMA utilisation of the MLP stacks); None in normal operation
+# bench.py sets this to (begin() -> token, end(token, flops, launches)) to bracket the MLP GEMM launches with HIP events on the
+# launch stream (MFMA utilisation of the MLP stacks); None in normal operation.  A stack's forward (or backward) pass is a run of
+# dependent GEMM launches with nothing between them: inside gemm_span() they are timed as ONE interval, launch gaps included.
 GEMM_TIMING = None
+_span = None   # [flops, launches, token] of the open span
+
+
+class gemm_span:
+    def __enter__(self):
+        global _span
+        self.outer = _span
+        if GEMM_TIMING is not None and _span is None:
+            _span = [0.0, 0, None]
+        return self
+
+    def __exit__(self, *exc):
+        global _span
+        if self.outer is None and _span is not None:
+            flops, launches, tok = _span
+            _span = None
+            if tok is not None:
+                GEMM_TIMING[1](tok, flops, launches)
+        return False
 
 
 def _timed_gemm(flops, launch):
     t = GEMM_TIMING
     if t is None:
         return launch()
-    tok = t[0](flops)
+    if _span is not None:
+        if _span[2] is None:
+            _span[2] = t[0]()
+        _span[0] += flops
+        _span[1] += 1
+        return launch()
+    tok = t[0]()
     launch()
-    t[1](tok)
+    t[1](tok, flops, 1)
 
 
 def linear_fwd_raw(x, W, b, act, out=None):
@@ -234,6 +260,11 @@ class _MLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, last_linear, *params):
+        with gemm_span():
+            return _MLP._forward_impl(ctx, x, last_linear, *params)
+
+    @staticmethod
+    def _forward_impl(ctx, x, last_linear, *params):
         require_device(x, *params)
         n = len(params) // 2
         x = _c2d(x)
@@ -253,6 +284,11 @@ class _MLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        with gemm_span():
+            return _MLP._backward_impl(ctx, g)
+
+    @staticmethod
+    def _backward_impl(ctx, g):
         n = ctx.n
         saved = ctx.saved_tensors
         acts, params = saved[: n + 1], saved[n + 1:]
@@ -300,6 +336,11 @@ class _MLPHeads(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_trunk, *params):
+        with gemm_span():
+            return _MLPHeads._forward_impl(ctx, x, n_trunk, *params)
+
+    @staticmethod
+    def _forward_impl(ctx, x, n_trunk, *params):
         require_device(x, *params)
         x = _c2d(x)
         acts = [x]
@@ -318,6 +359,11 @@ class _MLPHeads(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ga, gb):
+        with gemm_span():
+            return _MLPHeads._backward_impl(ctx, ga, gb)
+
+    @staticmethod
+    def _backward_impl(ctx, ga, gb):
         n = ctx.n
         saved = ctx.saved_tensors
         acts, params = saved[: n + 1], saved[n + 1:]
@@ -419,6 +465,11 @@ class _StacksPacked(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, *tensors):
+        with gemm_span():
+            return _StacksPacked._forward_impl(ctx, spec, *tensors)
+
+    @staticmethod
+    def _forward_impl(ctx, spec, *tensors):
         S = len(spec)
         require_device(*tensors)
         xs = [_c2d(x) for x in tensors[:S]]
@@ -447,6 +498,11 @@ class _StacksPacked(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
+        with gemm_span():
+            return _StacksPacked._backward_impl(ctx, *gs)
+
+    @staticmethod
+    def _backward_impl(ctx, *gs):
         spec = ctx.spec
         S = len(spec)
         saved = list(ctx.saved_tensors)
@@ -552,6 +608,11 @@ class _MLPInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, out_buf, col0, grad_cols, *params):
+        with gemm_span():
+            return _MLPInto._forward_impl(ctx, x, out_buf, col0, grad_cols, *params)
+
+    @staticmethod
+    def _forward_impl(ctx, x, out_buf, col0, grad_cols, *params):
         require_device(x, out_buf, *params)
         n = len(params) // 2
         x = _c2d(x)
@@ -571,6 +632,11 @@ class _MLPInto(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        with gemm_span():
+            return _MLPInto._backward_impl(ctx, g)
+
+    @staticmethod
+    def _backward_impl(ctx, g):
         n = ctx.n
         saved = ctx.saved_tensors
         acts, params = saved[:n], saved[n:]
