@@ -114,7 +114,12 @@ int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64
  *     PCVAE_GEMM_DX      dY, lddy   W, ldw    dX, lddx   Xact (or NULL), ldxa   -         as pcvae_linear_bwd_input
  *     PCVAE_GEMM_DX_ACC  (the same; dX = (dX + dY.W) * act'(Xact), as pcvae_linear_bwd_input_acc)
  *     PCVAE_GEMM_DW      dY, lddy   X, ldx    dW, lddw   -                      db / NULL as pcvae_linear_bwd_weight
- * 1 <= n <= 6.  Problems with M == 0 are skipped. */
+ * 1 <= n <= 6.  Problems with M == 0 are skipped.
+ * ws (optional: the DETERMINISTIC mode; pcvae_linear_group_ws_bytes(descs, n) bytes, ZERO when first used and private to the
+ * stream; the launch leaves its counters zero again): the batch splits of a weight gradient store partial tiles there and the last
+ * split to arrive adds their sum, in split order, to dW / db - no fp32 atomics, bitwise reproducible from run to run, at +12..45 us
+ * per launch (the last workgroup's serial reduction).  ws == NULL (default): fp32 atomics in arrival order, as
+ * pcvae_linear_bwd_weight (equal to ~1e-7 relative, not bitwise). */
 enum { PCVAE_GEMM_FWD = 0, PCVAE_GEMM_DX = 1, PCVAE_GEMM_DX_ACC = 2, PCVAE_GEMM_DW = 3 };
 typedef struct pcvae_gemm_desc {
     int32_t kind;
@@ -130,7 +135,8 @@ typedef struct pcvae_gemm_desc {
     float* aux_out;
     int64_t M, N, K;
 } pcvae_gemm_desc;
-int pcvae_linear_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stream);
+size_t pcvae_linear_group_ws_bytes(const pcvae_gemm_desc* descs, int n);
+int pcvae_linear_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws_bytes, pcvae_stream_t stream);
 /* in place: g *= (y > 0 ? 1 : 0.01)  - LeakyReLU backward keyed on the activated output */
 int pcvae_leaky_bwd(float* g, int64_t ldg, const float* y, int64_t ldy, int64_t rows, int cols,
                     pcvae_stream_t stream);

@@ -46,7 +46,8 @@ SIGNATURES = {
     "pcvae_linear_bwd_input": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P],
     "pcvae_linear_bwd_input_acc": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _P],
     "pcvae_linear_bwd_weight": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _P],
-    "pcvae_linear_group": [_P, _I, _P],
+    "pcvae_linear_group_ws_bytes": [_P, _I],
+    "pcvae_linear_group": [_P, _I, _P, _SZ, _P],
     "pcvae_leaky_bwd": [_P, _L, _P, _L, _L, _I, _P],
     "pcvae_reparam_fwd": [_P, _P, _P, _U64, _U64, _P, _L, _P, _L, _I, _P],
     "pcvae_philox_normal": [_P, _L, _U64, _U64, _P],
@@ -84,7 +85,7 @@ SIGNATURES = {
     "pcvae_coverage_count": [_P, _L, _L, _P, _P, _P],
     "pcvae_ils": [_P, _L, _I, _P, _L, _I, _P, _P],
 }
-_RESTYPES = {"pcvae_last_error": _c.c_char_p, "pcvae_catalog_ws_bytes": _SZ}
+_RESTYPES = {"pcvae_last_error": _c.c_char_p, "pcvae_catalog_ws_bytes": _SZ, "pcvae_linear_group_ws_bytes": _SZ}
 
 _lib = None
 

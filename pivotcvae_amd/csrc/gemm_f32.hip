@@ -62,6 +62,12 @@ struct GemmParams {
     int accumulate;                // EPI_DX: C = (C + A.B) * act'(aux) - the second of two layers that share an input
     int64_t k_per_split;           // EPI_DW: reduction range per z
     int kind, nx, ny, nz, slots;   // tile grid of this problem; slots = cdiv(nx ny nz, 8): workgroups it takes on each XCD
+    // EPI_DW with a workspace: the nz batch splits of an output tile store their partial tiles (and bias partials), the LAST one to
+    // arrive (a counter per tile, self-resetting) sums them in split order and adds the sum to C - no atomics on C, bitwise
+    // reproducible.  Null: fp32 atomics straight into C.
+    float* ws_part;                // [ny nx][nz][16][256]
+    float* ws_bias;                // [ny][nz][64]
+    unsigned* ws_cnt;              // [ny nx], zero between launches
 };
 
 struct GroupParams {
@@ -228,10 +234,58 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][j], b[g][j], acc, 0, 0, 0);
     }
 
-    if (do_bias && m0 + threadIdx.x < p.M) atomicAdd(&p.bias_grad[m0 + threadIdx.x], bsum);
-
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t n = n0 + wn * 32 + li;
+    if (EPI == EPI_DW && p.ws_part != nullptr) {
+        // Deterministic mode: partial tiles through the workspace.  (Not the default: the fp32 atomics of the 11 x 92 workgroups of
+        // enc_1's weight gradient cost 16 us of its 65 - device-scope atomics are served at the memory side - but the last
+        // workgroup's serial reduction of the partials costs more: +12 us there, +30 .. 45 us on the layers with few tiles and many
+        // splits.)
+        const int tile = by * p.nx + bx, tid = threadIdx.x;
+        if (p.nz > 1) {
+            float* part = p.ws_part + ((int64_t)tile * p.nz + bz) * 4096;
+            // device-scope (sc1) stores: written through to the memory side, where the other XCDs' workgroups can see them.  NOT a
+            // device-scope fence: that writes back and invalidates the whole L2 per workgroup (measured: +80 us per launch).
+            // The workgroup-scope release below is the s_waitcnt that holds the arrival back until the stores are acknowledged.
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(&part[r * 256 + tid], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (do_bias)
+                __hip_atomic_store(&p.ws_bias[((int64_t)by * p.nz + bz) * 64 + tid], bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            int* s_last = reinterpret_cast<int*>(smem);
+            if (tid == 0) {
+                const unsigned old = atomicAdd(&p.ws_cnt[tile], 1u);
+                *s_last = old == (unsigned)(p.nz - 1);
+                if (old == (unsigned)(p.nz - 1)) p.ws_cnt[tile] = 0;   // every split has arrived: ready for the next launch
+            }
+            __syncthreads();
+            if (!*s_last) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            float* all = p.ws_part + (int64_t)tile * p.nz * 4096;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int z = 0; z < p.nz; ++z)   // fixed order: bitwise reproducible; device-scope loads (past this XCD's L2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[r] += __hip_atomic_load(&all[z * 4096 + r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (do_bias) {
+                bsum = 0.f;
+                for (int z = 0; z < p.nz; ++z)
+                    bsum += __hip_atomic_load(&p.ws_bias[((int64_t)by * p.nz + z) * 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (do_bias && m0 + tid < p.M) p.bias_grad[m0 + tid] += bsum;
+        if (n >= p.N) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < p.M) p.C[m * p.ldc + n] += acc[r];
+        }
+        return;
+    }
+    if (do_bias && m0 + threadIdx.x < p.M) atomicAdd(&p.bias_grad[m0 + threadIdx.x], bsum);
+
     const float bias = (EPI == EPI_FWD && p.bias && n < p.N) ? p.bias[n] : 0.f;
     if (rowsA == BM && rowsB == BN) {   // interior tile (workgroup-uniform): no per-row bounds
 #pragma unroll
@@ -451,7 +505,46 @@ static int check_desc(const pcvae_gemm_desc& d) {
     return PCVAE_OK;
 }
 
-static int launch_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stream) {
+// Weight gradient C(n, kk) = sum_m dY[m, n] * X[m, kk]: both operands row-contiguous, the reduction over the batch split across z
+// so that a [256 x 1419] gradient still fills the chip.  The split count minimises (waves of workgroups) x (K rounds per
+// workgroup) for ~512 resident workgroups (sweeps over forced split counts on the model's layers found nothing better).
+// PCVAE_DETERMINISTIC=1 (environment, read per call): one split - only matters WITHOUT a workspace, where the partials land in
+// C with fp32 atomics in arrival order (equal to ~1e-7 relative, not bitwise); with a workspace every split count is bitwise
+// reproducible.
+struct DwPlan {
+    int64_t kps;      // batch rows per split (a multiple of 64)
+    int nx, ny, nz;
+};
+static DwPlan dw_plan(const pcvae_gemm_desc& d, bool have_ws) {
+    const char* det_env = getenv("PCVAE_DETERMINISTIC");
+    const bool one_split = !have_ws && det_env && det_env[0] == '1';
+    const int64_t tiles = cdiv(d.N, BM) * cdiv(d.K, BN), rounds_total = cdiv(d.M, 64);
+    int64_t splits = 1, best = INT64_MAX;
+    for (int64_t sp = 1; sp <= (one_split ? 1 : std::min<int64_t>(64, rounds_total)); ++sp) {
+        const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
+        const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp;              // +1: prologue / epilogue
+        if (cost < best) { best = cost; splits = nsp; }
+    }
+    const int64_t kps = cdiv(rounds_total, splits) * 64;
+    return DwPlan{kps, (int)cdiv(d.K, BN), (int)cdiv(d.N, BM), (int)cdiv(d.M, kps)};
+}
+
+// workspace of a launch: [tile counters of every weight-gradient problem: a FIXED 64 KB region, so that launches of different
+// shapes sharing one buffer never write partial tiles over counters][problem: partial tiles, bias partials]...
+constexpr size_t CNT_REGION = 65536;
+static size_t group_ws_bytes(const pcvae_gemm_desc* descs, int n) {
+    size_t cnt = 0, part = 0;
+    for (int i = 0; i < n; ++i) {
+        if (descs[i].kind != PCVAE_GEMM_DW || descs[i].M <= 0) continue;
+        const DwPlan pl = dw_plan(descs[i], true);
+        cnt += (size_t)pl.nx * pl.ny;
+        if (pl.nz > 1) part += ((size_t)pl.nx * pl.ny * pl.nz * 4096 + (size_t)pl.ny * pl.nz * 64) * sizeof(float);
+    }
+    if (cnt * sizeof(unsigned) > CNT_REGION) return 0;   // more output tiles than counters: the caller gets the atomics path
+    return cnt == 0 ? 0 : CNT_REGION + part;
+}
+
+static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws_bytes, pcvae_stream_t stream) {
     PCVAE_REQUIRE(descs && n >= 1 && n <= MAXG, "linear_group: 1..%d problems per launch", MAXG);
     GroupParams gp;
     gp.n = 0;
@@ -465,8 +558,10 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stre
                  : d.kind == PCVAE_GEMM_DW ? 256 : cdiv(d.M, BM) * cdiv(d.K, BN);
     }
     const bool small = tiles64 < small_below();
-    const char* det_env = getenv("PCVAE_DETERMINISTIC");
-    const bool deterministic = det_env && det_env[0] == '1';
+    const size_t ws_need = ws ? group_ws_bytes(descs, n) : 0;
+    const bool have_ws = ws != nullptr && ws_need > 0;
+    if (have_ws) PCVAE_REQUIRE(ws_bytes >= ws_need, "linear_group: workspace too small (pcvae_linear_group_ws_bytes)");
+    size_t cnt_off = 0, part_off = CNT_REGION;
     int64_t total = 0;
     for (int i = 0; i < n; ++i) {
         const pcvae_gemm_desc& d = descs[i];
@@ -485,24 +580,19 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stre
             g.kind = small ? KIND_DX_S : KIND_DX;
             g.nx = (int)cdiv(d.K, small ? SM : BN); g.ny = (int)cdiv(d.M, small ? SM : BM); g.nz = 1;
         } else {
-            // C(n, kk) = sum_m dY[m, n] * X[m, kk]: both operands row-contiguous, reduction over the batch split across z so that
-            // a [256 x 1419] gradient still fills the chip; partials land with fp32 atomics in the (pre-zeroed, accumulating)
-            // gradient buffer.  The split count minimises (waves of workgroups) x (K rounds per workgroup) for ~512 resident
-            // workgroups.  PCVAE_DETERMINISTIC=1 (environment, read per call): one split, so every gradient element receives
-            // exactly one atomic add onto the zeroed buffer - bit-reproducible from run to run, at the price of a mostly idle
-            // chip for the small layers.  (The default sums the partials in arrival order: equal to ~1e-7 relative, not bitwise.)
-            const int64_t tiles = cdiv(d.N, BM) * cdiv(d.K, BN), rounds_total = cdiv(d.M, 64);
-            int64_t splits = 1, best = INT64_MAX;
-            for (int64_t sp = 1; sp <= (deterministic ? 1 : std::min<int64_t>(64, rounds_total)); ++sp) {
-                const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
-                const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp;              // +1: prologue / epilogue
-                if (cost < best) { best = cost; splits = nsp; }
-            }
-            const int64_t kps = cdiv(rounds_total, splits) * 64;
+            const DwPlan pl = dw_plan(d, have_ws);
             g.A = d.a; g.lda = d.lda; g.B = d.b; g.ldb = d.ldb; g.C = d.c; g.ldc = d.ldc;
-            g.M = d.N; g.N = d.K; g.K = d.M; g.bias_grad = d.aux_out; g.k_per_split = kps;
+            g.M = d.N; g.N = d.K; g.K = d.M; g.bias_grad = d.aux_out; g.k_per_split = pl.kps;
             g.kind = KIND_DW;
-            g.nx = (int)cdiv(d.K, BN); g.ny = (int)cdiv(d.N, BM); g.nz = (int)cdiv(d.M, kps);
+            g.nx = pl.nx; g.ny = pl.ny; g.nz = pl.nz;
+            if (have_ws) {
+                char* base = static_cast<char*>(ws);
+                g.ws_cnt = reinterpret_cast<unsigned*>(base + cnt_off);
+                cnt_off += (size_t)pl.nx * pl.ny * sizeof(unsigned);
+                g.ws_part = reinterpret_cast<float*>(base + part_off);
+                g.ws_bias = g.ws_part + (pl.nz > 1 ? (size_t)pl.nx * pl.ny * pl.nz * 4096 : 0);
+                if (pl.nz > 1) part_off += ((size_t)pl.nx * pl.ny * pl.nz * 4096 + (size_t)pl.ny * pl.nz * 64) * sizeof(float);
+            }
         }
         const int64_t wgs = (int64_t)g.nx * g.ny * g.nz;
         PCVAE_REQUIRE(wgs < (1LL << 28), "linear: problem too large");
@@ -521,21 +611,26 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stre
 
 }  // namespace
 
-extern "C" int pcvae_linear_group(const pcvae_gemm_desc* descs, int n, pcvae_stream_t stream) {
-    return launch_group(descs, n, stream);
+extern "C" size_t pcvae_linear_group_ws_bytes(const pcvae_gemm_desc* descs, int n) {
+    if (!descs || n < 1 || n > MAXG) return 0;
+    return group_ws_bytes(descs, n);
+}
+
+extern "C" int pcvae_linear_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws_bytes, pcvae_stream_t stream) {
+    return launch_group(descs, n, ws, ws_bytes, stream);
 }
 
 extern "C" int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
                                 int64_t ldy, int64_t M, int64_t N, int64_t K, int act, pcvae_stream_t stream) {
     const pcvae_gemm_desc d{PCVAE_GEMM_FWD, act, X, ldx, W, ldw, Y, ldy, bias, 0, nullptr, M, N, K};
-    return launch_group(&d, 1, stream);
+    return launch_group(&d, 1, nullptr, 0, stream);
 }
 
 extern "C" int pcvae_linear_bwd_input(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact,
                                       int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
                                       pcvae_stream_t stream) {
     const pcvae_gemm_desc d{PCVAE_GEMM_DX, 0, dY, lddy, W, ldw, dX, lddx, Xact, ldxa, nullptr, M, N, K};
-    return launch_group(&d, 1, stream);
+    return launch_group(&d, 1, nullptr, 0, stream);
 }
 
 // dX = (dX + dY . W) * LeakyReLU'(Xact): the second of two layers fed by the same activated input (the mu / logvar heads of
@@ -544,12 +639,12 @@ extern "C" int pcvae_linear_bwd_input_acc(const float* dY, int64_t lddy, const f
                                           int64_t ldxa, float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
                                           pcvae_stream_t stream) {
     const pcvae_gemm_desc d{PCVAE_GEMM_DX_ACC, 0, dY, lddy, W, ldw, dX, lddx, Xact, ldxa, nullptr, M, N, K};
-    return launch_group(&d, 1, stream);
+    return launch_group(&d, 1, nullptr, 0, stream);
 }
 
 extern "C" int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW,
                                        int64_t lddw, float* db, int64_t M, int64_t N, int64_t K,
                                        pcvae_stream_t stream) {
     const pcvae_gemm_desc d{PCVAE_GEMM_DW, 0, dY, lddy, X, ldx, dW, lddw, nullptr, 0, db, M, N, K};
-    return launch_group(&d, 1, stream);
+    return launch_group(&d, 1, nullptr, 0, stream);
 }

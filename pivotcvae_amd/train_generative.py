@@ -86,20 +86,20 @@ def recommendation_test(model, resp_model, bs, n_test_trial=100, seed=0):
 
 
 class _FixedWorkspace(dict):
-    """workspace holder for graph capture: whatever stream asks, it gets the ONE pre-allocated buffer (never a new allocation
-    inside the capture); a request larger than the warm-up's is a bug and raises"""
+    """workspace holder for graph capture: whatever stream asks, it gets the pre-allocated buffer of that user (catalog kernels,
+    grouped GEMMs) - never a new allocation inside the capture; a request the warm-up did not make is a bug and raises"""
 
-    def __init__(self, buf):
+    def __init__(self, bufs):
         super().__init__()
-        self.buf = buf
+        self.bufs = bufs   # tag -> buffer
 
     def get(self, key, default=None):
-        if self.buf is None:
-            raise RuntimeError("catalog scratch requested during hipGraph capture but the warm-up used none")
-        return self.buf
+        if key[2] not in self.bufs:
+            raise RuntimeError(f"{key[2]} scratch requested during hipGraph capture but the warm-up used none")
+        return self.bufs[key[2]]
 
     def __setitem__(self, key, value):
-        raise RuntimeError("catalog scratch grew during hipGraph capture (the warm-up runs the same shapes: this is a bug)")
+        raise RuntimeError("scratch grew during hipGraph capture (the warm-up runs the same shapes: this is a bug)")
 
 
 class Trainer:
@@ -186,7 +186,10 @@ class Trainer:
                 self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        st["ws"] = max(warm.values(), key=lambda t: t.numel()) if warm else None
+        st["ws"] = {}
+        for key, buf in warm.items():   # per user (catalog kernels, grouped GEMMs): the largest buffer the warm-up allocated
+            if key[2] not in st["ws"] or st["ws"][key[2]].numel() < buf.numel():
+                st["ws"][key[2]] = buf
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), ops.workspace_holder(_FixedWorkspace(st["ws"])):
             st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)

@@ -214,7 +214,35 @@ def test_grouped_launch_equals_single_launches(ops):
         torch.testing.assert_close(dW.cpu(), ref.float(), rtol=1e-4, atol=5e-4)
     with pytest.raises(RuntimeError):   # seven problems are two launches through the helper, but the ABI itself takes at most six
         from pivotcvae_amd import _hip
-        _hip.check(_hip.lib().pcvae_linear_group((_hip.GemmDesc * 7)(), 7, None), "linear_group")
+        _hip.check(_hip.lib().pcvae_linear_group((_hip.GemmDesc * 7)(), 7, None, 0, None), "linear_group")
+
+
+def test_deterministic_weight_gradient_is_bitwise_reproducible(ops, monkeypatch):
+    """PCVAE_DETERMINISTIC=1: the batch splits of a weight gradient meet in the group's scratch buffer and are summed in split order
+    by the last workgroup to arrive: run-to-run BITWISE equal (the default's fp32 atomics are not), equal to fp64 at fp32 accuracy,
+    accumulating into what the buffers held, counters left zero (a second, differently shaped launch in between)."""
+    from pivotcvae_amd import _hip
+    monkeypatch.setenv("PCVAE_DETERMINISTIC", "1")
+    M, N, K = 8192, 256, 1419
+    g, x = rnd(M, N, seed=1).to(DEV), rnd(M, K, seed=2).to(DEV)
+    ref = (g.double().cpu().t() @ x.double().cpu())
+    outs = []
+    for rep in range(3):
+        dW, db = torch.full((N, K), 0.5, device=DEV), torch.full((N,), -1.0, device=DEV)
+        ops.linear_bwd_weight_raw(g, x, dW, db)
+        outs.append((dW.clone(), db.clone()))
+        d2, b2 = torch.zeros(48, 70, device=DEV), torch.zeros(48, device=DEV)   # another shape through the same scratch buffer
+        ops.linear_bwd_weight_raw(g[:300, :48], x[:300, :70], d2, b2)
+        torch.testing.assert_close(d2.cpu(), (g[:300, :48].double().cpu().t() @ x[:300, :70].double().cpu()).float(), rtol=1e-4, atol=1e-4)
+    for dW, db in outs[1:]:
+        assert torch.equal(dW, outs[0][0]) and torch.equal(db, outs[0][1])
+    torch.testing.assert_close(outs[0][0].cpu(), (ref + 0.5).float(), rtol=1e-4, atol=5e-4)
+    torch.testing.assert_close(outs[0][1].cpu(), (g.double().cpu().sum(0) - 1.0).float(), rtol=1e-4, atol=5e-4)
+    # the default (atomics, many splits) agrees to rounding
+    monkeypatch.delenv("PCVAE_DETERMINISTIC")
+    dA, bA = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    ops.linear_bwd_weight_raw(g, x, dA, bA)
+    torch.testing.assert_close(dA, outs[0][0] - 0.5, rtol=1e-5, atol=2e-4)
 
 
 def test_linear_on_column_windows(ops):

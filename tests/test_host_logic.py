@@ -182,13 +182,22 @@ def test_gemm_desc_layout_matches_the_header(tmp_path):
 
 def test_linear_group_argument_checks_need_no_gpu():
     L = _hip.lib()
-    assert L.pcvae_linear_group(None, 1, None) == -1
+    assert L.pcvae_linear_group(None, 1, None, 0, None) == -1
     d = (_hip.GemmDesc * 1)(_hip.GemmDesc(_hip.GEMM_FWD, 0, 8, 4, 8, 4, 8, 4, None, 0, None, 3, 4, 5))   # lda < K
-    assert L.pcvae_linear_group(d, 1, None) == -1 and b"leading" in L.pcvae_last_error()
+    assert L.pcvae_linear_group(d, 1, None, 0, None) == -1 and b"leading" in L.pcvae_last_error()
     d[0].kind = 9
-    assert L.pcvae_linear_group(d, 1, None) == -1 and b"kind" in L.pcvae_last_error()
+    assert L.pcvae_linear_group(d, 1, None, 0, None) == -1 and b"kind" in L.pcvae_last_error()
     many = (_hip.GemmDesc * 7)()
-    assert L.pcvae_linear_group(many, 7, None) == -1
+    assert L.pcvae_linear_group(many, 7, None, 0, None) == -1
+    # scratch of the weight gradients: a fixed 64 KB counter region + the partial tiles of every batch split; none without one
+    assert L.pcvae_linear_group_ws_bytes(d, 1) == 0
+    w = (_hip.GemmDesc * 1)(_hip.GemmDesc(_hip.GEMM_DW, 0, 8, 256, 8, 1419, 8, 1419, None, 0, None, 8192, 256, 1419))
+    need = L.pcvae_linear_group_ws_bytes(w, 1)
+    tiles = 4 * 23
+    assert need > 65536 and (need - 65536) % ((tiles * 4096 + 4 * 64) * 4) == 0   # splits x (partial tiles + bias partials)
+    assert L.pcvae_linear_group(w, 1, 8, need - 1, None) == -1 and b"workspace" in L.pcvae_last_error()
+    one = (_hip.GemmDesc * 1)(_hip.GemmDesc(_hip.GEMM_DW, 0, 8, 16, 8, 16, 8, 16, None, 0, None, 64, 16, 16))   # one split: counters only
+    assert L.pcvae_linear_group_ws_bytes(one, 1) == 65536
 
 
 def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():

@@ -15,6 +15,10 @@
 typedef int (*fwd_t)(const float*, int64_t, const float*, int64_t, const float*, float*, int64_t, int64_t, int64_t, int64_t, int, void*);
 typedef int (*dx_t)(const float*, int64_t, const float*, int64_t, const float*, int64_t, float*, int64_t, int64_t, int64_t, int64_t, void*);
 typedef int (*dw_t)(const float*, int64_t, const float*, int64_t, float*, int64_t, float*, int64_t, int64_t, int64_t, void*);
+struct Desc { int32_t kind, act; const float* a; int64_t lda; const float* b; int64_t ldb; float* c; int64_t ldc; const float* aux;
+              int64_t ldaux; float* aux_out; int64_t M, N, K; };   // pcvae_gemm_desc
+typedef size_t (*wsb_t)(const Desc*, int);
+typedef int (*grp_t)(const Desc*, int, void*, size_t, void*);
 
 struct Layer { const char* name; int64_t n_out, k_in; bool need_dx; int64_t dx_cols; };
 
@@ -25,7 +29,13 @@ int main(int argc, char** argv) {
     fwd_t fwd = (fwd_t)dlsym(h, "pcvae_linear_fwd");
     dx_t dxf = (dx_t)dlsym(h, "pcvae_linear_bwd_input");
     dw_t dwf = (dw_t)dlsym(h, "pcvae_linear_bwd_weight");
+    wsb_t wsb = (wsb_t)dlsym(h, "pcvae_linear_group_ws_bytes");
+    grp_t grp = (grp_t)dlsym(h, "pcvae_linear_group");
     if (!fwd || !dxf || !dwf) { printf("missing symbol\n"); return 1; }
+    const bool use_ws = wsb && grp && !getenv("PROBE_ATOMICS");   // weight gradients through the scratch buffer (what ops.py does)
+    void* ws = nullptr;
+    size_t ws_cap = 256u << 20;
+    if (use_ws) { CK(hipMalloc(&ws, ws_cap)); CK(hipMemset(ws, 0, ws_cap)); }
     const int64_t M = argc > 2 ? atoll(argv[2]) : 8192;
     const int iters = argc > 3 ? atoi(argv[3]) : 20;
     const Layer layers[] = {
@@ -65,7 +75,13 @@ int main(int argc, char** argv) {
         const bool z_only = L.dx_cols == 16;
         if (!z_only) {
             timeit("fwd", L, L.k_in, [&] { fwd(X, L.k_in, W, L.k_in, bias, Y, L.n_out, M, L.n_out, L.k_in, 1, nullptr); }, true);
-            timeit("dW", L, L.k_in, [&] { dwf(Y, L.n_out, X, L.k_in, dW, L.k_in, db, M, L.n_out, L.k_in, nullptr); }, true);
+            timeit("dW", L, L.k_in, [&] {
+                if (use_ws) {
+                    const Desc d{3, 0, Y, L.n_out, X, L.k_in, dW, L.k_in, nullptr, 0, db, M, L.n_out, L.k_in};
+                    const size_t need = wsb(&d, 1);
+                    if (need > ws_cap || grp(&d, 1, ws, need, nullptr) != 0) { printf("group launch failed\n"); exit(1); }
+                } else dwf(Y, L.n_out, X, L.k_in, dW, L.k_in, db, M, L.n_out, L.k_in, nullptr);
+            }, true);
         }
         if (L.need_dx)   // dX[M, cols] = dY[M, n_out] . W[n_out, :cols]; X doubles as the activated input (mask source)
             timeit("dX", L, L.dx_cols, [&] { dxf(Y, L.n_out, W, L.k_in, X, L.k_in, DX, L.k_in, M, L.n_out, L.dx_cols, nullptr); },
