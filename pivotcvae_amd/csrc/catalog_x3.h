@@ -654,9 +654,20 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_x3_kernel(CatParamsB p, 
     for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o, 64);
     const int64_t t = p.target[r];
     const bool t_ok = t >= 0 && t < p.N;
-    float zt = 0.f;   // the k-ordered fmaf chain of the f32 kernel / oracle
-    if (t_ok)
-        for (int k = 0; k < D; ++k) zt = fmaf(Ef[t * D + k], p.rx[r * D + k], zt);
+    float zt = 0.f;   // the k-ordered fmaf chain of the f32 kernel / oracle (16-byte loads, the same order)
+    if (t_ok) {
+        typedef float f32x4m __attribute__((ext_vector_type(4)));
+        const f32x4m* e4 = reinterpret_cast<const f32x4m*>(Ef + t * D);
+        const f32x4m* x4 = reinterpret_cast<const f32x4m*>(p.rx + r * D);
+#pragma unroll 8
+        for (int k = 0; k < D / 4; ++k) {
+            const f32x4m e = e4[k], x = x4[k];
+            zt = fmaf(e[0], x[0], zt);
+            zt = fmaf(e[1], x[1], zt);
+            zt = fmaf(e[2], x[2], zt);
+            zt = fmaf(e[3], x[3], zt);
+        }
+    }
     const float lse_r = log2f(L) * kLn2;
     if (lane == 0) {
         nll[r] = t_ok ? lse_r - zt : NAN;
@@ -664,10 +675,16 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_x3_kernel(CatParamsB p, 
     }
     if (dx) {
         const float invL = 1.f / L;
-        for (int d = lane; d < D; d += 64) {
-            float u = 0.f;
-            for (int j = 0; j < p.nsplit; ++j) u += p.pU[((int64_t)j * p.R + r) * D + d];
-            dx[r * D + d] = t_ok ? (u * invL - Ef[t * D + d]) * p.dx_scale : NAN;
+        static_assert(D == 128, "two columns per lane");
+        typedef float f32x2m __attribute__((ext_vector_type(2)));
+        f32x2m u = {0.f, 0.f};
+        for (int j = 0; j < p.nsplit; ++j) u += *reinterpret_cast<const f32x2m*>(p.pU + ((int64_t)j * p.R + r) * D + 2 * lane);
+        f32x2m o = {NAN, NAN};
+        if (t_ok) {
+            const f32x2m e = *reinterpret_cast<const f32x2m*>(Ef + t * D + 2 * lane);
+            o[0] = (u[0] * invL - e[0]) * p.dx_scale;
+            o[1] = (u[1] * invL - e[1]) * p.dx_scale;
         }
+        *reinterpret_cast<f32x2m*>(dx + r * D + 2 * lane) = o;
     }
 }
