@@ -245,6 +245,46 @@ def test_deterministic_weight_gradient_is_bitwise_reproducible(ops, monkeypatch)
     torch.testing.assert_close(dA, outs[0][0] - 0.5, rtol=1e-5, atol=2e-4)
 
 
+def test_linear_random_ragged_shapes(ops):
+    """forty random (M, N, K) with ragged everything - K below one 32-chunk, M / N below one tile, odd leading dimensions, column
+    windows - through forward, input gradient and weight gradient, each alone (32 x 32 or 64 x 64 tiles by size) and as one group
+    (64 x 64 LDS-DMA tiles), against fp64 on the CPU."""
+    import random
+    rng = random.Random(1234)
+    for case in range(40):
+        M = rng.choice([1, 2, 31, 33, 63, 64, 65, 127, 200, 1000, 1300])
+        N = rng.choice([1, 3, 16, 31, 32, 33, 64, 65, 100, 130])
+        K = rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 96, 97, 283])
+        padx, padw, pady = rng.choice([0, 1, 3]), rng.choice([0, 2]), rng.choice([0, 5])
+        xb, Wb = rnd(M, K + padx, seed=100 + case), rnd(N, K + padw, seed=200 + case, scale=0.3)
+        b, g = rnd(N, seed=300 + case), rnd(M, N + pady, seed=400 + case)
+        xd, Wd, bd, gd = xb.to(DEV)[:, padx:], Wb.to(DEV)[:, :K], b.to(DEV), g.to(DEV)[:, :N]
+        x64, W64, g64 = xb[:, padx:].double(), Wb[:, :K].double(), g[:, :N].double()
+        tol = dict(rtol=1e-4, atol=2e-5 * max(1.0, (max(K, N, M) / 64.0) ** 0.5))
+        want_y = torch.nn.functional.leaky_relu(x64 @ W64.t() + b.double(), 0.01).float()
+        want_dx, want_dW, want_db = (g64 @ W64).float(), (g64.t() @ x64).float(), g64.sum(0).float()
+        # alone
+        torch.testing.assert_close(ops.linear_fwd_raw(xd, Wd, bd, 1).cpu(), want_y, **tol)
+        torch.testing.assert_close(ops.linear_bwd_input_raw(gd, Wd).cpu(), want_dx, **tol)
+        dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        ops.linear_bwd_weight_raw(gd, xd, dW, db)
+        torch.testing.assert_close(dW.cpu(), want_dW, **tol)
+        torch.testing.assert_close(db.cpu(), want_db, **tol)
+        # as one group, outputs into column windows of wider buffers
+        grp = ops.GemmGroup()
+        ybuf, dxbuf = torch.full((M, N + 3), 9.0, device=DEV), torch.full((M, K + 2), 9.0, device=DEV)
+        grp.fwd(xd, Wd, bd, 1, out=ybuf[:, 3:])
+        grp.dx(gd, Wd, out=dxbuf[:, :K])
+        dW2, db2 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        grp.dw(gd, xd, dW2, db2)
+        grp.launch()
+        torch.testing.assert_close(ybuf[:, 3:].cpu(), want_y, **tol)
+        torch.testing.assert_close(dxbuf[:, :K].cpu(), want_dx, **tol)
+        torch.testing.assert_close(dW2.cpu(), want_dW, **tol)
+        torch.testing.assert_close(db2.cpu(), want_db, **tol)
+        assert torch.all(ybuf[:, :3] == 9.0) and torch.all(dxbuf[:, K:] == 9.0), "wrote outside its window"
+
+
 def test_linear_on_column_windows(ops):
     """inputs / outputs may be column windows of wider buffers (ld > width)."""
     big = rnd(33, 50, seed=1).to(DEV)
