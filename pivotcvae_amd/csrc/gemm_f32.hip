@@ -549,15 +549,17 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     GroupParams gp;
     gp.n = 0;
     int64_t tiles64 = 0;
+    bool has_dw = false;
     for (int i = 0; i < n; ++i) {
         if (int rc = check_desc(descs[i])) return rc;
         const pcvae_gemm_desc& d = descs[i];
         if (d.M == 0) continue;
+        has_dw |= d.kind == PCVAE_GEMM_DW;
         // output tiles of 64 x 64 over the whole launch decide the tile size of the forward / input-gradient problems
         tiles64 += d.kind == PCVAE_GEMM_FWD ? cdiv(d.M, BM) * cdiv(d.N, BN)
                  : d.kind == PCVAE_GEMM_DW ? 256 : cdiv(d.M, BM) * cdiv(d.K, BN);
     }
-    const bool small = tiles64 < small_below();
+    const bool small = tiles64 < small_below() && !has_dw;   // the weight gradient exists for 64 x 64 tiles only
     const size_t ws_need = ws ? group_ws_bytes(descs, n) : 0;
     const bool have_ws = ws != nullptr && ws_need > 0;
     if (have_ws) PCVAE_REQUIRE(ws_bytes >= ws_need, "linear_group: workspace too small (pcvae_linear_group_ws_bytes)");
