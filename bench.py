@@ -123,6 +123,9 @@ def gather_roofline(model, cfg, device, tables=4):
             "cache": "cold (512 MB written before every measurement)"}
 
 
+ASSEMBLE_RESULT = {}   # filled by mlp_roofline (the same eager steps): the train step's fused gather kernel
+
+
 def mlp_roofline(trainer, s, r, u, B, lo, steps=3):
     """MFMA utilisation of the MLP stacks (K3).  Every pass of a stack - the forward of encoder || prior, the forward of the
     slate-completion stack, and their two backward passes: runs of dependent GEMM launches with nothing between them - is
@@ -145,14 +148,26 @@ def mlp_roofline(trainer, s, r, u, B, lo, steps=3):
     was = trainer.capture_graph
     trainer.capture_graph = False
     trainer.step(s, r, u, global_batch=B, row_offset=lo)
+    asm_ev = []
     ops.GEMM_TIMING = (begin, end)
+    ops.ASSEMBLE_TIMING = (begin, lambda tok, nbytes: (tok[1].record(), asm_ev.append((nbytes, tok[0], tok[1]))))
     try:
         for _ in range(steps):
             trainer.step(s, r, u, global_batch=B, row_offset=lo)
         torch.cuda.synchronize()
     finally:
         ops.GEMM_TIMING = None
+        ops.ASSEMBLE_TIMING = None
         trainer.capture_graph = was
+    if asm_ev:   # the train step's own gather (item / user / pivot rows + one-hot click count + the concatenations, ONE launch)
+        a_ms = sum(a.elapsed_time(b) for _, a, b in asm_ev) / len(asm_ev)
+        ASSEMBLE_RESULT.clear()
+        ASSEMBLE_RESULT.update({"kernel": "assemble_inputs_vec_kernel", "bound": "hbm", "bytes_per_launch": asm_ev[0][0],
+                                "us_per_launch": a_ms * 1e3, "achieved": asm_ev[0][0] / (a_ms * 1e-3) / 1e9, "peak": 8000.0,
+                                "unit": "GB/s", "frac": asm_ev[0][0] / (a_ms * 1e-3) / 8e12,
+                                "timed_over": "one HIP event pair around the launch inside eager train steps (includes the pair's ~2.4 us)",
+                                "note": "S item rows + the user row read once, written into the encoder / prior / slate-completion inputs "
+                                        "and slot 0 of rx together with the one-hot click count"})
     ms = sum(a.elapsed_time(b) for _, _, a, b in ev)
     flops = sum(f for f, _, _, _ in ev)
     tf = flops / (ms * 1e-3) / 1e12
@@ -555,6 +570,8 @@ def main():
     if single and not args.no_extras:
         out["mlp_roofline"] = mlp_roofline(trainer, s, r, u, B, lo)
         out["gather_roofline"] = gather_roofline(model, cfg, device, tables=4 if N * D * 4 <= (1 << 30) else 2)
+        if ASSEMBLE_RESULT:
+            out["gather_roofline"]["train_step_kernel"] = dict(ASSEMBLE_RESULT)
         out["generate"] = generate_throughput(model, cfg, device)
         if args.config == "5":
             out["eval"] = eval_throughput(model, cfg, device)

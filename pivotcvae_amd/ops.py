@@ -415,6 +415,10 @@ def mlp_heads(x, trunk, head_a, head_b):
 
 
 # ---------------------------------------------------------------- fused training-path operators (fewer, larger launches)
+# bench.py sets this to (begin() -> token, end(token, bytes_moved)) to bracket the launch with HIP events inside real train steps
+ASSEMBLE_TIMING = None
+
+
 def assemble_inputs(E, U, s, r, u, Z):
     """condition + item / user / pivot gathers + the reference's concatenations in ONE launch (pcvae_assemble_inputs).
     -> (enc_in [B, S D + C (+D)], prior_in [B, C (+D)], scm_in [B, Z + C + D (+D)] with its z window unwritten, rx [B, S D] with
@@ -431,10 +435,15 @@ def assemble_inputs(E, U, s, r, u, Z):
     prior_in = torch.empty(B, C + ud, dtype=F32, device=dev)
     scm_in = torch.empty(B, Z + C + D + ud, dtype=F32, device=dev)
     rx = torch.empty(B, S * D, dtype=F32, device=dev)
+    timing = ASSEMBLE_TIMING
+    tok = timing[0]() if timing is not None else None
     check(lib().pcvae_assemble_inputs(ptr(E, F32), E.shape[0], ptr(U, F32) if U is not None else None,
                                       U.shape[0] if U is not None else 0, ptr(s), ptr(r, F32), ptr(uu), B, S, D, r.shape[1], Z,
                                       ptr(enc_in, F32), _ld(enc_in), ptr(prior_in, F32), _ld(prior_in), ptr(scm_in, F32), _ld(scm_in),
                                       ptr(rx, F32), _ld(rx), stream()), "assemble_inputs")
+    if timing is not None:   # rows read once + the four outputs written + the int64 indices
+        timing[1](tok, B * (4 * ((S + (U is not None)) * D + enc_in.shape[1] + prior_in.shape[1] + (scm_in.shape[1] - Z) + D)
+                            + 8 * (S + (U is not None))))
     return enc_in, prior_in, scm_in, rx
 
 

@@ -743,7 +743,7 @@ def test_dense_ce(ops, R, C):
 
 # ------------------------------------------------------------------ fused training-path kernels
 @pytest.mark.parametrize("no_user", [False, True])
-@pytest.mark.parametrize("B,S,D,Z,ncols", [(37, 5, 16, 4, 5), (130, 10, 128, 16, 10), (9, 20, 256, 16, 5)])
+@pytest.mark.parametrize("B,S,D,Z,ncols", [(37, 5, 16, 4, 5), (130, 10, 128, 16, 10), (9, 20, 256, 16, 5), (21, 3, 6, 3, 3)])
 def test_assemble_inputs(ops, B, S, D, Z, ncols, no_user):
     """condition + gathers + the reference's concatenations in one launch == the pieces put together with torch on the host
     (models/pivotcvae.py:250-258, :166, :201, :213, :231, :194); ncols < S: the in-loop evaluation's 5-column context."""
