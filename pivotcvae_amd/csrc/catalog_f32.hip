@@ -252,7 +252,9 @@ template <int D>
 __global__ void __launch_bounds__(256) catalog_ce_merge_f32_kernel(CatParams p, float* __restrict__ nll,
                                                                    float* __restrict__ lse, float* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave-uniform row, and known to be: the split maxima, the target index and the k-ordered logit chain below go through the
+    // scalar cache instead of 64-lane broadcast loads (see catalog_ce_merge_x3_kernel)
+    const int64_t r = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (r >= p.R) return;
     if (p.flags && p.flags[r >> 8] != 1) return;
     float M = -INFINITY;

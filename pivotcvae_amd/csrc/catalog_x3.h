@@ -646,13 +646,23 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_x3_kernel(CatParamsB p, 
                                                                   float* __restrict__ nll, float* __restrict__ lse,
                                                                   float* __restrict__ dx) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the row is wave-uniform, and known to be: the target index, the table row and the rx row then come through the SCALAR
+    // cache (s_load) instead of 64 vector loads of one address per step of the logit chain - as vector loads those 64 broadcast
+    // requests per wave kept the address unit busy for ~150 of this kernel's 196 us at config 4
+    const int64_t r = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (r >= p.R) return;
     if (p.safe_flags[r / ROWS_WG] != 0) return;   // this row block ran the exact f32 kernel (its merge writes the row)
+    // everything that does not depend on the target index is requested first: the gradient partials (two columns per lane) ride
+    // along with the index -> table row -> logit chain instead of queueing behind it
+    typedef float f32x2m __attribute__((ext_vector_type(2)));
+    static_assert(D == 128, "two columns per lane");
+    const int64_t t = p.target[r];
     float L = lane < p.nsplit ? p.pl[(int64_t)lane * p.R + r] : 0.f;
+    f32x2m u = {0.f, 0.f};
+    if (dx)
+        for (int j = 0; j < p.nsplit; ++j) u += *reinterpret_cast<const f32x2m*>(p.pU + ((int64_t)j * p.R + r) * D + 2 * lane);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) L += __shfl_xor(L, o, 64);
-    const int64_t t = p.target[r];
     const bool t_ok = t >= 0 && t < p.N;
     float zt = 0.f;   // the k-ordered fmaf chain of the f32 kernel / oracle (16-byte loads, the same order)
     if (t_ok) {
@@ -675,10 +685,6 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_x3_kernel(CatParamsB p, 
     }
     if (dx) {
         const float invL = 1.f / L;
-        static_assert(D == 128, "two columns per lane");
-        typedef float f32x2m __attribute__((ext_vector_type(2)));
-        f32x2m u = {0.f, 0.f};
-        for (int j = 0; j < p.nsplit; ++j) u += *reinterpret_cast<const f32x2m*>(p.pU + ((int64_t)j * p.R + r) * D + 2 * lane);
         f32x2m o = {NAN, NAN};
         if (t_ok) {
             const f32x2m e = *reinterpret_cast<const f32x2m*>(Ef + t * D + 2 * lane);
