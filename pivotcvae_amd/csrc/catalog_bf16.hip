@@ -311,16 +311,27 @@ __global__ void __launch_bounds__(256) catalog_row_bound_kernel(const float* __r
     __shared__ int any_unsafe;
     if (threadIdx.x == 0) any_unsafe = 0;
     __syncthreads();
-    const int64_t r = (int64_t)blockIdx.x * ROWS_WG + threadIdx.x;
+    // eight lanes per row: a wave-load covers 8 rows x 128 contiguous bytes (one thread per row made every load instruction
+    // touch 64 different cache lines), 32 rows of the block per pass
+    static_assert(ROWS_WG % 32 == 0 && D % 32 == 0, "8 lanes x 16 bytes per row and step");
+    const int part = threadIdx.x & 7, sub = threadIdx.x >> 3;
     bool unsafe = !(e_max_norm > 0.f);
-    if (r < R && !unsafe) {
-        float ss = 0.f;
-        for (int k = 0; k < D; k += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(rx + r * D + k);
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    if (!unsafe)
+        for (int pass = 0; pass < ROWS_WG / 32; ++pass) {
+            const int64_t r = (int64_t)blockIdx.x * ROWS_WG + pass * 32 + sub;
+            float ss = 0.f;
+            if (r < R) {
+#pragma unroll
+                for (int k = 0; k < D / 32; ++k) {
+                    const float4 v = *reinterpret_cast<const float4*>(rx + r * D + 4 * (part + 8 * k));
+                    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+            }
+            ss += __shfl_xor(ss, 1, 64);
+            ss += __shfl_xor(ss, 2, 64);
+            ss += __shfl_xor(ss, 4, 64);
+            if (r < R) unsafe |= !(sqrtf(ss) * e_max_norm * kLog2e <= kFastBound);  // NaN/inf rows count as unsafe
         }
-        unsafe = !(sqrtf(ss) * e_max_norm * kLog2e <= kFastBound);  // NaN/inf rows count as unsafe
-    }
     if (unsafe) atomicOr(&any_unsafe, 1);
     __syncthreads();
     if (threadIdx.x == 0) flags[blockIdx.x] = (uint8_t)any_unsafe;
