@@ -92,7 +92,8 @@ int pcvae_philox_randint(int64_t* out, int64_t n, int64_t hi, uint64_t seed, uin
  *                                                                 models/pivotcvae.py:274)
  *     dX  : dX[M,K] = (dY[M,N] @ W[N,K]) * act'(Xact[M,K])      (Xact = ACTIVATED output that fed
  *                                                                 this layer, NULL -> no act')
- *     dW  : dW[N,K] += dY[M,N]^T @ X[M,K] ;  db[N] += colsum(dY)   (accumulating; db may be NULL)
+ *     dW  : dW[N,K] += dY[M,N]^T @ X[M,K] ;  db[N] += colsum(dY)   (accumulating; db may be NULL).  The single-layer entry point
+ *           runs the batch as ONE split (no scratch buffer to combine splits through): pcvae_linear_group is the fast path
  * ------------------------------------------------------------------------------------------- */
 int pcvae_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y,
                      int64_t ldy, int64_t M, int64_t N, int64_t K, int act, pcvae_stream_t stream);
@@ -115,11 +116,11 @@ int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64
  *     PCVAE_GEMM_DX_ACC  (the same; dX = (dX + dY.W) * act'(Xact), as pcvae_linear_bwd_input_acc)
  *     PCVAE_GEMM_DW      dY, lddy   X, ldx    dW, lddw   -                      db / NULL as pcvae_linear_bwd_weight
  * 1 <= n <= 6.  Problems with M == 0 are skipped.
- * ws (optional: the DETERMINISTIC mode; pcvae_linear_group_ws_bytes(descs, n) bytes, ZERO when first used and private to the
- * stream; the launch leaves its counters zero again): the batch splits of a weight gradient store partial tiles there and the last
- * split to arrive adds their sum, in split order, to dW / db - no fp32 atomics, bitwise reproducible from run to run, at +12..45 us
- * per launch (the last workgroup's serial reduction).  ws == NULL (default): fp32 atomics in arrival order, as
- * pcvae_linear_bwd_weight (equal to ~1e-7 relative, not bitwise). */
+ * ws (pcvae_linear_group_ws_bytes(descs, n) bytes, ZERO when first used and private to the stream; a launch leaves its counters
+ * zero again): the batch splits of a weight gradient store their partial tiles there and the last split to arrive adds their sum,
+ * in split order, to dW / db - one writer per element, bitwise reproducible from run to run.  (There are NO fp32 atomics on
+ * gradients: atomicAdd(float*) between workgroups of different XCDs loses updates on this part, tools/atomic_tile_probe.hip.)
+ * ws == NULL: every weight gradient of the launch runs as ONE batch split - correct, and slow for large layers. */
 enum { PCVAE_GEMM_FWD = 0, PCVAE_GEMM_DX = 1, PCVAE_GEMM_DX_ACC = 2, PCVAE_GEMM_DW = 3 };
 typedef struct pcvae_gemm_desc {
     int32_t kind;

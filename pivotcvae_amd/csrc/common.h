@@ -65,4 +65,18 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }
 
+// fp32 atomic add that is correct when workgroups on DIFFERENT XCDs add into one cache line.  HIP's atomicAdd(float*) compiles to an
+// agent-scope global_atomic_add_f32 without sc1, which the issuing XCD's L2 executes; concurrent adders on other XCDs lose updates
+// line by line (tools/atomic_tile_probe.hip: 11 workgroups adding 1.0 to the same 64 x 64 tiles - 17 of 20 launches wrong; integer
+// adds and a compare-and-swap loop - 0 of 20).  Hence a CAS loop on the bits; used off the hot path only (the weight gradients
+// do not use atomics on their output at all: gemm_f32.hip).
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    unsigned old = __hip_atomic_load(u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(u, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+    } while (old != assumed);
+}
+
 }  // namespace pcvae

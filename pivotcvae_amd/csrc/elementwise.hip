@@ -347,7 +347,7 @@ __device__ __forceinline__ void kld_combine(const float t, float* __restrict__ o
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
         if (threadIdx.x == 0) {
             out[0] = -0.5f * tot;
-            g_kld_done = 0;
+            atomicExch(&g_kld_done, 0u);
         }
     }
 }
@@ -1139,7 +1139,7 @@ __global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __re
     for (int64_t i = wave; i < n_idx; i += n_waves) {
         const float* src = g + (i / group) * g_ld + (i % group) * (int64_t)D;
         float* dst = dtable + idx[i] * (int64_t)D;
-        for (int d = lane; d < D; d += 64) atomicAdd(dst + d, src[d]);
+        for (int d = lane; d < D; d += 64) atomic_add_f32(dst + d, src[d]);
     }
 }
 extern "C" int pcvae_scatter_add_rows(const float* g, int64_t g_ld, int group, int D, const int64_t* idx, int64_t n_idx,

@@ -64,7 +64,7 @@ struct GemmParams {
     int kind, nx, ny, nz, slots;   // tile grid of this problem; slots = cdiv(nx ny nz, 8): workgroups it takes on each XCD
     // EPI_DW with a workspace: the nz batch splits of an output tile store their partial tiles (and bias partials), the LAST one to
     // arrive (a counter per tile, self-resetting) sums them in split order and adds the sum to C - no atomics on C, bitwise
-    // reproducible.  Null: fp32 atomics straight into C.
+    // reproducible.  Null: the problem runs as ONE split.
     float* ws_part;                // [ny nx][nz][16][256]
     float* ws_bias;                // [ny][nz][64]
     unsigned* ws_cnt;              // [ny nx], zero between launches
@@ -128,8 +128,6 @@ __device__ __forceinline__ void store_c(const GemmParams& p, int64_t m, int64_t 
         if (p.accumulate) v += p.C[m * p.ldc + n];
         if (p.aux && !(p.aux[m * p.ldaux + n] > 0.f)) v *= kLeakySlope;
         p.C[m * p.ldc + n] = v;
-    } else {
-        atomicAdd(&p.C[m * p.ldc + n], v);
     }
 }
 
@@ -236,17 +234,20 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
 
     // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int64_t n = n0 + wn * 32 + li;
-    if (EPI == EPI_DW && p.ws_part != nullptr) {
-        // Deterministic mode: partial tiles through the workspace.  (Not the default: the fp32 atomics of the 11 x 92 workgroups of
-        // enc_1's weight gradient cost 16 us of its 65 - device-scope atomics are served at the memory side - but the last
-        // workgroup's serial reduction of the partials costs more: +12 us there, +30 .. 45 us on the layers with few tiles and many
-        // splits.)
+    if (EPI == EPI_DW) {
+        // NO fp32 atomics on the output.  HIP's atomicAdd(float*) is an agent-scope global_atomic_add_f32 that the issuing XCD's L2
+        // executes, and workgroups of different XCDs adding into one cache line lose updates (common.h: atomic_add_f32; the batch
+        // splits of a tile run on different XCDs by construction).  The nz splits of an output tile store their partial tiles in
+        // the launch's workspace instead, and the LAST one to arrive (a counter per tile, integer atomics are coherent) sums them
+        // in split order and adds the sum to C: one writer per element, bitwise reproducible.  One split (no workspace): plain
+        // read-modify-write.
+        //   * partials travel with device-scope (sc1) stores / loads: written through to, and read from, the memory side.  NOT a
+        //     device-scope fence: that writes back and invalidates the whole L2 per workgroup (measured: +80 us per launch).  The
+        //     workgroup-scope release is the s_waitcnt that holds the arrival back until the stores are acknowledged.
+        //   * the last workgroup requests RB splits together (the first version walked them one by one: +12 .. 45 us per launch).
         const int tile = by * p.nx + bx, tid = threadIdx.x;
         if (p.nz > 1) {
             float* part = p.ws_part + ((int64_t)tile * p.nz + bz) * 4096;
-            // device-scope (sc1) stores: written through to the memory side, where the other XCDs' workgroups can see them.  NOT a
-            // device-scope fence: that writes back and invalidates the whole L2 per workgroup (measured: +80 us per launch).
-            // The workgroup-scope release below is the s_waitcnt that holds the arrival back until the stores are acknowledged.
 #pragma unroll
             for (int r = 0; r < 16; ++r) __hip_atomic_store(&part[r * 256 + tid], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (do_bias)
@@ -257,18 +258,30 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             if (tid == 0) {
                 const unsigned old = atomicAdd(&p.ws_cnt[tile], 1u);
                 *s_last = old == (unsigned)(p.nz - 1);
-                if (old == (unsigned)(p.nz - 1)) p.ws_cnt[tile] = 0;   // every split has arrived: ready for the next launch
+                if (old == (unsigned)(p.nz - 1)) atomicExch(&p.ws_cnt[tile], 0u);   // every split has arrived: ready for the next launch
             }
             __syncthreads();
             if (!*s_last) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            float* all = p.ws_part + (int64_t)tile * p.nz * 4096;
+            float* all = p.ws_part + (int64_t)tile * p.nz * 4096 + tid;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            for (int z = 0; z < p.nz; ++z)   // fixed order: bitwise reproducible; device-scope loads (past this XCD's L2)
+            constexpr int RB = 4;   // splits requested together: 64 loads in flight per thread instead of 16
+            for (int z0 = 0; z0 < p.nz; z0 += RB) {   // fixed order: bitwise reproducible
+                float v[RB][16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    acc[r] += __hip_atomic_load(&all[z * 4096 + r * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int u = 0; u < RB; ++u) {
+                    const int z = z0 + u < p.nz ? z0 + u : p.nz - 1;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        v[u][r] = __hip_atomic_load(&all[(int64_t)z * 4096 + r * 256], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < RB; ++u)
+                    if (z0 + u < p.nz)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += v[u][r];
+            }
             if (do_bias) {
                 bsum = 0.f;
                 for (int z = 0; z < p.nz; ++z)
@@ -284,7 +297,6 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
         }
         return;
     }
-    if (do_bias && m0 + threadIdx.x < p.M) atomicAdd(&p.bias_grad[m0 + threadIdx.x], bsum);
 
     const float bias = (EPI == EPI_FWD && p.bias && n < p.N) ? p.bias[n] : 0.f;
     if (rowsA == BM && rowsB == BN) {   // interior tile (workgroup-uniform): no per-row bounds
@@ -508,16 +520,13 @@ static int check_desc(const pcvae_gemm_desc& d) {
 // Weight gradient C(n, kk) = sum_m dY[m, n] * X[m, kk]: both operands row-contiguous, the reduction over the batch split across z
 // so that a [256 x 1419] gradient still fills the chip.  The split count minimises (waves of workgroups) x (K rounds per
 // workgroup) for ~512 resident workgroups (sweeps over forced split counts on the model's layers found nothing better).
-// PCVAE_DETERMINISTIC=1 (environment, read per call): one split - only matters WITHOUT a workspace, where the partials land in
-// C with fp32 atomics in arrival order (equal to ~1e-7 relative, not bitwise); with a workspace every split count is bitwise
-// reproducible.
+// Without a workspace there is nothing to combine splits with (no fp32 atomics on the output: gemm_tile_dma): one split.
 struct DwPlan {
     int64_t kps;      // batch rows per split (a multiple of 64)
     int nx, ny, nz;
 };
 static DwPlan dw_plan(const pcvae_gemm_desc& d, bool have_ws) {
-    const char* det_env = getenv("PCVAE_DETERMINISTIC");
-    const bool one_split = !have_ws && det_env && det_env[0] == '1';
+    const bool one_split = !have_ws;   // without a workspace there is no way to combine splits (no fp32 atomics: see below)
     const int64_t tiles = cdiv(d.N, BM) * cdiv(d.K, BN), rounds_total = cdiv(d.M, 64);
     int64_t splits = 1, best = INT64_MAX;
     for (int64_t sp = 1; sp <= (one_split ? 1 : std::min<int64_t>(64, rounds_total)); ++sp) {
@@ -540,7 +549,7 @@ static size_t group_ws_bytes(const pcvae_gemm_desc* descs, int n) {
         cnt += (size_t)pl.nx * pl.ny;
         if (pl.nz > 1) part += ((size_t)pl.nx * pl.ny * pl.nz * 4096 + (size_t)pl.ny * pl.nz * 64) * sizeof(float);
     }
-    if (cnt * sizeof(unsigned) > CNT_REGION) return 0;   // more output tiles than counters: the caller gets the atomics path
+    if (cnt * sizeof(unsigned) > CNT_REGION) return 0;   // more output tiles than counters: the caller gets the one-split path
     return cnt == 0 ? 0 : CNT_REGION + part;
 }
 

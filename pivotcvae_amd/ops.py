@@ -236,9 +236,9 @@ class GemmGroup:
             part = self.descs[i:i + GEMM_GROUP_MAX]
             arr = (GemmDesc * len(part))(*part)
             flops = sum(2.0 * d.M * d.N * d.K for d in part)
-            # PCVAE_DETERMINISTIC=1: weight gradients reduce their batch splits through a scratch buffer in split order (bitwise
-            # reproducible; measured +12 .. 45 us per launch against the default, fp32 atomics in arrival order)
-            nbytes = lib().pcvae_linear_group_ws_bytes(arr, len(part)) if os.environ.get("PCVAE_DETERMINISTIC") == "1" else 0
+            # weight gradients combine their batch splits through a scratch buffer, in split order (no fp32 atomics: those lose
+            # updates between XCDs - csrc/common.h; bitwise reproducible)
+            nbytes = lib().pcvae_linear_group_ws_bytes(arr, len(part))
             ws = _workspace(self.keep[0].device, nbytes, tag="gemm", zero=True) if nbytes else None
             _timed_gemm(flops, lambda: check(lib().pcvae_linear_group(arr, len(part), ptr(ws), nbytes, stream()), "linear_group"))
         self.descs, self.keep = [], []

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
     wsb_t wsb = (wsb_t)dlsym(h, "pcvae_linear_group_ws_bytes");
     grp_t grp = (grp_t)dlsym(h, "pcvae_linear_group");
     if (!fwd || !dxf || !dwf) { printf("missing symbol\n"); return 1; }
-    const bool use_ws = wsb && grp && getenv("PROBE_DETERMINISTIC");   // weight gradients through the scratch buffer (PCVAE_DETERMINISTIC=1)
+    const bool use_ws = wsb && grp && !getenv("PROBE_NO_WS");   // weight gradients through the scratch buffer (what ops.py does)
     void* ws = nullptr;
     size_t ws_cap = 256u << 20;
     if (use_ws) { CK(hipMalloc(&ws, ws_cap)); CK(hipMemset(ws, 0, ws_cap)); }
