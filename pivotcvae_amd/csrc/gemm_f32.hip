@@ -531,7 +531,10 @@ static DwPlan dw_plan(const pcvae_gemm_desc& d, bool have_ws) {
     int64_t splits = 1, best = INT64_MAX;
     for (int64_t sp = 1; sp <= (one_split ? 1 : std::min<int64_t>(64, rounds_total)); ++sp) {
         const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
-        const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp;              // +1: prologue / epilogue
+        // +1: prologue / epilogue; the last term is the last workgroup's reduction of the nsp partial tiles, four per memory
+        // round trip (a round of 64 batch rows ~ 0.5 us ~ 64 units; a round trip ~ 1.5-2 us)
+        constexpr int64_t red = 192;   // (96 .. 384 measured within 3 % of each other on the model's layers)
+        const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp + (nsp > 1 ? red * cdiv(nsp, 4) : 0);
         if (cost < best) { best = cost; splits = nsp; }
     }
     const int64_t kps = cdiv(rounds_total, splits) * 64;
@@ -574,8 +577,14 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     if (have_ws) PCVAE_REQUIRE(ws_bytes >= ws_need, "linear_group: workspace too small (pcvae_linear_group_ws_bytes)");
     size_t cnt_off = 0, part_off = CNT_REGION;
     int64_t total = 0;
-    for (int i = 0; i < n; ++i) {
-        const pcvae_gemm_desc& d = descs[i];
+    // longest problem first: slot order is dispatch order, and a launch ends with its last workgroup
+    int order[MAXG];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order, order + n, [&](int a, int b) {
+        return (double)descs[a].M * descs[a].N * descs[a].K > (double)descs[b].M * descs[b].N * descs[b].K;
+    });
+    for (int oi = 0; oi < n; ++oi) {
+        const pcvae_gemm_desc& d = descs[order[oi]];
         if (d.M == 0) continue;
         GemmParams& g = gp.g[gp.n];
         g = GemmParams{};

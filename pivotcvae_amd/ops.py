@@ -298,22 +298,22 @@ class _MLP(torch.autograd.Function):
         if not ctx.last_linear:  # the top layer is activated: apply its LeakyReLU' explicitly
             g = leaky_bwd_(g.clone(), acts[n])
         grads = [None] * (2 * n)
-        for i in range(n - 1, -1, -1):   # a layer's weight- and input-gradient are independent: one grouped launch
+        dwg = GemmGroup()   # the weight gradients are off the dependency chain: ONE grouped launch behind the input-gradient chain
+        for i in range(n - 1, -1, -1):
             W, b = params[2 * i], params[2 * i + 1]
-            grp = GemmGroup()
             if ctx.needs_input_grad[2 + 2 * i] or ctx.needs_input_grad[3 + 2 * i]:
                 dW, db = ctx.direct[2 * i], ctx.direct[2 * i + 1]
                 if dW is None or db is None:   # else: accumulated in place, nothing to hand to autograd
                     dW, db = torch.zeros_like(W), torch.zeros_like(b)
                     grads[2 * i], grads[2 * i + 1] = dW, db
-                grp.dw(g, acts[i], dW, db)
+                dwg.dw(g, acts[i], dW, db)
             if i > 0:
-                g = grp.dx(g, W, xact=acts[i])  # acts[i] is layer i-1's activated output
+                g = linear_bwd_input_raw(g, W, xact=acts[i])  # acts[i] is layer i-1's activated output
             elif ctx.needs_input_grad[0]:
-                g = grp.dx(g, W, xact=None)
+                g = linear_bwd_input_raw(g, W, xact=None)
             else:
                 g = None
-            grp.launch()
+        dwg.launch()
         return (g, None) + tuple(grads)
 
 
@@ -382,26 +382,24 @@ class _MLPHeads(torch.autograd.Function):
             grp.dw(g, a, dW, db)
 
         ga, gb = _c2d(ga), _c2d(gb)
-        grp = GemmGroup()   # both heads' weight gradients and the first head's input gradient: independent, one launch
-        weight_grad(grp, n, ga, h)
-        weight_grad(grp, n + 1, gb, h)
+        dwg = GemmGroup()   # every weight gradient of the node: ONE grouped launch behind the input-gradient chain
+        weight_grad(dwg, n, ga, h)
+        weight_grad(dwg, n + 1, gb, h)
         if n == 0 and not ctx.needs_input_grad[0]:
-            grp.launch()
+            dwg.launch()
             return (None, None) + tuple(grads)
         # d h = ga Wa + gb Wb, masked with the trunk's top LeakyReLU' in the second GEMM's epilogue
-        g = grp.dx(ga, params[2 * n], xact=None)
-        grp.launch()
+        g = linear_bwd_input_raw(ga, params[2 * n], xact=None)
         g = linear_bwd_input_acc_raw(gb, params[2 * n + 2], h if n > 0 else None, g)
         for i in range(n - 1, -1, -1):
-            grp = GemmGroup()
-            weight_grad(grp, i, g, acts[i])
+            weight_grad(dwg, i, g, acts[i])
             if i > 0:
-                g = grp.dx(g, params[2 * i], xact=acts[i])
+                g = linear_bwd_input_raw(g, params[2 * i], xact=acts[i])
             elif ctx.needs_input_grad[0]:
-                g = grp.dx(g, params[0], xact=None)
+                g = linear_bwd_input_raw(g, params[0], xact=None)
             else:
                 g = None
-            grp.launch()
+        dwg.launch()
         return (g, None) + tuple(grads)
 
 
@@ -526,6 +524,8 @@ class _StacksPacked(torch.autograd.Function):
             params.append(saved[pos:pos + 2 * n + 4])
             pos += 2 * n + 4
         g = [_c2d(x) for x in gs]
+        dwg = GemmGroup()   # the weight gradients of every layer of every stack: off the dependency chain, ONE grouped launch (six
+        #                     problems per launch) behind the input-gradient chain - the reductions of their batch splits overlap
         for lvl in range(max(spec) + 1):   # level 0 = the heads, level j = trunk layer n - j
             grp = GemmGroup()
             for s, n in enumerate(spec):
@@ -534,13 +534,15 @@ class _StacksPacked(torch.autograd.Function):
                     Wa, ba, Wb, bb = P[2 * n:2 * n + 4]
                     dWa, dba, dWb, dbb = D[2 * n:2 * n + 4]
                     h = acts[s][n]
-                    grp.dw(g[s], h, _cat2(dWa, dWb), _cat2(dba, dbb))
+                    dwg.dw(g[s], h, _cat2(dWa, dWb), _cat2(dba, dbb))
                     g[s] = grp.dx(g[s], _cat2(Wa, Wb), xact=h if n > 0 else None) if (n > 0 or need_x) else None
                 elif lvl <= n:
                     i = n - lvl
-                    grp.dw(g[s], acts[s][i], D[2 * i], D[2 * i + 1])
+                    dwg.dw(g[s], acts[s][i], D[2 * i], D[2 * i + 1])
                     g[s] = grp.dx(g[s], P[2 * i], xact=acts[s][i] if i > 0 else None) if (i > 0 or need_x) else None
-            grp.launch()
+            if grp.descs:
+                grp.launch()
+        dwg.launch()
         return (None,) + tuple(g) + (None,) * (len(saved) - sum(n + 1 for n in spec))
 
 
@@ -653,27 +655,29 @@ class _MLPInto(torch.autograd.Function):
         acts, params = saved[:n], saved[n:]
         g = _c2d(g)[:, ctx.col0:ctx.col0 + ctx.width]
         grads = [None] * (2 * n)
-        for i in range(n - 1, -1, -1):   # a layer's weight- and input-gradient are independent: one grouped launch
+        dwg = GemmGroup()   # the weight gradients are off the dependency chain: ONE grouped launch behind the input-gradient chain
+        for i in range(n - 1, -1, -1):
             W, b = params[2 * i], params[2 * i + 1]
-            grp = GemmGroup()
             if ctx.needs_input_grad[4 + 2 * i] or ctx.needs_input_grad[5 + 2 * i]:
                 dW, db = ctx.direct[2 * i], ctx.direct[2 * i + 1]
                 if dW is None or db is None:
                     dW, db = torch.zeros_like(W), torch.zeros_like(b)
                     grads[2 * i], grads[2 * i + 1] = dW, db
-                grp.dw(g, acts[i], dW, db)
+                dwg.dw(g, acts[i], dW, db)
             if i > 0:
-                g = grp.dx(g, W, xact=acts[i])
+                g = linear_bwd_input_raw(g, W, xact=acts[i])
             elif ctx.needs_input_grad[0]:
                 if ctx.grad_cols is not None and ctx.grad_cols < W.shape[1]:
                     full = torch.empty(g.shape[0], W.shape[1], dtype=F32, device=g.device)
+                    grp = GemmGroup()
                     grp.dx(g, W, xact=None, out=full[:, :ctx.grad_cols], cols=ctx.grad_cols)
+                    grp.launch()
                     g = full
                 else:
-                    g = grp.dx(g, W, xact=None)
+                    g = linear_bwd_input_raw(g, W, xact=None)
             else:
                 g = None
-            grp.launch()
+        dwg.launch()
         return (g, None, None, None) + tuple(grads)
 
 

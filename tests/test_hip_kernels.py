@@ -217,12 +217,11 @@ def test_grouped_launch_equals_single_launches(ops):
         _hip.check(_hip.lib().pcvae_linear_group((_hip.GemmDesc * 7)(), 7, None, 0, None), "linear_group")
 
 
-def test_deterministic_weight_gradient_is_bitwise_reproducible(ops, monkeypatch):
-    """PCVAE_DETERMINISTIC=1: the batch splits of a weight gradient meet in the group's scratch buffer and are summed in split order
-    by the last workgroup to arrive: run-to-run BITWISE equal (the default's fp32 atomics are not), equal to fp64 at fp32 accuracy,
-    accumulating into what the buffers held, counters left zero (a second, differently shaped launch in between)."""
+def test_weight_gradient_is_bitwise_reproducible(ops):
+    """the batch splits of a weight gradient meet in the group's scratch buffer and are summed in split order by the last workgroup
+    to arrive: run-to-run BITWISE equal, equal to fp64 at fp32 accuracy, accumulating into what the buffers held, counters left
+    zero (a second, differently shaped launch in between); the single-layer C entry point (one split, no scratch) agrees."""
     from pivotcvae_amd import _hip
-    monkeypatch.setenv("PCVAE_DETERMINISTIC", "1")
     M, N, K = 8192, 256, 1419
     g, x = rnd(M, N, seed=1).to(DEV), rnd(M, K, seed=2).to(DEV)
     ref = (g.double().cpu().t() @ x.double().cpu())
@@ -238,11 +237,27 @@ def test_deterministic_weight_gradient_is_bitwise_reproducible(ops, monkeypatch)
         assert torch.equal(dW, outs[0][0]) and torch.equal(db, outs[0][1])
     torch.testing.assert_close(outs[0][0].cpu(), (ref + 0.5).float(), rtol=1e-4, atol=5e-4)
     torch.testing.assert_close(outs[0][1].cpu(), (g.double().cpu().sum(0) - 1.0).float(), rtol=1e-4, atol=5e-4)
-    # the default (atomics, many splits) agrees to rounding
-    monkeypatch.delenv("PCVAE_DETERMINISTIC")
+    # the single-layer C entry point (no scratch buffer: one batch split) agrees to rounding
     dA, bA = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
-    ops.linear_bwd_weight_raw(g, x, dA, bA)
-    torch.testing.assert_close(dA, outs[0][0] - 0.5, rtol=1e-5, atol=2e-4)
+    _hip.check(_hip.lib().pcvae_linear_bwd_weight(_hip.ptr(g), N, _hip.ptr(x), K, _hip.ptr(dA), K, _hip.ptr(bA), M, N, K, _hip.stream()),
+               "linear_bwd_weight")
+    torch.testing.assert_close(dA, outs[0][0] - 0.5, rtol=1e-5, atol=5e-4)   # 8192-term fp32 sums in two different orders
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 64, 64), (256, 256, 1408), (300, 256, 1419), (129, 1152, 283), (1000, 48, 283)])
+def test_weight_gradient_many_batch_splits_repeated(ops, M, N, K):
+    """Batch splits of one output tile run on different XCDs.  Combined with fp32 atomicAdd they lost updates line by line (a whole
+    split's contribution missing in a few percent of the elements, launch after launch, with hipMemset or a fill kernel in front:
+    tools/atomic_tile_probe.hip shows the same without any of our kernels); ten launches each, against fp64, zeroed by a fill kernel
+    immediately before - the situation that failed."""
+    g, x = rnd(M, N, seed=3), rnd(M, K, seed=4)
+    gd, xd = g.to(DEV), x.to(DEV)
+    want_W, want_b = (g.double().t() @ x.double()).float(), g.double().sum(0).float()
+    for _ in range(10):
+        dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+        ops.linear_bwd_weight_raw(gd, xd, dW, db)
+        torch.testing.assert_close(dW.cpu(), want_W, rtol=1e-4, atol=2e-4 * max(1.0, (M / 64.0) ** 0.5))
+        torch.testing.assert_close(db.cpu(), want_b, rtol=1e-4, atol=2e-4 * max(1.0, (M / 64.0) ** 0.5))
 
 
 def test_linear_random_ragged_shapes(ops):
