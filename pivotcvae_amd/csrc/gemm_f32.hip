@@ -461,7 +461,9 @@ __device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int b
 // runs, equal shares of every problem on every XCD, the first (largest) problem dispatched first.
 // (Two instantiations - a launch is all 64 x 64 DMA tiles or all small tiles - so that the DMA body's ~110 registers, not
 // the register-staged small body's 150, set the occupancy of the launches that matter.)
-template <bool SMALL>
+// (... and launches without a weight gradient - every forward and input-gradient launch - take an instantiation without that body:
+// its split reduction holds 64 more registers, the difference between five and four workgroups per CU.)
+template <bool SMALL, bool HAS_DW>
 __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int xcd = blockIdx.x & 7;
@@ -478,11 +480,9 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
         if (p.kind == KIND_FWD_S) gemm_tile_small<true, true, EPI_FWD>(p, bx, by, smem);
         else gemm_tile_small<true, false, EPI_DX>(p, bx, by, smem);
     } else {
-        switch (p.kind) {
-            case KIND_FWD: gemm_tile_dma<true, true, EPI_FWD>(p, bx, by, bz, smem); break;
-            case KIND_DX: gemm_tile_dma<true, false, EPI_DX>(p, bx, by, bz, smem); break;
-            default: gemm_tile_dma<false, false, EPI_DW>(p, bx, by, bz, smem); break;
-        }
+        if (p.kind == KIND_FWD) gemm_tile_dma<true, true, EPI_FWD>(p, bx, by, bz, smem);
+        else if (p.kind == KIND_DX || !HAS_DW) gemm_tile_dma<true, false, EPI_DX>(p, bx, by, bz, smem);
+        else gemm_tile_dma<false, false, EPI_DW>(p, bx, by, bz, smem);
     }
 }
 
@@ -623,9 +623,13 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     if (gp.n == 0) return PCVAE_OK;
     PCVAE_REQUIRE(total * 8 < (1LL << 31), "linear_group: launch too large");
     if (small)
-        hipLaunchKernelGGL(gemm_group_kernel<true>, dim3((unsigned)(total * 8)), dim3(256), SMALL_LDS, as_stream(stream), gp);
+        hipLaunchKernelGGL((gemm_group_kernel<true, false>), dim3((unsigned)(total * 8)), dim3(256), SMALL_LDS, as_stream(stream), gp);
+    else if (has_dw)
+        hipLaunchKernelGGL((gemm_group_kernel<false, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+                           as_stream(stream), gp);
     else
-        hipLaunchKernelGGL(gemm_group_kernel<false>, dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES, as_stream(stream), gp);
+        hipLaunchKernelGGL((gemm_group_kernel<false, false>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+                           as_stream(stream), gp);
     return check_launch("linear_group");
 }
 
