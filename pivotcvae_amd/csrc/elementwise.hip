@@ -1129,8 +1129,9 @@ extern "C" int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, 
 // =============================================================================================
 // Training the click model (reference pretrain_env.py:25-139): the pieces the forward-only evaluation path did not need.
 // =============================================================================================
-// embedding backward: dtable[idx[i], :] += g_row(i), g laid out like the output of pcvae_gather_rows.  fp32 atomics: rows
-// that occur several times in a batch are summed in arrival order (the reference's index_add on the GPU is unordered too).
+// embedding backward: dtable[idx[i], :] += g_row(i), g laid out like the output of pcvae_gather_rows.  Rows that occur several
+// times in a batch are summed in arrival order (the reference's index_add on the GPU is unordered too) by a compare-and-swap loop
+// (common.h: atomic_add_f32 - the plain fp32 atomicAdd loses updates between XCDs).
 __global__ void __launch_bounds__(256) scatter_add_rows_kernel(const float* __restrict__ g, int64_t g_ld, int group, int D,
                                                                const int64_t* __restrict__ idx, int64_t n_idx,
                                                                float* __restrict__ dtable) {
