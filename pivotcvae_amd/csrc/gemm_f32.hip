@@ -266,7 +266,10 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             float* all = p.ws_part + (int64_t)tile * p.nz * 4096 + tid;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            constexpr int RB = 4;   // splits requested together: 64 loads in flight per thread instead of 16
+#ifndef PCVAE_GEMM_RB
+#define PCVAE_GEMM_RB 4
+#endif
+            constexpr int RB = PCVAE_GEMM_RB;   // splits requested together: 64 loads in flight per thread instead of 16
             for (int z0 = 0; z0 < p.nz; z0 += RB) {   // fixed order: bitwise reproducible
                 float v[RB][16];
 #pragma unroll
