@@ -321,6 +321,13 @@ int pcvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                        float eps, int step, float grad_scale, float weight_decay, pcvae_stream_t stream);
 
+/* optimizer.zero_grad() (train_generative.py:124) as a memset on the stream: the flat gradient buffer (+ its statistics tail) */
+int pcvae_zero(void* p, size_t nbytes, pcvae_stream_t stream);
+
+/* the logged ELBO terms of a step (train_generative.py:62-63, :128): out[0..2] = (rec + beta * kld, rec, kld).  A data-parallel
+ * rank writes the record into the tail of its gradient buffer: ONE all-reduce sums gradients and statistics.                  */
+int pcvae_elbo_pack(const float* rec, const float* kld, float beta, float* out, pcvae_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training the click model                       pretrain_env.py:25-139 ; env/response_model.py:76-87
  *   scatter_add_rows    : nn.Embedding backward, dtable[idx[i], :] += g_row(i)  (g laid out like gather_rows' output)

@@ -330,10 +330,12 @@ __device__ unsigned int g_kld_done = 0;
 __device__ __forceinline__ void kld_combine(const float t, float* __restrict__ out) {
     __shared__ bool last;
     // device-scope (sc1) store / loads of the partials instead of __threadfence(): a device-scope fence writes back and invalidates
-    // the whole L2 of the XCD, once per block - 10 of this kernel's 16 us at config 4.  The workgroup-scope release is the
-    // s_waitcnt that holds the arrival count back until the store is acknowledged at the memory side.
+    // the whole L2 of the XCD, once per block - 10 of this kernel's 16 us at config 4.  The explicit s_waitcnt vmcnt(0) holds the
+    // arrival count back until the store is acknowledged at the memory side (a workgroup-scope release emits no such wait on
+    // gfx950: without it the last block could read the partial of a previous call).
     if (threadIdx.x == 0) {
         __hip_atomic_store(&g_kld_partial[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         last = atomicAdd(&g_kld_done, 1u) == gridDim.x - 1;
     }
@@ -692,6 +694,32 @@ extern "C" int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcv
     PCVAE_REQUIRE(x && out && n >= 0, "sum: bad arguments");
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, as_stream(stream), x, n, scale, out);
     return check_launch("sum");
+}
+
+// the logged ELBO terms of one step as one 3-float record: out = (rec + beta * kld, rec, kld).  A data-parallel rank writes its
+// record into the tail of the flat gradient buffer, so the gradient all-reduce sums the statistics too (train_generative.py:62).
+__global__ void elbo_pack_kernel(const float* __restrict__ rec, const float* __restrict__ kld, float beta, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        const float r = rec[0], k = kld[0];
+        out[0] = r + beta * k;
+        out[1] = r;
+        out[2] = k;
+    }
+}
+
+extern "C" int pcvae_elbo_pack(const float* rec, const float* kld, float beta, float* out, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(rec && kld && out, "elbo_pack: bad arguments");
+    hipLaunchKernelGGL(elbo_pack_kernel, dim3(1), dim3(64), 0, as_stream(stream), rec, kld, beta, out);
+    return check_launch("elbo_pack");
+}
+
+// zero a buffer on the stream (optimizer.zero_grad(), train_generative.py:124): a memset node, not a fill kernel
+extern "C" int pcvae_zero(void* p, size_t nbytes, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(p || nbytes == 0, "zero: bad arguments");
+    if (nbytes == 0) return PCVAE_OK;
+    const hipError_t e = hipMemsetAsync(p, 0, nbytes, as_stream(stream));
+    if (e != hipSuccess) { set_error("zero: %s", hipGetErrorString(e)); return PCVAE_ELAUNCH; }
+    return PCVAE_OK;
 }
 
 // =============================================================================================

@@ -242,8 +242,9 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
         // in split order and adds the sum to C: one writer per element, bitwise reproducible.  One split (no workspace): plain
         // read-modify-write.
         //   * partials travel with device-scope (sc1) stores / loads: written through to, and read from, the memory side.  NOT a
-        //     device-scope fence: that writes back and invalidates the whole L2 per workgroup (measured: +80 us per launch).  The
-        //     workgroup-scope release is the s_waitcnt that holds the arrival back until the stores are acknowledged.
+        //     device-scope fence: that writes back and invalidates the whole L2 per workgroup (measured: +80 us per launch).  An
+        //     explicit s_waitcnt vmcnt(0) in every thread, in front of the barrier that precedes the arrival, holds the arrival
+        //     back until the stores are acknowledged.
         //   * the last workgroup requests RB splits together (the first version walked them one by one: +12 .. 45 us per launch).
         const int tile = by * p.nx + bx, tid = threadIdx.x;
         if (p.nz > 1) {
@@ -252,6 +253,11 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             for (int r = 0; r < 16; ++r) __hip_atomic_store(&part[r * 256 + tid], acc[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (do_bias)
                 __hip_atomic_store(&p.ws_bias[((int64_t)by * p.nz + bz) * 64 + tid], bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // EVERY thread holds here until its own sc1 stores are acknowledged by the memory side; only then may the barrier be
+            // passed and the arrival be counted.  The workgroup-scope release alone does NOT do that on gfx950 (outside tgsplit
+            // mode it emits no vmcnt wait: the ISA had the stores, s_barrier and the global_atomic_add back to back, so the last
+            // workgroup of another XCD could read a stale partial).  tools/isa_loop_check.py asserts the wait is in the ISA.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             int* s_last = reinterpret_cast<int*>(smem);

@@ -682,6 +682,10 @@ class _MLPInto(torch.autograd.Function):
 
 
 def mlp_into(x, layers, out_buf, col0, grad_cols=None):
+    if grad_cols is not None and x.requires_grad and type(x.grad_fn).__name__ != "_LatentPackedBackward":
+        # the columns behind grad_cols of the returned input gradient are UNWRITTEN memory; only latent_packed (which reads the
+        # first Z columns and nothing else) may be the producer of x
+        raise RuntimeError("mlp_into(grad_cols=...): x must come straight from ops.latent_packed")
     flat = []
     for W, b in layers:
         flat += [W, b]
@@ -1045,10 +1049,22 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     return nll, lse, dx
 
 
+_unit_seeds = set()   # data_ptr of the tensors a Trainer seeds backward with (value exactly 1)
+
+
+def register_unit_seed(t):
+    """``t``: a 0-d device tensor holding exactly 1.0 that the caller will pass as the upstream gradient of a ``unit_upstream`` loss
+    (Trainer does).  Only then does backward hand the saved direction on without a scaling launch; any other upstream gradient
+    (a scaled loss, accumulation with loss / k) is applied."""
+    _unit_seeds.add(t.data_ptr())
+    return t
+
+
 class _CatalogCE(torch.autograd.Function):
     """mean-reduced (times ``inv_count``) full-catalog softmax CE; backward = saved direction * upstream.
-    ``unit_upstream``: the caller promises to seed the backward of this loss with exactly 1 (Trainer does: it seeds (rec, KLD) with
-    (1, beta)); the kernel then writes the direction times inv_count and backward hands it on without a scaling launch."""
+    ``unit_upstream``: the caller intends to seed the backward of this loss with a constant 1 registered through
+    ``register_unit_seed`` (Trainer does: it seeds (rec, KLD) with (1, beta)); the kernel then writes the direction times inv_count
+    and backward hands it on without a scaling launch.  Any other upstream gradient is still applied correctly (one launch)."""
 
     @staticmethod
     def forward(ctx, rx, table, target, keep_prob, seed, row_offset, keep_mask, prec, inv_count, unit_upstream):
@@ -1066,12 +1082,13 @@ class _CatalogCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
-        if ctx.unit:
+        if ctx.unit and g.data_ptr() in _unit_seeds:   # the registered constant 1: the kernel already wrote dx * inv_count
             return (dx,) + (None,) * 9
         g = g.contiguous()
         out = torch.empty_like(dx)
+        # unit_upstream but some OTHER upstream gradient: dx is pre-scaled by inv_count, only g is left to apply
         check(lib().pcvae_scale_rows(ptr(dx, F32), _ld(dx), ptr(out, F32), _ld(out), dx.shape[0], dx.shape[1],
-                                     ptr(g, F32), ctx.inv_count, stream()), "scale_rows")
+                                     ptr(g, F32), 1.0 if ctx.unit else ctx.inv_count, stream()), "scale_rows")
         return (out,) + (None,) * 9
 
 
@@ -1301,6 +1318,22 @@ def dense_ce(p, target, inv_count=None):
     """nn.CrossEntropyLoss()(p, target) for a small dense [R, C] logits tensor.  ``inv_count`` replaces the 1/R of the mean
     (a data-parallel rank passes 1/(R_local * world_size))."""
     return _DenseCE.apply(p, target, (1.0 / p.shape[0]) if inv_count is None else inv_count)
+
+
+def elbo_pack_(rec, kld, beta, out):
+    """out[0..2] = (rec + beta * kld, rec, kld) - the logged terms of a step as one record (pcvae_elbo_pack)"""
+    require_device(rec, kld, out)
+    check(lib().pcvae_elbo_pack(ptr(rec, F32), ptr(kld, F32), float(beta), ptr(out, F32), stream()), "elbo_pack")
+    return out
+
+
+def zero_(t):
+    """t[...] = 0 as a memset on the current stream (optimizer.zero_grad())"""
+    require_device(t)
+    if not t.is_contiguous():
+        raise ValueError("zero_: contiguous tensor expected")
+    check(lib().pcvae_zero(ptr(t), t.numel() * t.element_size(), stream()), "zero")
+    return t
 
 
 # ------------------------------------------------------------------------------------------- K8

@@ -61,7 +61,10 @@ class FlatAdam:
         self.t = 0
 
     def zero_grad(self):
-        self.grad_ext.zero_()
+        if self.grad_ext.is_cuda:
+            ops.zero_(self.grad_ext)   # one memset node on the stream (gradients + the statistics tail)
+        else:
+            self.grad_ext.zero_()      # the CPU tests' optimiser (collective logic only)
         for p, g in zip(self.params, self._grad_views()):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g  # someone set it to None / replaced it: re-attach the flat view

@@ -112,13 +112,19 @@ class Trainer:
     """
 
     def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None,
-                 capture_graph=False):
+                 capture_graph=False, world_size=None, rank=0):
         import torch.distributed as dist
         self.model, self.beta, self.n_neg = model, float(beta), n_neg
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
         self.rank = self.dist.get_rank(process_group) if self.dist else 0
+        # ``world_size`` WITHOUT an initialised process group: this object plays rank ``rank`` of ``world_size`` and the caller does
+        # the reduction between local_phase() and finish_phase() (sum the ranks' ``opt.grad_ext`` buffers - what all_reduce(SUM)
+        # leaves in every rank's buffer).  tests/test_hip_data_parallel.py runs W simulated ranks on ONE GPU this way.
+        self.external_reduce = False
+        if world_size is not None and self.dist is None:
+            self.world, self.rank, self.external_reduce = int(world_size), int(rank), int(world_size) > 1
         self.opt = optimizer if optimizer is not None else FlatAdam(model, lr)
         self._own_loss = loss_fn is None
         self.loss_fn = loss_fn or (lambda m, s, r, u, **kw: m.loss(s, r, u, **kw))
@@ -134,6 +140,8 @@ class Trainer:
             getattr(model, "TRAIN_RULE", "gt") in ("gt", "pt")
         self._graph = None
         self._static = None
+        self._stats, self._in_tail = None, False
+        self.capture_failed = None   # the reason, if hipGraph capture was asked for and fell back to eager launches
 
     def shard(self, *tensors):
         """Contiguous shard of a global batch for this rank (+ its offset in the global batch)."""
@@ -158,7 +166,7 @@ class Trainer:
             # d(rec + beta KLD) = 1 d rec + beta d KLD: seeding backward with the two constants saves the mul / add / fill / mul
             # launches of forming the sum and differentiating it (the logged loss is formed in step(), one launch)
             if self._seed is None:
-                self._seed = (torch.ones((), dtype=torch.float32, device=s.device),
+                self._seed = (ops.register_unit_seed(torch.ones((), dtype=torch.float32, device=s.device)),
                               torch.full((), float(self.beta), dtype=torch.float32, device=s.device), float(self.beta))
             elif self._seed[2] != float(self.beta):   # beta changed (annealing): in place, a captured graph keeps the address
                 self._seed[1].fill_(float(self.beta))
@@ -195,9 +203,10 @@ class Trainer:
             st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
         self._graph, self._static = graph, st
 
-    def step(self, s, r, u, eps=None, global_batch=None, row_offset=0):
-        """s, r, u: THIS rank's shard.  Returns (loss, recLoss, KLD) as device scalars of the GLOBAL batch
-        (after a 3-float all-reduce when world_size > 1); nothing is synchronised with the host."""
+    def local_phase(self, s, r, u, eps=None, global_batch=None, row_offset=0):
+        """Phase 1 of a step - everything a rank does on its own: zero-grad, local loss (reconstruction term scaled by
+        1 / (B_local S world), eps / mask / sampler streams at GLOBAL slate indices), backward into the flat gradient buffer, and
+        the rank's (loss, rec, KLD) record written behind the gradients (``opt.tail``)."""
         B, S = s.shape
         W = self.world
         gb = global_batch if global_batch is not None else B * W
@@ -207,11 +216,12 @@ class Trainer:
             if self._graph is None:
                 try:
                     self._capture(s, r, u, row_offset)
-                except Exception as e:  # capture is an optimisation: fall back to eager launches
+                except Exception as e:  # capture is an optimisation: fall back to eager launches, and say so
                     import warnings
                     warnings.warn(f"hipGraph capture failed ({e}); running eagerly")
                     torch.cuda.synchronize()
                     self.capture_graph, self._graph = False, None
+                    self.capture_failed = str(e)
         if self.capture_graph and self._graph is not None and tuple(s.shape) == tuple(self._static["s"].shape) \
                 and row_offset == self._static["row_offset"]:
             st = self._static
@@ -226,24 +236,49 @@ class Trainer:
             loss, rec, kld = st["out"]
         else:
             loss, rec, kld = self._local(s, r, u, eps, row_offset, eps_offset)
-        if self.dist is not None:  # also with a 1-rank group: the collective path is then the one that is exercised
-            terms = [rec, kld] if loss is None else [loss, rec, kld]
-            tail = getattr(self.opt, "tail", None)
-            if tail is not None and tail.numel() >= len(terms):
-                # ONE collective per step: the logged scalars ride in the tail of the flat gradient buffer
-                torch.stack(terms, out=tail[:len(terms)])
-                self.dist.all_reduce(self.opt.grad_ext, group=self.pg)  # SUM
-                stats = tail[:len(terms)].clone()   # the tail is zeroed with the gradients at the next step
-            else:   # an optimiser without the tail: gradients, then the scalars
-                self.dist.all_reduce(self.opt.grad, group=self.pg)
-                stats = torch.stack(terms)
-                self.dist.all_reduce(stats, group=self.pg)
-            loss, rec, kld = (None, stats[0], stats[1]) if loss is None else (stats[0], stats[1], stats[2])
-        if loss is None:
-            loss = torch.add(rec, kld, alpha=float(self.beta))
+        tail = getattr(self.opt, "tail", None)
+        self._stats, self._in_tail = None, False
+        host_record = lambda: torch.stack([torch.add(rec, kld, alpha=float(self.beta)) if loss is None else loss, rec, kld])
+        if (self.world > 1 or self.dist is not None) and tail is not None and tail.numel() >= 3:
+            # (rec + beta KLD, rec, KLD) as ONE record behind the gradients: the gradient all-reduce sums the statistics with them -
+            # a second, latency-bound collective for three floats would cost as much as the first
+            if rec.is_cuda:
+                ops.elbo_pack_(rec, kld, self.beta, tail)
+            else:   # the CPU tests' injected compute (collective logic only)
+                tail[:3].copy_(host_record())
+            self._in_tail = True
+        elif rec.is_cuda:
+            self._stats = ops.elbo_pack_(rec, kld, self.beta, torch.empty(3, dtype=torch.float32, device=rec.device))
+        else:
+            self._stats = host_record()
+
+    def reduce_phase(self):
+        """Phase 2: ONE all_reduce(SUM) over gradients + statistics (RCCL over xGMI on the GPUs).  Also with a 1-rank group: the
+        collective path is then the one that is exercised.  Simulated ranks (``external_reduce``): the caller sums the buffers."""
+        if self.dist is None:
+            return
+        if self._in_tail:
+            self.dist.all_reduce(self.opt.grad_ext, group=self.pg)
+        else:
+            self.dist.all_reduce(self.opt.grad, group=self.pg)
+            self.dist.all_reduce(self._stats, group=self.pg)
+
+    def finish_phase(self):
+        """Phase 3: identical Adam on every rank.  -> (loss, recLoss, KLD) of the GLOBAL batch as device scalars."""
+        stats = self.opt.tail[:3].clone() if self._in_tail else self._stats   # the tail is zeroed with the gradients
         self.opt.step()
         self.global_step += 1
-        return loss, rec, kld
+        return stats[0], stats[1], stats[2]
+
+    def step(self, s, r, u, eps=None, global_batch=None, row_offset=0):
+        """s, r, u: THIS rank's shard.  Returns (loss, recLoss, KLD) as device scalars of the GLOBAL batch; nothing is
+        synchronised with the host."""
+        if self.external_reduce:
+            raise RuntimeError("this Trainer plays one of several simulated ranks: call local_phase(), sum the ranks' "
+                               "opt.grad_ext yourself, then finish_phase()")
+        self.local_phase(s, r, u, eps, global_batch, row_offset)
+        self.reduce_phase()
+        return self.finish_phase()
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -343,6 +378,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
             if m.candidateFlag:
                 return candidate_loss(m, s, r, u, beta, n_cand, seed=0x5641, row_offset=row_offset)
             return m.loss(s, r, u, beta, n_neg=None if n_cand >= N else n_cand, mask_seed=0x5641, row_offset=row_offset)
+    run_eval = eval_fn is not None or resp_model is not None   # neither given: the recommendation test is skipped
     if eval_fn is None:
         eval_fn = lambda m: recommendation_test(m, resp_model, bs, n_test_trial=n_test_trial, seed=seed)
 
@@ -386,7 +422,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
         log("validation Loss: " + str(v_loss) + " = " + str(v_rec) + " + " + str(beta) + " * " + str(v_kld))
 
         # recommendation test
-        if resp_model is not None or eval_fn is not None:
+        if run_eval:
             stats = eval_fn(model)
             if stats is not None:
                 stats = stats.detach().cpu()

@@ -277,6 +277,130 @@ def make_case(name, model, S, D, Z, N, NU, B, H, HP, no_user, seed, beta=0.001, 
     print(f"{name}: {len(out)} arrays, none_grads={len(none_grads)}")
 
 
+def make_stated_case(name, model, S, D, Z, N, NU, B, H, HP, seed, beta=0.001, lr=3e-4, n_neg_part=None):
+    """Round 3: the reference at a BASELINE config's STATED size (configs 1 and 2 of SURVEY.md 8d) and one D = 128 case - the
+    width that takes the MFMA bf16 / bf16x3 catalog kernels and the fused train path.  Same recipe as make_case but without the
+    dense [R, N] logits: raw tables, state, inputs, recorded eps, the three loss terms at n_neg = N, every .grad, the trained
+    parameters after 1 and 3 Adam steps, recommend() ids + pivots + top-2 margins (train_generative.py:44-65, 103, 124-134;
+    models/pivotcvae.py:242-296; models/listcvae.py:134-188).  A recorded Bernoulli mask (n_neg < N) only where it is small."""
+    torch.manual_seed(seed)
+    a = (2.0 / D) ** 0.5
+    raw_doc = torch.nn.Embedding(N, D)
+    raw_doc.weight.data.uniform_(-a, a)
+    raw_user = torch.nn.Embedding(NU, D)
+    raw_user.weight.data.uniform_(-a, a)
+    st = structs(model, S, D, Z, H, HP, False)
+    m = build(model, st, raw_doc, raw_user, S, D, Z, False)
+    g = torch.Generator().manual_seed(seed + 1000)
+    s = torch.randint(0, N, (B, S), generator=g)
+    u = torch.randint(0, NU, (B, 1), generator=g)
+    r = (torch.rand(B, S, generator=g) < 0.5).float()
+    r[0] = 0.0
+    r[-1] = 1.0
+    frozen = ("docEmbed.weight", "userEmbed.weight")
+    out = {"raw_doc": raw_doc.weight.detach().numpy().copy(), "raw_user": raw_user.weight.detach().numpy().copy()}
+    for k, v in m.state_dict().items():
+        out["sd/" + k] = v.detach().numpy().copy()
+    out["s"], out["r"], out["u"] = s.numpy(), r.numpy(), u.numpy()
+    batch = {"slates": s.numpy(), "users": u.numpy(), "responses": r.numpy()}
+    CEL = torch.nn.CrossEntropyLoss()
+
+    # forward pieces that are small: z_mu / z_logvar / rx / prior (the dense p is NOT kept)
+    torch.manual_seed(seed + 1)
+    with Recorder() as rec, torch.no_grad():
+        _p, rx, z, _emb, z_mu, z_logvar = m.forward(s, r, u=u)
+        pMu, pLogvar = m.get_prior(r, u)
+    out["fwd/eps"] = rec.eps[0].numpy()
+    for k, v in dict(rx=rx, z=z, z_mu=z_mu, z_logvar=z_logvar, pMu=pMu, pLogvar=pLogvar).items():
+        out["fwd/" + k] = v.numpy().copy()
+    del _p
+
+    # loss + gradients, full-catalog softmax
+    torch.manual_seed(seed + 2)
+    m.zero_grad()
+    with Recorder() as rec:
+        loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m, CEL, beta, n_neg=N)
+        loss.backward()
+    out["full/eps"] = rec.eps[0].numpy()
+    out["full/loss"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+    none_grads = []
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            none_grads.append(k)
+        else:
+            out["grad/" + k] = prm.grad.detach().numpy().copy()
+
+    # the reference's masked mode with the draw recorded, where [R, N] is small enough to keep
+    if n_neg_part and B * S * N <= 2_000_000:
+        torch.manual_seed(seed + 3)
+        m.zero_grad()
+        with Recorder() as rec:
+            loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m, CEL, beta, n_neg=n_neg_part)
+            loss.backward()
+        out["part/eps"] = rec.eps[0].numpy()
+        out["part/neg_sample"] = rec.masks[0].numpy().astype(np.uint8)
+        out["part/loss"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+        for k, prm in m.named_parameters():
+            if prm.grad is not None:
+                out["part/grad/" + k] = prm.grad.detach().numpy().copy()
+
+    # three Adam steps
+    m2 = build(model, st, raw_doc, raw_user, S, D, Z, False)
+    m2.load_state_dict(m.state_dict())
+    opt = torch.optim.Adam(m2.parameters(), lr=lr)
+    torch.manual_seed(seed + 4)
+    for step in range(3):
+        opt.zero_grad()
+        with Recorder() as rec:
+            loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m2, CEL, beta, n_neg=N)
+        loss.backward()
+        opt.step()
+        out[f"adam/eps{step}"] = rec.eps[0].numpy()
+        out[f"adam/loss{step}"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+        if step in (0, 2):
+            for k, v in m2.state_dict().items():
+                if k not in frozen and k not in none_grads:   # frozen tables and the PSM stack are bit-unchanged (asserted below)
+                    out[f"adam/step{step + 1}/" + k] = v.detach().numpy().copy()
+    for k, v in m2.state_dict().items():
+        if k in frozen or k in none_grads:
+            assert torch.equal(v, m.state_dict()[k]), k
+
+    # recommend
+    ctx = torch.zeros(B, S)
+    ctx[:, : min(3, S)] = 1.0
+    ctx[0] = 0.0
+    pivots = []
+    hook = m.docEmbed.register_forward_hook(lambda mod, inp, o: pivots.append(inp[0].detach().clone()))
+    torch.manual_seed(seed + 5)
+    with Recorder() as rec, torch.no_grad():
+        items, rec_mu = m.recommend(ctx, u, return_item=True)
+    hook.remove()
+    out["rec/r"], out["rec/eps"], out["rec/items"], out["rec/z_mu"] = ctx.numpy(), rec.eps[0].numpy(), items.numpy(), rec_mu.numpy()
+    torch.manual_seed(seed + 5)
+    with torch.no_grad():
+        rx_rec, _ = m.recommend(ctx, u, return_item=False)
+        E = m.docEmbed.weight
+        out["rec/rx"] = rx_rec.numpy().copy()
+        out["rec/item_margin"] = top2_margin(rx_rec.reshape(-1, D) @ E.t())
+    if model != "listcvae":
+        out["rec/pivot"] = pivots[0].numpy()
+
+    meta = dict(name=name, model=model, S=S, D=D, Z=Z, N=N, NU=NU, B=B, no_user=False, beta=beta, lr=lr,
+                n_neg_part=n_neg_part, structs=st, none_grads=none_grads, seed=seed, torch=torch.__version__)
+    out["meta"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.1f} MB, loss {out['full/loss']}")
+
+
+def make_stated():
+    """round 3: configs 1 and 2 at their stated sizes + the D = 128 case"""
+    make_stated_case("stated_config1_listcvae", "listcvae", S=5, D=16, Z=16, N=1000, NU=100, B=64, H=256, HP=128, seed=801,
+                     n_neg_part=100)
+    make_stated_case("stated_config2_gt_pi", "pivotcvae_gt_pi", S=5, D=32, Z=16, N=10000, NU=200, B=1024, H=256, HP=128, seed=802)
+    make_stated_case("stated_d128_gt_pi", "pivotcvae_gt_pi", S=10, D=128, Z=16, N=5003, NU=50, B=64, H=128, HP=64, seed=803)
+
+
 def make_response_model(name, N, NU, D, S, B, H, seed):
     """G7: UserResponseModel_MLP (env/response_model.py:46-87)."""
     torch.manual_seed(seed)
@@ -403,6 +527,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "response_analysis":
         make_analysis()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "stated":   # round 3 (every earlier case stays byte-identical)
+        make_stated()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "round2":   # G10 / G11 only (every earlier case stays byte-identical)
         make_urm("response_urm", N=203, NU=11, D=16, S=5, B=9, seed=601)
         make_candidates("candidate_sets", N=40, S=5, Cn=12, L=16, seed=701)
@@ -428,6 +555,7 @@ def main():
     make_analysis()
     make_urm("response_urm", N=203, NU=11, D=16, S=5, B=9, seed=601)
     make_candidates("candidate_sets", N=40, S=5, Cn=12, L=16, seed=701)
+    make_stated()
 
 
 if __name__ == "__main__":

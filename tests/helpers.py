@@ -38,7 +38,12 @@ class Golden:
 
 def model_cases():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
-    return [n for n in names if not n.startswith(("response_", "candidate_"))]
+    return [n for n in names if not n.startswith(("response_", "candidate_", "stated_"))]
+
+
+def stated_cases():
+    """goldens minted from the reference at a BASELINE config's STATED size (no dense logits inside): tests/test_*stated*"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "stated_*.npz")))
 
 
 def load(name):

@@ -1,0 +1,211 @@
+"""-m gpu: the data-parallel step ON THE HIP COMPUTE PATH with W simulated ranks on one GPU ("a multi-rank
+test that runs DP on 1 GPU with W simulated ranks (split batch, sum grads on host)").
+
+One replica plays every rank in turn: ``Trainer(world_size=W)`` runs the PRODUCT's ``local_phase`` on shard w exactly as
+``Trainer.step`` would on rank w (``row_offset`` = index of the shard's first slate, ``inv_count = 1 / (B_local S W)`` folded
+into the catalog merge kernels, ``eps_offset = (step B_global + row_offset) Z``, ``mask_seed = step``); the W flat gradient
+buffers (+ their statistics tails) are summed - exactly what ``all_reduce(SUM)`` leaves in every rank's buffer - and
+``finish_phase`` applies the one Adam step.  Replicas are identical before a step and apply the same update, so one replica
+playing all ranks IS the W-rank job.  Checked against the single-process step on the whole batch:
+
+  * ELBO terms (rtol 1e-6), every parameter gradient (<= 2e-5 of its tensor's scale), parameters after 1 and 3 steps;
+  * the in-kernel Philox streams - eps, the sparse kept set, candidate draws, sampled pivots - bitwise independent of W;
+  * the fused train path and the operator-by-operator path (FUSED_TRAIN_PATH = False) under sharding;
+  * once at config 4's STATED size with W = 8, B_local = 1024 (the driver's 8-GPU run, one rank at a time).
+
+Reference semantics preserved: /root/reference/train_generative.py:59-63 (recLoss is a MEAN over B S rows, KLD a SUM over B).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+Z, H, HP, NU = 16, 256, 128, 500
+
+
+def make_model(N, S, D, prec, seed=0, variant="pivotcvae_gt_pi"):
+    import pivotcvae_amd as pa
+    torch.manual_seed(seed)
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    a = (2.0 / D) ** 0.5
+    doc = torch.nn.Embedding(N, D, device=DEV)
+    doc.weight.data = (torch.rand(N, D, device=DEV, generator=gen) * 2 - 1) * a
+    usr = torch.nn.Embedding(NU, D, device=DEV)
+    usr.weight.data = (torch.rand(NU, D, device=DEV, generator=gen) * 2 - 1) * a
+    C = S + 1
+    m = pa.PIVOTCVAE_MODELS[variant](doc, usr, S, D, Z, C, [S * D + C + D, H, H], [Z + C + D, H, H, D],
+                                     [Z + C + 2 * D, H, H, (S - 1) * D], [C + D, HP, HP], False, DEV)
+    return m.set_catalog_precision(prec)
+
+
+def batch(N, S, B, seed=1):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    s = torch.randint(0, N, (B, S), device=DEV, generator=g)
+    u = torch.randint(0, NU, (B, 1), device=DEV, generator=g)
+    r = (torch.rand(B, S, device=DEV, generator=g) < 0.5).float()
+    return s, r, u
+
+
+def simulated_step(tr, W, s, r, u, eps=None):
+    """one global step of the W-rank job, this trainer playing every rank in turn -> ((loss, rec, kld), summed grads, eps used)"""
+    B = s.shape[0]
+    per = B // W
+    acc = torch.zeros_like(tr.opt.grad_ext)
+    eps_used = []
+    for w in range(W):
+        tr.rank = w
+        sl = slice(w * per, (w + 1) * per)
+        tr.local_phase(s[sl], r[sl], u[sl], None if eps is None else eps[sl], global_batch=B, row_offset=w * per)
+        acc += tr.opt.grad_ext              # all_reduce(SUM) over gradients + the statistics tail
+        eps_used.append(tr.model._last_eps.clone())
+    tr.opt.grad_ext.copy_(acc)
+    grads = tr.opt.grad.clone()
+    return tr.finish_phase(), grads, torch.cat(eps_used)
+
+
+def single_step(tr, s, r, u, eps=None):
+    tr.local_phase(s, r, u, eps)
+    grads = tr.opt.grad.clone()
+    eps_used = tr.model._last_eps.clone()
+    tr.reduce_phase()
+    return tr.finish_phase(), grads, eps_used
+
+
+def grads_close(tr, got, want, tol=2e-5):
+    """per parameter tensor: max |difference| <= tol * max |gradient| of that tensor"""
+    off = 0
+    for p in tr.opt.params:
+        n = p.numel()
+        a, b = got[off:off + n], want[off:off + n]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= tol * max(scale, 1e-30) + 1e-12, (tuple(p.shape), float((a - b).abs().max()), scale)
+        off += n
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("W", [2, 8])
+@pytest.mark.parametrize("fused", [True, False])
+def test_w_simulated_ranks_equal_the_single_process_step(W, prec, fused):
+    """mid-size D = 128 model (the width of the bf16x3 / MFMA kernels), full-catalog softmax, in-kernel Philox eps"""
+    from pivotcvae_amd.train_generative import Trainer
+    N, S, D, B = 20011, 10, 128, 512
+    s, r, u = batch(N, S, B)
+    runs = {}
+    for mode in ("single", "sharded"):
+        m = make_model(N, S, D, prec)
+        m.FUSED_TRAIN_PATH = fused
+        m.rng_seed = 4242
+        tr = Trainer(m, lr=3e-4, beta=0.001, world_size=W if mode == "sharded" else None)
+        assert tr.world == (W if mode == "sharded" else 1)
+        out = []
+        for _ in range(3):
+            st, g, e = simulated_step(tr, W, s, r, u) if mode == "sharded" else single_step(tr, s, r, u)
+            out.append(([float(x) for x in st], g, e, tr.opt.flat.clone()))
+        runs[mode] = (tr, out)
+    tr = runs["single"][0]
+    for k, ((st1, g1, e1, p1), (stW, gW, eW, pW)) in enumerate(zip(runs["single"][1], runs["sharded"][1])):
+        assert torch.equal(e1, eW), f"step {k}: eps depends on the world size"      # Philox at global slate indices: BITWISE
+        np.testing.assert_allclose(stW, st1, rtol=1e-6 if k == 0 else 2e-6)          # all-reduced ELBO terms == whole-batch terms
+        np.testing.assert_allclose(st1[0], st1[1] + 0.001 * st1[2], rtol=1e-6)
+        if k == 0:   # same parameters on both sides: the summed shard gradients ARE the whole-batch gradient
+            grads_close(tr, gW, g1)
+        # Adam's first steps move a weight by ~lr * sign(g): a gradient that changes sign at rounding level moves by up to 2 lr
+        diff = (pW - p1).abs()
+        assert float(diff.max()) <= 2.001 * 3e-4 * (k + 1)
+        assert float((diff > 3e-6).float().mean()) < 2e-3, f"step {k}: {float((diff > 3e-6).float().mean())}"
+    assert runs["single"][1][0][0] != runs["single"][1][1][0]   # the steps really differ (eps, parameters)
+
+
+@pytest.mark.parametrize("W", [2, 8])
+def test_masked_mode_and_sampled_pivots_under_sharding(W):
+    """the reference's default n_neg = 1000 (sparse kept-rows kernel, mask keyed by GLOBAL row) and a sampled-pivot rule (sgt:
+    Gumbel-max sampler keyed by GLOBAL slate index): the sharded job reproduces the single-process one"""
+    from pivotcvae_amd.train_generative import Trainer
+    N, S, D, B = 50021, 10, 128, 256
+    s, r, u = batch(N, S, B, seed=3)
+    for variant in ("pivotcvae_gt_pi", "pivotcvae_sgt_pi"):
+        res = {}
+        for mode in ("single", "sharded"):
+            m = make_model(N, S, D, "f32", variant=variant)
+            m.rng_seed = 99
+            tr = Trainer(m, lr=3e-4, beta=0.001, n_neg=1000, world_size=W if mode == "sharded" else None)
+            out = []
+            for _ in range(2):
+                st, g, e = simulated_step(tr, W, s, r, u) if mode == "sharded" else single_step(tr, s, r, u)
+                out.append(([float(x) for x in st], g, e))
+            res[mode] = (tr, out)
+        for k in range(2):
+            st1, g1, e1 = res["single"][1][k]
+            stW, gW, eW = res["sharded"][1][k]
+            assert torch.equal(e1, eW)
+            np.testing.assert_allclose(stW, st1, rtol=2e-6)
+            if k == 0:
+                grads_close(res["single"][0], gW, g1)
+
+
+def test_in_kernel_streams_are_bitwise_independent_of_the_sharding():
+    """each stream on its own, same inputs: a shard's draws == the corresponding rows of the whole batch's draws, bit for bit"""
+    from pivotcvae_amd import ops
+    N, S, D, B, W = 30011, 10, 128, 64, 8
+    per = B // W
+    s, r, u = batch(N, S, B, seed=5)
+    g = torch.Generator(device=DEV).manual_seed(6)
+    E = torch.nn.functional.normalize(torch.rand(N, D, device=DEV, generator=g) - 0.5, dim=1).contiguous()
+    rx = (torch.rand(B * S, D, device=DEV, generator=g) - 0.5) * 4
+    tgt = s.reshape(-1)
+    table = ops.CatalogTable(E)
+    # eps
+    full = ops.philox_normal_(torch.empty(B, Z, device=DEV), seed=7, offset=3 * B * Z)
+    parts = [ops.philox_normal_(torch.empty(per, Z, device=DEV), seed=7, offset=(3 * B + w * per) * Z) for w in range(W)]
+    assert torch.equal(full, torch.cat(parts))
+    # sparse kept set: per-row nll / lse / dx of the masked CE (one wave per row: bitwise a function of (seed, global row, rx row))
+    nll, lse, dx = ops.catalog_ce_sparse_raw(rx, table, tgt, 1000.0 / N, seed=11, row_offset=0)
+    for w in range(W):
+        sl = slice(w * per * S, (w + 1) * per * S)
+        a, b, c = ops.catalog_ce_sparse_raw(rx[sl].contiguous(), table, tgt[sl].contiguous(), 1000.0 / N, seed=11, row_offset=w * per * S)
+        assert torch.equal(a, nll[sl]) and torch.equal(b, lse[sl]) and torch.equal(c, dx[sl])
+    # ... and a different seed is a different kept set
+    assert not torch.equal(ops.catalog_ce_sparse_raw(rx, table, tgt, 1000.0 / N, seed=12, row_offset=0)[1], lse)
+    # candidate draws
+    cand, ctg = ops.candidate_draw(s, N, 50, seed=13, row_offset=0)
+    for w in range(W):
+        sl = slice(w * per, (w + 1) * per)
+        c2, t2 = ops.candidate_draw(s[sl].contiguous(), N, 50, seed=13, row_offset=w * per * S)
+        assert torch.equal(c2, cand[sl]) and torch.equal(t2, ctg[sl])
+    # sampled pivots (Gumbel-max over sigmoid scores)
+    q = rx[:B].contiguous()
+    ids = ops.catalog_sample(q, table, seed=17, row_offset=40)
+    for w in range(W):
+        sl = slice(w * per, (w + 1) * per)
+        assert torch.equal(ops.catalog_sample(q[sl].contiguous(), table, seed=17, row_offset=40 + w * per), ids[sl])
+
+
+def test_config4_stated_size_eight_ranks_of_1024_slates():
+    """the driver's 8-GPU run, one rank at a time on one GPU: N = 1M, K = 10, D = 128, global B = 8192, bf16x3 (the headline
+    arithmetic) - the eight summed shard gradients and the all-reduced ELBO equal the single-process step on the whole batch"""
+    import bench
+    from pivotcvae_amd.train_generative import Trainer
+    cfg = bench.CONFIGS["4"]
+    B, W = cfg["B"], 8
+    model, _ = bench.build_model(cfg, torch.device(DEV), "bf16x3")
+    model.rng_seed = 5
+    s, r, u = bench.synthetic_batch(cfg, B, torch.device(DEV))
+    flat0 = None
+    res = {}
+    for mode in ("single", "sharded"):
+        tr = Trainer(model, lr=bench.LR, beta=bench.BETA, world_size=W if mode == "sharded" else None)
+        if flat0 is None:
+            flat0 = tr.opt.flat.clone()
+        else:
+            tr.opt.flat.copy_(flat0)    # the same replica again, parameters rewound to the start
+        st, g, e = simulated_step(tr, W, s, r, u) if mode == "sharded" else single_step(tr, s, r, u)
+        res[mode] = (tr, [float(x) for x in st], g, e, tr.opt.flat.clone())
+        del tr
+    tr, st1, g1, e1, p1 = res["single"]
+    _, stW, gW, eW, pW = res["sharded"]
+    assert torch.equal(e1, eW)
+    np.testing.assert_allclose(stW, st1, rtol=1e-6)
+    grads_close(tr, gW, g1)
+    diff = (pW - p1).abs()
+    assert float(diff.max()) <= 2.001 * bench.LR and float((diff > 3e-6).float().mean()) < 2e-3

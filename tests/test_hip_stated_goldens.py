@@ -1,0 +1,107 @@
+"""-m gpu: the HIP path against goldens minted from the REAL reference at a BASELINE config's stated size (round 3):
+config 1 (List-CVAE N = 1000 S = 5 D = 16 B = 64), config 2 (PivotCVAE gt_pi N = 10 000 S = 5 D = 32 B = 1024) and a D = 128,
+S = 10 case whose width takes the MFMA kernels, so the bf16x3 (fp32-equivalent) catalog kernel and the fused train route meet
+the reference itself, not only the oracle.  Tolerances are the existing ones (tests/test_hip_model_golden.py): ELBO terms
+1e-4 relative, gradients rtol 2e-4, parameters after Adam steps rtol 1e-4 + atol 3e-6, greedy ids bit-exact on rows whose
+top-2 margin is not a rounding tie.  Reference: train_generative.py:44-65, 103, 124-134; models/pivotcvae.py:242-296;
+models/listcvae.py:134-188."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import DEV, build_from_golden, close, dev
+from tests.helpers import load, stated_cases
+
+pytestmark = pytest.mark.gpu
+CASES = [(n, p) for n in stated_cases() for p in (["f32", "bf16x3"] if "d128" in n else ["f32"])]
+
+
+def _model(g, prec, fused=True):
+    m = build_from_golden(g)
+    m.set_catalog_precision(prec)
+    if hasattr(m, "FUSED_TRAIN_PATH"):
+        m.FUSED_TRAIN_PATH = fused
+    return m
+
+
+@pytest.mark.parametrize("name,prec", CASES)
+def test_forward_pieces(name, prec):
+    g = load(name)
+    m = _model(g, prec)
+    with torch.no_grad():
+        s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
+        mu, lv = m.sample_encoding(s, r, u)
+        pmu, plv = m.get_prior(r, u)
+    for got, key in ((mu, "z_mu"), (lv, "z_logvar"), (pmu, "pMu"), (plv, "pLogvar")):
+        close(got, g.t("fwd/" + key), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,prec", CASES)
+@pytest.mark.parametrize("trainer_route", [False, True])
+def test_loss_and_gradients(name, prec, trainer_route):
+    """trainer_route: gradients through Trainer (flat buffers attached -> the fused train path for gt_pi);
+    otherwise model.loss(...).backward() on a bare module (operator-by-operator route)"""
+    from pivotcvae_amd.train_generative import Trainer
+    g = load(name)
+    m = _model(g, prec)
+    s, r, u, eps = dev(g.t("s")), dev(g.t("r")), dev(g.t("u")), dev(g.t("full/eps"))
+    if trainer_route:
+        tr = Trainer(m, lr=g.meta["lr"], beta=g.meta["beta"])
+        tr.local_phase(s, r, u, eps)
+        loss, rec, kld = (float(x) for x in tr._stats)
+    else:
+        loss, rec, kld = m.loss(s, r, u, g.meta["beta"], eps=eps)
+        loss.backward()
+        loss, rec, kld = loss.item(), rec.item(), kld.item()
+    np.testing.assert_allclose([loss, rec, kld], g.a["full/loss"], rtol=1e-4)
+    want = g.sub("grad")
+    for k, prm in m.named_parameters():
+        if k in want:
+            close(prm.grad, want[k], rtol=2e-4, atol=2e-6)
+        else:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+
+
+def test_config1_masked_mode_with_the_recorded_draw():
+    g = load("stated_config1_listcvae")
+    m = _model(g, "f32")
+    loss, rec, kld = m.loss(dev(g.t("s")), dev(g.t("r")), dev(g.t("u")), g.meta["beta"], eps=dev(g.t("part/eps")),
+                            keep_mask=dev(g.t("part/neg_sample")))
+    loss.backward()
+    np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], g.a["part/loss"], rtol=1e-4)
+    for k, v in g.sub("part/grad").items():
+        close(dict(m.named_parameters())[k].grad, v, rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("name,prec", CASES)
+def test_three_adam_steps(name, prec):
+    from pivotcvae_amd.train_generative import Trainer
+    g = load(name)
+    m = _model(g, prec)
+    tr = Trainer(m, lr=g.meta["lr"], beta=g.meta["beta"])
+    s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
+    for step in range(3):
+        loss, rec, kld = tr.step(s, r, u, eps=dev(g.t(f"adam/eps{step}")))
+        np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], g.a[f"adam/loss{step}"], rtol=1e-4)
+        if step in (0, 2):
+            sd = m.state_dict()
+            for k, v in g.sub(f"adam/step{step + 1}").items():
+                close(sd[k], v, rtol=1e-4, atol=3e-6)
+    for k in g.meta["none_grads"] + ["docEmbed.weight", "userEmbed.weight"]:
+        assert torch.equal(m.state_dict()[k].cpu(), g.sd[k]), k
+
+
+@pytest.mark.parametrize("name,prec", CASES)
+def test_greedy_ids(name, prec):
+    g = load(name)
+    m = _model(g, prec)
+    with torch.no_grad():
+        items, mu = m.recommend(dev(g.t("rec/r")), dev(g.t("u")), return_item=True, eps=dev(g.t("rec/eps")))
+        rx, _ = m.recommend(dev(g.t("rec/r")), dev(g.t("u")), return_item=False, eps=dev(g.t("rec/eps")))
+    close(mu, g.t("rec/z_mu"), rtol=1e-5, atol=1e-6)
+    close(rx, g.t("rec/rx"), rtol=1e-5, atol=1e-5)
+    safe = g.a["rec/item_margin"] > 1e-5     # rows whose top-2 margin is above fp32 rounding of a D-term dot product
+    assert safe.mean() > 0.99
+    np.testing.assert_array_equal(items.cpu().numpy()[safe], g.a["rec/items"][safe])
+    if g.has("rec/pivot"):
+        np.testing.assert_array_equal(m.last_pivot.cpu().numpy(), g.a["rec/pivot"])

@@ -222,6 +222,19 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
                 assert not clob, (name, clob[:5])
 
 
+def test_arrival_counters_wait_for_their_partial_stores():
+    """The batch splits of a weight gradient and the KL block partials are handed over through device-scope (sc1) stores + an
+    integer arrival counter.  The stores must be ACKNOWLEDGED before the counter is bumped: an explicit s_waitcnt vmcnt(0) has to
+    sit between the last sc1 store and the global_atomic_add in the generated ISA (a workgroup-scope release emits none)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_loop_check", os.path.join(ROOT, "tools", "isa_loop_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    bad, seen = mod.arrival_counter_waits()
+    assert seen >= 3, "hand-offs not found in the generated ISA"   # weight-gradient GEMM + the two KL kernels
+    assert not bad, bad[:5]
+
+
 def test_catalog_kernel_choice_and_range_alignment(monkeypatch):
     """pcvae_catalog_ce_variant mirrors the launch logic (host only): f32 -> 0; bf16 D = 256 -> pipelined always; D = 128 /
     64 -> pipelined on long ranges only, PCVAE_PIPE_MIN_TILES overrides; unsupported shapes -> -1."""

@@ -1,0 +1,68 @@
+"""Pin the CPU oracle against the goldens minted from the real reference at STATED sizes (round 3): config 1 (List-CVAE,
+N = 1000, S = 5, D = 16, B = 64), config 2 (PivotCVAE gt_pi, N = 10 000, S = 5, D = 32, B = 1024), and a D = 128, S = 10 case -
+loss terms, every gradient, three Adam steps, greedy ids.  The fixtures hold no dense [R, N] logits."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pivotcvae_oracle as orc
+from tests.helpers import load, stated_cases
+
+CASES = stated_cases()
+
+
+def close(a, b, rtol, atol):
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_the_three_stated_cases_exist():
+    assert CASES == ["stated_config1_listcvae", "stated_config2_gt_pi", "stated_d128_gt_pi"]
+    m1, m2 = load(CASES[0]).meta, load(CASES[1]).meta
+    assert (m1["model"], m1["N"], m1["S"], m1["D"], m1["B"]) == ("listcvae", 1000, 5, 16, 64)          # BASELINE.json configs[0]
+    assert (m2["model"], m2["N"], m2["S"], m2["D"], m2["B"]) == ("pivotcvae_gt_pi", 10000, 5, 32, 1024)  # configs[1]
+    assert m2["structs"]["enc"] == [198, 256, 256] and m2["structs"]["scm"] == [86, 256, 256, 128]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_pieces_loss_and_gradients(name):
+    g = load(name)
+    cfg = g.cfg()
+    close(orc.normalize_rows(g.t("raw_doc")), g.t("sd/docEmbed.weight"), 2e-6, 2e-7)
+    f = orc.forward(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("fwd/eps"))
+    for k in ("rx", "z", "z_mu", "z_logvar"):
+        close(f[k], g.t("fwd/" + k), 1e-5, 1e-6)
+    (loss, rec, kld), grads = orc.loss_and_grads(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("full/eps"), g.meta["beta"])
+    np.testing.assert_allclose([loss, rec, kld], g.a["full/loss"], rtol=2e-6)
+    assert sorted(k for k, v in grads.items() if v is None) == sorted(
+        k for k in g.meta["none_grads"] if not k.startswith(("docEmbed", "userEmbed")))
+    for k, v in g.sub("grad").items():
+        close(grads[k], v, 5e-5, 2e-7)
+    if g.has("part/neg_sample"):
+        (loss, rec, kld), grads = orc.loss_and_grads(g.sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t("part/eps"), g.meta["beta"],
+                                                     neg_sample=g.t("part/neg_sample"))
+        np.testing.assert_allclose([loss, rec, kld], g.a["part/loss"], rtol=2e-6)
+        for k, v in g.sub("part/grad").items():
+            close(grads[k], v, 5e-5, 2e-7)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_three_adam_steps_and_greedy_ids(name):
+    g = load(name)
+    cfg = g.cfg()
+    sd, state = g.sd, {}
+    for step in range(3):
+        (loss, rec, kld), grads = orc.loss_and_grads(sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t(f"adam/eps{step}"), g.meta["beta"])
+        np.testing.assert_allclose([loss, rec, kld], g.a[f"adam/loss{step}"], rtol=3e-6)
+        sd = orc.adam_step(sd, grads, state, g.meta["lr"])
+        if step in (0, 2):
+            for k, v in g.sub(f"adam/step{step + 1}").items():
+                close(sd[k], v, 2e-5, 3e-7)
+    for k in g.meta["none_grads"]:
+        assert torch.equal(sd[k], g.sd[k])
+    o = orc.recommend(g.sd, cfg, g.t("rec/r"), g.t("u"), g.t("rec/eps"))
+    close(o["rx"], g.t("rec/rx"), 1e-5, 1e-6)
+    safe = torch.from_numpy(g.a["rec/item_margin"] > 1e-5)
+    assert float(safe.float().mean()) > 0.99
+    assert torch.equal(o["items"][safe], g.t("rec/items")[safe])
+    if cfg.model != "listcvae":
+        assert torch.equal(o["pivot"], g.t("rec/pivot"))

@@ -120,6 +120,33 @@ def hot_loops(pattern="pipe"):
     return out
 
 
+def arrival_counter_waits(sources=("gemm_f32.hip", "elementwise.hip")):
+    """-> list of (file, kernel, line) where an arrival counter is bumped (integer global_atomic_add) behind device-scope (sc1)
+    stores of partial results WITHOUT an `s_waitcnt vmcnt(0)` in between.  A workgroup-scope release emits no vmcnt wait on
+    gfx950, so the hand-off of the weight gradients' batch splits (gemm_f32.hip) and of the KL partials (elementwise.hip)
+    carries an explicit one; this check keeps hipcc (and future edits) from losing it.  Also returns the number of hand-offs seen."""
+    bad, seen = [], 0
+    for f in sources:
+        src = os.path.join(ROOT, "pivotcvae_amd", "csrc", f)
+        asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
+                              src, "-o", "-"], capture_output=True, text=True, check=True).stdout
+        for m in re.finditer(r"^(_Z\S+):\s*; @", asm, re.M):
+            body = asm[m.end():asm.find(".Lfunc_end", m.end())].split("\n")
+            lines = [l.split(";")[0].strip() for l in body]
+            last_sc1, waited = None, True
+            for n, l in enumerate(lines):
+                if l.startswith("global_store") and " sc1" in l and "sc0" not in l:
+                    last_sc1, waited = n, False
+                elif l.startswith("s_waitcnt") and "vmcnt(0)" in l:
+                    waited = True
+                elif re.match(r"global_atomic_add(_u32)?\s", l) and last_sc1 is not None:
+                    seen += 1
+                    if not waited:
+                        bad.append((f, m.group(1), l))
+                    last_sc1 = None
+    return bad, seen
+
+
 def main():
     ok = True
     for name, loops in hot_loops().items():
@@ -135,6 +162,11 @@ def main():
             # enforced for the bf16x3 kernel, whose schedule has MFMA-dense stretches where the hazard was observed; the round-1
             # kernels (parity-tested on hardware at every size) are reported only
             ok = ok and not bad and not (clob and "x3" in name)
+    bad, seen = arrival_counter_waits()
+    print(f"arrival counters behind sc1 stores: {seen} hand-offs, {len(bad)} without s_waitcnt vmcnt(0)")
+    for b in bad[:10]:
+        print("   ", b)
+    ok = ok and seen > 0 and not bad
     return 0 if ok else 1
 
 
