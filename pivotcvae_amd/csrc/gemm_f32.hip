@@ -496,9 +496,11 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
 }
 
 // 64 x 64 tiles once the launch fills the chip, else 32 x 32 tiles with the K chunk split over the waves
+// (read at every launch, ~50 ns: PCVAE_GEMM_SMALL_BELOW=0 makes every launch use the 64 x 64 tiles, whose k order per output row
+// does not depend on M - the data-parallel tests use it to get forward activations that are BITWISE independent of the sharding)
 static inline int64_t small_below() {
-    static const int64_t below = [] { const char* e = getenv("PCVAE_GEMM_SMALL_BELOW"); return e ? atoll(e) : 256LL; }();
-    return below;
+    const char* e = getenv("PCVAE_GEMM_SMALL_BELOW");
+    return e ? atoll(e) : 256LL;
 }
 
 static int check_desc(const pcvae_gemm_desc& d) {

@@ -8,7 +8,12 @@ buffers (+ their statistics tails) are summed - exactly what ``all_reduce(SUM)``
 ``finish_phase`` applies the one Adam step.  Replicas are identical before a step and apply the same update, so one replica
 playing all ranks IS the W-rank job.  Checked against the single-process step on the whole batch:
 
-  * ELBO terms (rtol 1e-6), every parameter gradient (<= 2e-5 of its tensor's scale), parameters after 1 and 3 steps;
+  * ELBO terms (rtol 1e-6), every parameter gradient (<= 2e-5 of its tensor's scale), parameters after 1 and 3 steps.  The strict
+    gradient bound is asserted with the GEMMs pinned to ONE tile path (PCVAE_GEMM_SMALL_BELOW=0): a row's forward activations are
+    then bitwise independent of the batch size, so no LeakyReLU unit changes sign between the two jobs.  With the default tile
+    choice (32 x 32 K-split tiles for small shards, another summation order) an activation within rounding of 0 flips its
+    LeakyReLU' from 1 to 0.01 for ONE slate - a discrete change of that slate's contribution (~1 expected flip per 8M
+    activations = one config-4 batch); that mode is held to 1e-3 of scale;
   * the in-kernel Philox streams - eps, the sparse kept set, candidate draws, sampled pivots - bitwise independent of W;
   * the fused train path and the operator-by-operator path (FUSED_TRAIN_PATH = False) under sharding;
   * once at config 4's STATED size with W = 8, B_local = 1024 (the driver's 8-GPU run, one rank at a time).
@@ -72,6 +77,19 @@ def single_step(tr, s, r, u, eps=None):
     return tr.finish_phase(), grads, eps_used
 
 
+STRICT, FLIP_BUDGET = 2e-5, 1e-3
+
+
+@pytest.fixture(params=["one_tile_path", "default_tiles"])
+def tile_mode(request, monkeypatch):
+    """-> gradient tolerance (fraction of the tensor's scale); see the module docstring"""
+    if request.param == "one_tile_path":
+        monkeypatch.setenv("PCVAE_GEMM_SMALL_BELOW", "0")
+        return STRICT
+    monkeypatch.delenv("PCVAE_GEMM_SMALL_BELOW", raising=False)
+    return FLIP_BUDGET
+
+
 def grads_close(tr, got, want, tol=2e-5):
     """per parameter tensor: max |difference| <= tol * max |gradient| of that tensor"""
     off = 0
@@ -86,7 +104,7 @@ def grads_close(tr, got, want, tol=2e-5):
 @pytest.mark.parametrize("prec", ["f32", "bf16x3"])
 @pytest.mark.parametrize("W", [2, 8])
 @pytest.mark.parametrize("fused", [True, False])
-def test_w_simulated_ranks_equal_the_single_process_step(W, prec, fused):
+def test_w_simulated_ranks_equal_the_single_process_step(W, prec, fused, tile_mode):
     """mid-size D = 128 model (the width of the bf16x3 / MFMA kernels), full-catalog softmax, in-kernel Philox eps"""
     from pivotcvae_amd.train_generative import Trainer
     N, S, D, B = 20011, 10, 128, 512
@@ -109,7 +127,7 @@ def test_w_simulated_ranks_equal_the_single_process_step(W, prec, fused):
         np.testing.assert_allclose(stW, st1, rtol=1e-6 if k == 0 else 2e-6)          # all-reduced ELBO terms == whole-batch terms
         np.testing.assert_allclose(st1[0], st1[1] + 0.001 * st1[2], rtol=1e-6)
         if k == 0:   # same parameters on both sides: the summed shard gradients ARE the whole-batch gradient
-            grads_close(tr, gW, g1)
+            grads_close(tr, gW, g1, tol=tile_mode)
         # Adam's first steps move a weight by ~lr * sign(g): a gradient that changes sign at rounding level moves by up to 2 lr
         diff = (pW - p1).abs()
         assert float(diff.max()) <= 2.001 * 3e-4 * (k + 1)
@@ -118,7 +136,7 @@ def test_w_simulated_ranks_equal_the_single_process_step(W, prec, fused):
 
 
 @pytest.mark.parametrize("W", [2, 8])
-def test_masked_mode_and_sampled_pivots_under_sharding(W):
+def test_masked_mode_and_sampled_pivots_under_sharding(W, tile_mode):
     """the reference's default n_neg = 1000 (sparse kept-rows kernel, mask keyed by GLOBAL row) and a sampled-pivot rule (sgt:
     Gumbel-max sampler keyed by GLOBAL slate index): the sharded job reproduces the single-process one"""
     from pivotcvae_amd.train_generative import Trainer
@@ -141,7 +159,7 @@ def test_masked_mode_and_sampled_pivots_under_sharding(W):
             assert torch.equal(e1, eW)
             np.testing.assert_allclose(stW, st1, rtol=2e-6)
             if k == 0:
-                grads_close(res["single"][0], gW, g1)
+                grads_close(res["single"][0], gW, g1, tol=tile_mode)
 
 
 def test_in_kernel_streams_are_bitwise_independent_of_the_sharding():
@@ -181,7 +199,7 @@ def test_in_kernel_streams_are_bitwise_independent_of_the_sharding():
         assert torch.equal(ops.catalog_sample(q[sl].contiguous(), table, seed=17, row_offset=40 + w * per), ids[sl])
 
 
-def test_config4_stated_size_eight_ranks_of_1024_slates():
+def test_config4_stated_size_eight_ranks_of_1024_slates(tile_mode):
     """the driver's 8-GPU run, one rank at a time on one GPU: N = 1M, K = 10, D = 128, global B = 8192, bf16x3 (the headline
     arithmetic) - the eight summed shard gradients and the all-reduced ELBO equal the single-process step on the whole batch"""
     import bench
@@ -206,6 +224,8 @@ def test_config4_stated_size_eight_ranks_of_1024_slates():
     _, stW, gW, eW, pW = res["sharded"]
     assert torch.equal(e1, eW)
     np.testing.assert_allclose(stW, st1, rtol=1e-6)
-    grads_close(tr, gW, g1)
+    # a weight gradient is an fp32 sum over 8192 slates; one process adds them in batch-split order, eight ranks add 1024 each and
+    # the all-reduce adds the eight: rounding ~ 6e-8 x |partial sums| x sqrt(adds), a few 1e-5 of a tensor's scale at this size
+    grads_close(tr, gW, g1, tol=max(tile_mode, 5e-5))
     diff = (pW - p1).abs()
     assert float(diff.max()) <= 2.001 * bench.LR and float((diff > 3e-6).float().mean()) < 2e-3

@@ -16,6 +16,17 @@ pytestmark = pytest.mark.gpu
 CASES = [(n, p) for n in stated_cases() for p in (["f32", "bf16x3"] if "d128" in n else ["f32"])]
 
 
+def adam_close(got, want, lr, steps, rtol=1e-4, atol=3e-6):
+    """parameters after Adam steps: rtol / atol as in tests/test_hip_model_golden.py for (nearly) every element.  Adam's first steps
+    move a weight by ~lr * g / (|g| + 1e-8): where |g| is of the order of its own rounding error (a handful of the 1e5 .. 1e6
+    weights at these sizes) the normalised step follows the noise - those may differ by up to the whole move, 2 lr per step."""
+    a, b = got.detach().cpu(), want.detach().cpu() if torch.is_tensor(want) else torch.as_tensor(want)
+    diff = (a - b).abs()
+    off = diff > atol + rtol * b.abs()
+    assert float(off.float().mean()) <= 1e-4, (float(off.float().mean()), float(diff.max()))
+    assert float(diff.max()) <= 2.001 * lr * steps
+
+
 def _model(g, prec, fused=True):
     m = build_from_golden(g)
     m.set_catalog_precision(prec)
@@ -86,7 +97,7 @@ def test_three_adam_steps(name, prec):
         if step in (0, 2):
             sd = m.state_dict()
             for k, v in g.sub(f"adam/step{step + 1}").items():
-                close(sd[k], v, rtol=1e-4, atol=3e-6)
+                adam_close(sd[k], v, g.meta["lr"], step + 1)
     for k in g.meta["none_grads"] + ["docEmbed.weight", "userEmbed.weight"]:
         assert torch.equal(m.state_dict()[k].cpu(), g.sd[k]), k
 
