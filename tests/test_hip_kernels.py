@@ -831,3 +831,58 @@ def test_downsample_dense_is_the_documented_stream(ops):
     assert torch.equal(full.cpu(), pred)
     with pytest.raises(RuntimeError):
         downsample(pred.to(DEV), slate.to(DEV), n_neg=N + 1)
+
+
+def test_split_hand_off_stress_two_thousand_grouped_launches(ops):
+    """Round 3 hardening of the weight gradients' batch-split hand-off (csrc/gemm_f32.hip: sc1 stores of the partial tiles, an
+    explicit s_waitcnt vmcnt(0) in every thread, barrier, an integer arrival counter, sc1 loads by the last workgroup).  The failure
+    mode it replaced - and the one a missing wait would bring back - is a silently wrong gradient in a few percent of the elements,
+    timing dependent.  So: > 2 000 grouped launches over random ragged (M, N, K), 1 - 3 weight gradients per launch (+ an unrelated
+    forward GEMM riding along in some), split counts from 1 up to the cost model's maximum of 64, issued BACK TO BACK without any
+    host synchronisation; every repetition of a launch must equal its own first result BITWISE, and the first one fp64."""
+    import random
+    rng = random.Random(20260)
+    cases = []
+    # shapes that force many splits (few output tiles, long batch), the model's own layers, and ragged everything
+    forced = [(4096, 64, 64), (8192, 32, 16), (4097, 64, 65), (2000, 256, 139), (8192, 256, 1419), (1024, 1152, 256), (6000, 100, 33)]
+    for i in range(42):
+        probs = []
+        for _ in range(rng.choice([1, 1, 2, 3])):
+            if rng.random() < 0.35:
+                M, N, K = rng.choice(forced)
+            else:
+                M = rng.choice([1, 63, 64, 65, 200, 513, 1000, 2049, 4100, 8192])
+                N = rng.choice([1, 16, 33, 64, 65, 128, 256, 300])
+                K = rng.choice([1, 7, 32, 64, 65, 130, 283, 400])
+            probs.append((M, N, K))
+        cases.append((probs, rng.random() < 0.4))
+    REPS = 50
+    launches = 0
+    max_splits = 0
+    for ci, (probs, with_fwd) in enumerate(cases):
+        ins = [(rnd(M, N, seed=7000 + 10 * ci + j).to(DEV), rnd(M, K, seed=8000 + 10 * ci + j).to(DEV)) for j, (M, N, K) in enumerate(probs)]
+        outs = [[(torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)) for (M, N, K) in probs] for _ in range(REPS)]
+        if with_fwd:
+            xf, Wf, bf = rnd(300, 70, seed=9000 + ci).to(DEV), rnd(40, 70, seed=9100 + ci).to(DEV), rnd(40, seed=9200 + ci).to(DEV)
+            yf = [torch.empty(300, 40, device=DEV) for _ in range(REPS)]
+        for rep in range(REPS):            # no host sync anywhere in this loop
+            grp = ops.GemmGroup()
+            for (g, x), (dW, db) in zip(ins, outs[rep]):
+                grp.dw(g, x, dW, db)
+            if with_fwd:
+                grp.fwd(xf, Wf, bf, 1, out=yf[rep])
+            grp.launch()
+            launches += 1
+        for j, ((M, N, K), (g, x)) in enumerate(zip(probs, ins)):
+            max_splits = max(max_splits, min(64, (M + 63) // 64))
+            first_W, first_b = outs[0][j]
+            for rep in range(1, REPS):
+                assert torch.equal(outs[rep][j][0], first_W), (ci, j, rep, probs)
+                assert torch.equal(outs[rep][j][1], first_b), (ci, j, rep, probs)
+            atol = 2e-5 * max(1.0, (M / 64.0) ** 0.5)
+            torch.testing.assert_close(first_W.cpu(), (g.double().cpu().t() @ x.double().cpu()).float(), rtol=1e-4, atol=atol)
+            torch.testing.assert_close(first_b.cpu(), g.double().cpu().sum(0).float(), rtol=1e-4, atol=atol)
+        if with_fwd:
+            for rep in range(1, REPS):
+                assert torch.equal(yf[rep], yf[0])
+    assert launches >= 2000 and max_splits == 64
