@@ -86,6 +86,9 @@ def synthetic_batch(cfg, B, device, seed=1):
 def kernel_name(R, N, D, dtype):
     """the dominant kernel's name as rocprofv3 shows it (the library reports which variant a shape runs)"""
     from pivotcvae_amd import _hip
+    from pivotcvae_amd import ops
+    if dtype == "bf16x3" and ops.x3_width(D):
+        D = ops.x3_width(D)    # narrower tables run the 128-wide kernel on zero columns
     v = _hip.lib().pcvae_catalog_ce_variant(R, N, D, _hip.PREC_NAMES[dtype])
     return {0: f"catalog_ce_f32_kernel<{D}>", 1: f"catalog_ce_bf16_fast_kernel<{D}>",
             2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>", 3: f"catalog_ce_x3_pipe_kernel<{D}, 2>"}.get(v, "?")
@@ -540,8 +543,8 @@ def main():
         raise SystemExit("global batch not divisible by the number of GPUs")
     if args.dtype is None:
         args.dtype = {"3": "bf16", "5": "bf16"}.get(args.config, "bf16x3" if D in ops.X3_DIMS else "f32")
-    if args.dtype == "bf16x3" and D not in ops.X3_DIMS:
-        raise SystemExit(f"bf16x3 exists for D in {ops.X3_DIMS}")
+    if args.dtype == "bf16x3" and ops.x3_width(D) is None:
+        raise SystemExit(f"bf16x3 exists for D <= {ops.X3_MAX_PADDED}")
     model, st = build_model(cfg, device, args.dtype)
     # hipGraph replay pays off when the step is launch-bound (per-rank batch <= 4096 slates: ~50 launches of 5-30 us);
     # at a full single-GPU batch of config 4 the catalog kernel is > 95 % of the step and eager launches keep the HIP events
@@ -592,7 +595,7 @@ def main():
         was_graph = trainer.capture_graph
         trainer.capture_graph = False
         for dt_name in ("f32", "bf16x3", "bf16"):
-            if dt_name == args.dtype or (dt_name == "bf16x3" and D not in ops.X3_DIMS) or \
+            if dt_name == args.dtype or (dt_name == "bf16x3" and ops.x3_width(D) is None) or \
                     (dt_name == "bf16" and D not in ops.BF16_DIMS) or args.n_neg is not None:
                 continue
             if dt_name == "f32" and 4.0 * R_local * N * D > 2e14:   # config 5 in exact f32: minutes per step

@@ -852,30 +852,32 @@ class CatalogTable:
     def __init__(self, weight):
         self.weight = weight
         self._ver = None
-        self._hi = self._x3 = self._pad = None
+        self._hi = self._x3 = None
+        self._pad = {}
         self._emax = 0.0
 
     def _refresh(self):
         w = self.weight
         key = (w.data_ptr(), w._version, tuple(w.shape))
         if self._ver != key:
-            self._hi = self._x3 = self._pad = None
+            self._hi = self._x3 = None
+            self._pad = {}
             self._emax = 0.0
             self._ver = key
 
-    def padded(self):
-        """-> (fp32 table of a supported width, that width)"""
+    def padded(self, width=None):
+        """-> (fp32 table of a supported width, that width); ``width``: pad to exactly this many columns (the bf16x3 kernel's 128)"""
         self._refresh()
         w = self.weight
         D = w.shape[1]
-        Dp = _padded_width(D)
+        Dp = _padded_width(D) if width is None else int(width)
         if Dp == D:
             return w, D
-        if self._pad is None:
+        if Dp not in self._pad:
             pad = torch.zeros(w.shape[0], Dp, dtype=F32, device=w.device)
             copy2d(w.detach(), pad[:, :D])
-            self._pad = pad
-        return self._pad, Dp
+            self._pad[Dp] = pad
+        return self._pad[Dp], Dp
 
     def _max_norm(self, w32):
         if self._emax == 0.0:
@@ -892,6 +894,7 @@ class CatalogTable:
         w32 = w.detach().contiguous()
         self._max_norm(w32)
         if prec == PREC_BF16X3:
+            w32 = self.padded(x3_width(w.shape[1]))[0].detach()   # narrower tables ride the 128-wide kernel on zero columns
             if self._x3 is None:
                 x3 = torch.empty(w32.shape[0], 2 * w32.shape[1], dtype=torch.int16, device=w.device)
                 check(lib().pcvae_split_bf16x2(ptr(w32, F32), w32.shape[0], w32.shape[1], ptr(x3), stream()), "split_bf16x2")
@@ -951,7 +954,17 @@ def _as_table(E):
 
 
 BF16_DIMS = (64, 128, 256)  # the bf16 MFMA kernels exist for these widths; narrower tables are tiny: exact f32 path
-X3_DIMS = (128,)            # widths the bf16x3 (fp32-equivalent) kernel exists for
+X3_DIMS = (128,)            # widths the bf16x3 (fp32-equivalent) kernel is instantiated for ...
+X3_MAX_PADDED = 128         # ... and any narrower table runs it on zero columns (a zero column adds exactly 0 to every product of the
+#                             three-MFMA split: same logits, same gradient in the real columns).  D = 64 does 2x, D = 32 4x the
+#                             necessary MFMAs and is still 2.2x / 1.6x faster than the exact f32-MFMA kernel at its tolerances
+
+
+def x3_width(D):
+    """table width the bf16x3 kernel runs a D-wide catalog at (None: no bf16x3 route for this width)"""
+    if D in X3_DIMS:
+        return D
+    return X3_MAX_PADDED if D < X3_MAX_PADDED else None
 
 
 SPARSE_MAX_KEEP_PROB = 0.03   # above this the dense masked kernel (one pass over the catalog) is the cheaper one
@@ -991,10 +1004,11 @@ def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, wa
 
 
 def effective_precision(prec, D):
-    """bf16 kernels exist for D in BF16_DIMS, the bf16x3 kernel for D in X3_DIMS; everything else computes in exact f32"""
+    """bf16 kernels exist for D in BF16_DIMS, the bf16x3 kernel for D <= 128 (natively at 128, narrower tables zero-padded);
+    everything else computes in exact f32"""
     if prec == PREC_BF16 and D in BF16_DIMS:
         return PREC_BF16
-    if prec == PREC_BF16X3 and D in X3_DIMS:
+    if prec == PREC_BF16X3 and x3_width(D) is not None:
         return PREC_BF16X3
     return PREC_F32
 
@@ -1030,7 +1044,7 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     if keep_mask is not None or keep_prob < 1.0:
         prec = PREC_F32 if prec == PREC_BF16X3 else prec   # masked calls: the x3 kernel is max-free / mask-free
     E, E_lo = table.operands(prec)
-    D = _padded_width(D0)
+    D = x3_width(D0) if prec == PREC_BF16X3 else _padded_width(D0)
     rx = _pad_cols(rx, D)
     nll = torch.empty(R, dtype=F32, device=rx.device)
     lse = torch.empty(R, dtype=F32, device=rx.device)

@@ -13,7 +13,8 @@ from tests.gpu_util import DEV, build_from_golden, close, dev
 from tests.helpers import load, stated_cases
 
 pytestmark = pytest.mark.gpu
-CASES = [(n, p) for n in stated_cases() for p in (["f32", "bf16x3"] if "d128" in n else ["f32"])]
+# bf16x3: natively at D = 128, on zero-padded columns at D = 16 / 32 (ops.x3_width) - the reference-precision fast path of every case
+CASES = [(n, p) for n in stated_cases() for p in ("f32", "bf16x3")]
 
 
 def adam_close(got, want, lr, steps, rtol=1e-4, atol=3e-6):

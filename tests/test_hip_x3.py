@@ -181,3 +181,31 @@ def test_x3_model_level_elbo_and_gradients(ops):
     for k, gf in res["f32"][1].items():
         gx = res["bf16x3"][1][k]
         assert (gx - gf).abs().max() <= 2e-5 * gf.abs().max() + 1e-9, k
+
+
+@pytest.mark.parametrize("Dn", [16, 32, 64, 100])
+@pytest.mark.parametrize("R,N", [(130, 33), (257, 9000), (64, 40001)])
+def test_x3_narrow_tables_ride_the_128_wide_kernel(ops, Dn, R, N):
+    """round 3: D < 128 (configs 2 and 3: D = 32 / 64) runs bf16x3 on zero-padded columns - a zero column adds exactly 0 to each of
+    the three products, so the result is the D-wide fp32-equivalent one: held to the fp32 C oracle at the f32 kernel's tolerances"""
+    from pivotcvae_amd._hip import PREC_BF16X3
+    assert ops.x3_width(Dn) == 128 and ops.effective_precision(PREC_BF16X3, Dn) == PREC_BF16X3
+    rx, E = rnd(R, Dn, seed=11, scale=2.0), orc.normalize_rows(rnd(N, Dn, seed=12))
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(13))
+    tgt[0], tgt[-1] = 0, N - 1
+    table = ops.CatalogTable(E.to(DEV))
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), table, tgt.to(DEV), prec=PREC_BF16X3)
+    assert dx.shape == (R, Dn)
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    # ... and it is not the exact kernel answering: the two differ in the last bits
+    n32, l32, _ = ops.catalog_ce_raw(rx.to(DEV), table, tgt.to(DEV), prec=0)
+    torch.testing.assert_close(lse, l32, rtol=2e-6, atol=2e-6)
+    # the autograd op on the padded route: gradient of the mean
+    x = rx.to(DEV).requires_grad_(True)
+    loss = ops.catalog_ce(x, table, tgt.to(DEV), prec=PREC_BF16X3)
+    loss.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), wd / R, rtol=2e-5, atol=2e-6 / R)
+    np.testing.assert_allclose(loss.item(), wn.mean(), rtol=2e-6)
