@@ -321,6 +321,15 @@ int pcvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                        float eps, int step, float grad_scale, float weight_decay, pcvae_stream_t stream);
 
+/* Measurement only (bench.py, tools/): per-kernel durations from HIP events attached to the dispatch itself.  While enabled, the
+ * instrumented launches (tags below) go out through hipExtLaunchKernelGGL with a start / stop event pair; read returns the number
+ * of timed launches and fills their durations (ms) and tags in launch order.  No reference counterpart (the reference times with
+ * time.time(), train_generative.py:113).                                                                                       */
+#define PCVAE_TIMER_GATHER 1        /* gather_rows_vec4_kernel      (pcvae_gather_rows)      */
+#define PCVAE_TIMER_ASSEMBLE 2      /* assemble_inputs_vec_kernel   (pcvae_assemble_inputs)  */
+int pcvae_kernel_timer(int enable);
+int pcvae_kernel_timer_read(float* ms, int* tags, int cap);
+
 /* optimizer.zero_grad() (train_generative.py:124) as a memset on the stream: the flat gradient buffer (+ its statistics tail) */
 int pcvae_zero(void* p, size_t nbytes, pcvae_stream_t stream);
 

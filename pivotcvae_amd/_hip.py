@@ -77,6 +77,8 @@ SIGNATURES = {
     "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],
     "pcvae_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "pcvae_adam_step_l2": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _F, _P],
+    "pcvae_kernel_timer": [_I],
+    "pcvae_kernel_timer_read": [_P, _P, _I],
     "pcvae_zero": [_P, _SZ, _P],
     "pcvae_elbo_pack": [_P, _P, _F, _P, _P],
     "pcvae_scatter_add_rows": [_P, _L, _I, _I, _P, _L, _P, _L, _P],

@@ -74,7 +74,9 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
 static inline bool catalog_bf16_pipelined(int D, int tiles_per_split) {
     if (D == 256) return true;
     const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
-    return tiles_per_split >= (env_min ? atoi(env_min) : 512);
+    // D = 64 runs what is left after its last full trip at steady speed, so it pays off from shorter ranges on (config 3: 391
+    // tiles per range, 0.939 against 0.967 ms per launch - round 3)
+    return tiles_per_split >= (env_min ? atoi(env_min) : (D == 64 ? 256 : 512));
 }
 
 int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,

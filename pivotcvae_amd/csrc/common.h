@@ -1,6 +1,7 @@
 // Shared device/host helpers for libpcvae_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -21,6 +22,22 @@ int check_launch(const char* what);
     } while (0)
 
 static inline hipStream_t as_stream(pcvae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- per-kernel timing (pcvae_kernel_timer): HIP events ATTACHED to a dispatch (hipExtLaunchKernelGGL's start / stop events carry
+// the kernel's own begin / end timestamps - what rocprofv3's kernel trace shows), as opposed to a hipEventRecord pair around the
+// launch, which also measures its own two marker packets (~2.4 us on this chip: 12 % of the 20 us gather).  Off by default.
+bool timer_on();
+void timer_events(int tag, hipEvent_t* start, hipEvent_t* stop);   // a fresh pair, remembered under `tag`
+#define PCVAE_LAUNCH_TIMED(tag, kernel, grid, block, shmem, stream, ...)                                        \
+    do {                                                                                                        \
+        if (::pcvae::timer_on()) {                                                                              \
+            hipEvent_t e0_, e1_;                                                                                \
+            ::pcvae::timer_events(tag, &e0_, &e1_);                                                             \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, e0_, e1_, 0, __VA_ARGS__);               \
+        } else {                                                                                                \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                \
+        }                                                                                                       \
+    } while (0)
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr float kLeakySlope = 0.01f;  // nn.LeakyReLU() default (reference models/cvae.py:43)

@@ -53,6 +53,10 @@ __global__ void __launch_bounds__(256) gather_rows_vec4_kernel(const f32x4* __re
     }
 }
 
+// (Round 3, measured and dropped: the wave's row indices through the SCALAR cache - 4 s_load_dwordx16 instead of 16 broadcast vector
+// loads.  23.3 us against 21.5 us for this kernel on the same box: every row load then waits for ALL indices (one lgkmcnt), while
+// here a lane's row load follows its own index load.)
+
 // generic fallback (any D / alignment): one wave per row, 4 B per lane
 __global__ void __launch_bounds__(256) gather_rows_scalar_kernel(const float* __restrict__ table, int D,
                                                                  const int64_t* __restrict__ idx, int64_t n_idx,
@@ -84,11 +88,11 @@ extern "C" int pcvae_gather_rows(const float* table, int64_t n_rows, int D, cons
         const int64_t n_groups = cdiv(n_idx, rows_per_wave);
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(cdiv(cdiv(n_groups, GATHER_UNROLL), 4), GATHER_MAXBLOCKS));
         if (out_ld == (int64_t)group * D)
-            hipLaunchKernelGGL((gather_rows_vec4_kernel<GATHER_UNROLL, true>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                               reinterpret_cast<const f32x4*>(table), chunks, lpr, idx, n_idx, group, out, out_ld, D);
+            PCVAE_LAUNCH_TIMED(PCVAE_TIMER_GATHER, (gather_rows_vec4_kernel<GATHER_UNROLL, true>), dim3((unsigned)blocks), dim3(256), 0,
+                               as_stream(stream), reinterpret_cast<const f32x4*>(table), chunks, lpr, idx, n_idx, group, out, out_ld, D);
         else
-            hipLaunchKernelGGL((gather_rows_vec4_kernel<GATHER_UNROLL, false>), dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                               reinterpret_cast<const f32x4*>(table), chunks, lpr, idx, n_idx, group, out, out_ld, D);
+            PCVAE_LAUNCH_TIMED(PCVAE_TIMER_GATHER, (gather_rows_vec4_kernel<GATHER_UNROLL, false>), dim3((unsigned)blocks), dim3(256), 0,
+                               as_stream(stream), reinterpret_cast<const f32x4*>(table), chunks, lpr, idx, n_idx, group, out, out_ld, D);
     } else {
         const int64_t blocks = std::min<int64_t>(cdiv(n_idx, 4), 256 * 8);
         hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), table,
@@ -664,9 +668,9 @@ extern "C" int pcvae_assemble_inputs(const float* E, int64_t n_items, const floa
     if (B == 0) return PCVAE_OK;
     const int cpr = D / 4;
     if (D % 4 == 0 && cpr <= 64 && 64 % cpr == 0 && B * (S + 1) < (1LL << 31))   // a row = an aligned group of <= 64 lanes
-        hipLaunchKernelGGL(assemble_inputs_vec_kernel<4>, dim3((unsigned)cdiv(B * (S + (U ? 1 : 0)), (256 / cpr) * 4)), dim3(256), 0,
-                           as_stream(stream), E, U, s, r, u, B, S, D, ncols, Z, enc_in, ld_enc, prior_in, ld_prior, scm_in, ld_scm, rx,
-                           ld_rx);
+        PCVAE_LAUNCH_TIMED(PCVAE_TIMER_ASSEMBLE, assemble_inputs_vec_kernel<4>, dim3((unsigned)cdiv(B * (S + (U ? 1 : 0)), (256 / cpr) * 4)),
+                           dim3(256), 0, as_stream(stream), E, U, s, r, u, B, S, D, ncols, Z, enc_in, ld_enc, prior_in, ld_prior, scm_in,
+                           ld_scm, rx, ld_rx);
     else
         hipLaunchKernelGGL(assemble_inputs_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), E, U, s, r, u, B, S, D,
                            ncols, Z, enc_in, ld_enc, prior_in, ld_prior, scm_in, ld_scm, rx, ld_rx);

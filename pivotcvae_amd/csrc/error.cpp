@@ -1,5 +1,6 @@
 // Host-side error text + ABI version for libpcvae_hip.so.
 #include "common.h"
+#include <vector>
 
 namespace pcvae {
 static thread_local char g_err[512] = "";
@@ -19,7 +20,48 @@ int check_launch(const char* what) {
     }
     return PCVAE_OK;
 }
+
+// ---- kernel timer ------------------------------------------------------------------------------------------------------------
+namespace {
+struct TimedLaunch { int tag; hipEvent_t e0, e1; };
+std::vector<TimedLaunch>& timed() { static std::vector<TimedLaunch> v; return v; }
+bool g_timer_on = false;
+}
+bool timer_on() { return g_timer_on; }
+void timer_events(int tag, hipEvent_t* start, hipEvent_t* stop) {
+    TimedLaunch t{tag, nullptr, nullptr};
+    hipEventCreate(&t.e0);
+    hipEventCreate(&t.e1);
+    timed().push_back(t);
+    *start = t.e0;
+    *stop = t.e1;
+}
 }  // namespace pcvae
+
+// enable = 1: start collecting (forgets earlier launches); 0: stop.  Not thread-safe: a measurement tool's switch, not a product path.
+extern "C" int pcvae_kernel_timer(int enable) {
+    using namespace pcvae;
+    for (auto& t : timed()) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+    timed().clear();
+    g_timer_on = enable != 0;
+    return PCVAE_OK;
+}
+// -> number of timed launches so far; fills ms[i] / tags[i] for the first `cap` of them (synchronises on their stop events)
+extern "C" int pcvae_kernel_timer_read(float* ms, int* tags, int cap) {
+    using namespace pcvae;
+    int n = 0;
+    for (auto& t : timed()) {
+        if (n < cap && ms && tags) {
+            if (hipEventSynchronize(t.e1) != hipSuccess || hipEventElapsedTime(&ms[n], t.e0, t.e1) != hipSuccess) {
+                set_error("kernel_timer_read: event %d unreadable", n);
+                return PCVAE_ELAUNCH;
+            }
+            tags[n] = t.tag;
+        }
+        ++n;
+    }
+    return n;
+}
 
 extern "C" int pcvae_abi_version(void) { return PCVAE_ABI_VERSION; }
 extern "C" const char* pcvae_last_error(void) { return pcvae::g_err; }

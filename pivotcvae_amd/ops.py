@@ -668,10 +668,10 @@ class _MLPInto(torch.autograd.Function):
                 g = linear_bwd_input_raw(g, W, xact=acts[i])
             elif ctx.needs_input_grad[0]:
                 if ctx.grad_cols is not None and ctx.grad_cols < W.shape[1]:
+                    # the z-columns-only input gradient of the bottom layer is a sliver of a GEMM ([B, 256] x [256, Z]) and, like the
+                    # weight gradients, needs nothing but the chain's last g: it rides in THEIR launch instead of paying its own
                     full = torch.empty(g.shape[0], W.shape[1], dtype=F32, device=g.device)
-                    grp = GemmGroup()
-                    grp.dx(g, W, xact=None, out=full[:, :ctx.grad_cols], cols=ctx.grad_cols)
-                    grp.launch()
+                    dwg.dx(g, W, xact=None, out=full[:, :ctx.grad_cols], cols=ctx.grad_cols)
                     g = full
                 else:
                     g = linear_bwd_input_raw(g, W, xact=None)

@@ -243,7 +243,8 @@ def test_catalog_kernel_choice_and_range_alignment(monkeypatch):
     assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_F32) == 0
     assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_BF16) == 2      # config 4 on one GPU: 7 8xx tiles per range
     assert L.pcvae_catalog_ce_variant(10240, 1_000_000, 128, _hip.PREC_BF16) == 2      # one 8-GPU shard: 980 tiles per range
-    assert L.pcvae_catalog_ce_variant(40960, 100_000, 64, _hip.PREC_BF16) == 1         # config 3: 100 tiles per range
+    assert L.pcvae_catalog_ce_variant(40960, 100_000, 64, _hip.PREC_BF16) == 2         # config 3: 391 tiles per range (D = 64: pipelined from 256)
+    assert L.pcvae_catalog_ce_variant(40960, 20_000, 64, _hip.PREC_BF16) == 1          # a short catalog at D = 64
     assert L.pcvae_catalog_ce_variant(256, 8192, 128, _hip.PREC_BF16) == 1             # a small catalog
     assert L.pcvae_catalog_ce_variant(163840, 10_000_000, 256, _hip.PREC_BF16) == 2    # config 5
     assert L.pcvae_catalog_ce_variant(64, 1000, 256, _hip.PREC_BF16) == 2
