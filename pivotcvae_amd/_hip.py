@@ -18,6 +18,7 @@ PREC_F32, PREC_BF16, PREC_BF16X3, PREC_SCREENED = 0, 1, 2, 3
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
 GEMM_FWD, GEMM_DX, GEMM_DX_ACC, GEMM_DW = 0, 1, 2, 3
+GEMM_X3 = 0x100   # OR-ed into a problem's kind: bf16x3 arithmetic (include/pcvae.h: PCVAE_GEMM_X3)
 GEMM_GROUP_MAX = 6
 
 _c = ctypes

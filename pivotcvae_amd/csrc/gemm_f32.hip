@@ -38,6 +38,7 @@ using namespace pcvae;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -132,11 +133,23 @@ __device__ __forceinline__ void store_c(const GemmParams& p, int64_t m, int64_t 
 }
 
 // ---- 64 x 64 tile, LDS-DMA --------------------------------------------------------------------------------------------------
-template <bool A_KC, bool B_KC, int EPI>
+// X3 (round 3): the same tile, staging and epilogues, but the contraction runs on the bf16 matrix cores at fp32-EQUIVALENT precision:
+// every operand value v is split in registers into hi = RNE bf16(v), lo = RNE bf16(v - hi) and a product is three
+// v_mfma_f32_16x16x32_bf16 (hi*hi + lo*hi + hi*lo, fp32 accumulate; lo*lo dropped: 2^-18 relative) - the catalog kernel's bf16x3
+// arithmetic (catalog_x3.h) applied to the MLP stacks.  The fp32 LDS images are the SAME ones: with the k order
+// kset(g) = {4g .. 4g+3} u {16+4g .. 16+4g+3} (g = lane >> 4; any bijection of k is a valid order as long as both operands use
+// it) a lane's eight k values of a k-contiguous image are the two 16-byte chunks g and g+4 of its row, and the XOR swizzle
+// (row >> 1) & 7 makes those ds_read_b128 conflict-free for 16-row operand tiles as well (searched over the guide's b128 service
+// groups); a row-contiguous image is read with 8 ds_read_b32 whose two 32-lane halves hit disjoint bank halves (the 32-row
+// rotation of the lines with k bit 2 set).  A wave's 32 x 32 tile = 2 x 2 MFMA tiles of 16 x 16: 12 MFMAs of 16 cycles per
+// 32-deep chunk against 16 of 64 cycles for v_mfma_f32_32x32x2_f32 - the loop turns from matrix-pipe-bound to VALU-bound (the
+// splits: ~96 vector ops per chunk), about 2x faster on the large layers.
+template <bool A_KC, bool B_KC, int EPI, bool X3>
 __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx, const int by, const int bz, char* smem) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
+    const int c16 = lane & 15, gq = lane >> 4;   // X3: MFMA 16x16x32 lane coordinates
     const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
 
     int64_t kbeg = 0, kend = p.K;
@@ -147,9 +160,13 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
     const int nch = (int)((kend - kbeg + DK - 1) / DK);
     const bool ragged = ((kend - kbeg) % DK) != 0;
 
+    // one accumulator of 16 floats per lane either way: a 32 x 32 MFMA tile, or 2 x 2 tiles of 16 x 16 (acc4[rt][ct])
     f32x16 acc;
+    f32x4 acc4[2][2];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc4[0][0][i] = 0.f; acc4[0][1][i] = 0.f; acc4[1][0][i] = 0.f; acc4[1][1][i] = 0.f; }
     // EPI_DW: A(m, k) = dY[k][m]; the column sums of dY (bias gradient) are the k-sums of the A images this workgroup streams
     // anyway.  Only the workgroups of the first output column do it, 64 threads each.
     const bool do_bias = (EPI == EPI_DW) && p.bias_grad != nullptr && bx == 0 && threadIdx.x < BM;
@@ -208,6 +225,45 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             for (int k = 0; k < DK; ++k)
                 bsum += *reinterpret_cast<const float*>(sA + k * 256 + ((threadIdx.x ^ (((k >> 2) & 1) << 5)) << 2));
         }
+        if constexpr (X3) {
+            // operand tile t (16 rows) of this wave: eight k values kset(gq) of row 16 t + c16, then the hi / lo split
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+            auto fetch = [&](const char* img, const bool kc, const int row, bf16x8& hi, bf16x8& lo) {
+                float v[8];
+                if (kc) {
+                    const unsigned sw = (unsigned)((row >> 1) & 7);
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(img + row * 128 + ((((unsigned)gq) ^ sw) << 4));
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(img + row * 128 + ((((unsigned)gq + 4u) ^ sw) << 4));
+                    v[0] = q0[0]; v[1] = q0[1]; v[2] = q0[2]; v[3] = q0[3];
+                    v[4] = q1[0]; v[5] = q1[1]; v[6] = q1[2]; v[7] = q1[3];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = (e < 4 ? 4 * gq + e : 16 + 4 * gq + (e - 4));
+                        v[e] = *reinterpret_cast<const float*>(img + k * 256 + ((row ^ (((k >> 2) & 1) << 5)) << 2));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const __bf16 hv = (__bf16)v[e];
+                    hi[e] = hv;
+                    lo[e] = (__bf16)(v[e] - (float)hv);
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                fetch(sA, A_KC, wm * 32 + 16 * t + c16, ah[t], al[t]);
+                fetch(sB, B_KC, wn * 32 + 16 * t + c16, bh[t], bl[t]);
+            }
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], bh[ct], acc4[rt][ct], 0, 0, 0);
+                    acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bl[ct], acc4[rt][ct], 0, 0, 0);
+                    acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bh[ct], acc4[rt][ct], 0, 0, 0);
+                }
+        } else {
         float a[4][4], b[4][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -230,10 +286,20 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][j], b[g][j], acc, 0, 0, 0);
+        }
     }
 
-    // C/D map of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int64_t n = n0 + wn * 32 + li;
+    // Where a lane's 16 accumulator values sit in the wave's 32 x 32 tile (row dm, column dn):
+    //   32x32 MFMA : register r -> dm = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), dn = lane & 31
+    //   X3         : register r = 8 rt + 4 ct + i -> dm = 16 rt + 4 (lane >> 4) + i, dn = 16 ct + (lane & 15)
+    if constexpr (X3) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = acc4[r >> 3][(r >> 2) & 1][r & 3];
+    }
+    auto dm_of = [&](int r) { return X3 ? 16 * (r >> 3) + 4 * gq + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * h; };
+    auto dn_of = [&](int r) { return X3 ? 16 * ((r >> 2) & 1) + c16 : li; };
+
+    const int64_t nw = n0 + wn * 32, mw = m0 + wm * 32;   // origin of this wave's 32 x 32 tile
     if (EPI == EPI_DW) {
         // NO fp32 atomics on the output.  HIP's atomicAdd(float*) is an agent-scope global_atomic_add_f32 that the issuing XCD's L2
         // executes, and workgroups of different XCDs adding into one cache line lose updates (common.h: atomic_add_f32; the batch
@@ -298,28 +364,32 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             }
         }
         if (do_bias && m0 + tid < p.M) p.bias_grad[m0 + tid] += bsum;
-        if (n >= p.N) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < p.M) p.C[m * p.ldc + n] += acc[r];
+            const int64_t m = mw + dm_of(r), n = nw + dn_of(r);
+            if (m < p.M && n < p.N) p.C[m * p.ldc + n] += acc[r];
         }
         return;
     }
 
-    const float bias = (EPI == EPI_FWD && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    // (a lane's columns: one for the 32 x 32 MFMA tile, two - registers 0..3 | 8..11 and 4..7 | 12..15 - for X3)
+    float bias[2] = {0.f, 0.f};
+    if (EPI == EPI_FWD && p.bias) {
+        if (nw + dn_of(0) < p.N) bias[0] = p.bias[nw + dn_of(0)];
+        if (X3 && nw + dn_of(4) < p.N) bias[1] = p.bias[nw + dn_of(4)];
+    }
     if (rowsA == BM && rowsB == BN) {   // interior tile (workgroup-uniform): no per-row bounds
 #pragma unroll
-        for (int r = 0; r < 16; ++r) store_c<EPI>(p, m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n, acc[r], bias);
+        for (int r = 0; r < 16; ++r) store_c<EPI>(p, mw + dm_of(r), nw + dn_of(r), acc[r], bias[X3 ? (r >> 2) & 1 : 0]);
         return;
     }
-    if (n >= p.N) return;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M) store_c<EPI>(p, m, n, acc[r], bias);
+        const int64_t m = mw + dm_of(r), n = nw + dn_of(r);
+        if (m < p.M && n < p.N) store_c<EPI>(p, m, n, acc[r], bias[X3 ? (r >> 2) & 1 : 0]);
     }
 }
+
 
 // ---- small-M variant ------------------------------------------------------------------------------------------------------
 // A rank of the data-parallel job holds B/8 = 1024 slates: a [1024 x 256] layer is only 64 tiles of 64 x 64, a quarter
@@ -472,7 +542,7 @@ __device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int b
 // the register-staged small body's 150, set the occupancy of the launches that matter.)
 // (... and launches without a weight gradient - every forward and input-gradient launch - take an instantiation without that body:
 // its split reduction holds 64 more registers, the difference between five and four workgroups per CU.)
-template <bool SMALL, bool HAS_DW>
+template <bool SMALL, bool HAS_DW, bool X3 = false>
 __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int xcd = blockIdx.x & 7;
@@ -489,9 +559,9 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
         if (p.kind == KIND_FWD_S) gemm_tile_small<true, true, EPI_FWD>(p, bx, by, smem);
         else gemm_tile_small<true, false, EPI_DX>(p, bx, by, smem);
     } else {
-        if (p.kind == KIND_FWD) gemm_tile_dma<true, true, EPI_FWD>(p, bx, by, bz, smem);
-        else if (p.kind == KIND_DX || !HAS_DW) gemm_tile_dma<true, false, EPI_DX>(p, bx, by, bz, smem);
-        else gemm_tile_dma<false, false, EPI_DW>(p, bx, by, bz, smem);
+        if (p.kind == KIND_FWD) gemm_tile_dma<true, true, EPI_FWD, X3>(p, bx, by, bz, smem);
+        else if (p.kind == KIND_DX || !HAS_DW) gemm_tile_dma<true, false, EPI_DX, X3>(p, bx, by, bz, smem);
+        else gemm_tile_dma<false, false, EPI_DW, X3>(p, bx, by, bz, smem);
     }
 }
 
@@ -509,7 +579,7 @@ static int check_desc(const pcvae_gemm_desc& d) {
                   (long long)d.K);
     // a tile's DMA lane offsets are 32-bit byte offsets from the tile origin: 64 rows (or 32 k lines) of ld floats
     PCVAE_REQUIRE(d.lda < (1LL << 22) && d.ldb < (1LL << 22), "linear: leading dimension too large");
-    switch (d.kind) {
+    switch (d.kind & ~PCVAE_GEMM_X3) {
         case PCVAE_GEMM_FWD:
             PCVAE_REQUIRE(d.lda >= d.K && d.ldb >= d.K && d.ldc >= d.N, "linear_fwd: bad leading dimension");
             PCVAE_REQUIRE(d.act == PCVAE_ACT_NONE || d.act == PCVAE_ACT_LEAKY || d.act == PCVAE_ACT_RELU,
@@ -558,7 +628,7 @@ constexpr size_t CNT_REGION = 65536;
 static size_t group_ws_bytes(const pcvae_gemm_desc* descs, int n) {
     size_t cnt = 0, part = 0;
     for (int i = 0; i < n; ++i) {
-        if (descs[i].kind != PCVAE_GEMM_DW || descs[i].M <= 0) continue;
+        if ((descs[i].kind & ~PCVAE_GEMM_X3) != PCVAE_GEMM_DW || descs[i].M <= 0) continue;
         const DwPlan pl = dw_plan(descs[i], true);
         cnt += (size_t)pl.nx * pl.ny;
         if (pl.nz > 1) part += ((size_t)pl.nx * pl.ny * pl.nz * 4096 + (size_t)pl.ny * pl.nz * 64) * sizeof(float);
@@ -572,9 +642,16 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     GroupParams gp;
     gp.n = 0;
     int64_t tiles64 = 0;
-    bool has_dw = false;
+    bool has_dw = false, x3 = true;   // bf16x3 arithmetic: only if EVERY problem of the launch asks for it (one kernel per launch)
+    pcvae_gemm_desc local[MAXG];
     for (int i = 0; i < n; ++i) {
         if (int rc = check_desc(descs[i])) return rc;
+        local[i] = descs[i];
+        x3 = x3 && (local[i].kind & PCVAE_GEMM_X3) != 0;
+        local[i].kind &= ~PCVAE_GEMM_X3;
+    }
+    descs = local;
+    for (int i = 0; i < n; ++i) {
         const pcvae_gemm_desc& d = descs[i];
         if (d.M == 0) continue;
         has_dw |= d.kind == PCVAE_GEMM_DW;
@@ -633,10 +710,16 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     }
     if (gp.n == 0) return PCVAE_OK;
     PCVAE_REQUIRE(total * 8 < (1LL << 31), "linear_group: launch too large");
-    if (small)
+    if (small)   // (the K-split 32 x 32 tiles of small launches stay in exact f32: they are launch-bound, not MFMA-bound)
         hipLaunchKernelGGL((gemm_group_kernel<true, false>), dim3((unsigned)(total * 8)), dim3(256), SMALL_LDS, as_stream(stream), gp);
+    else if (has_dw && x3)
+        hipLaunchKernelGGL((gemm_group_kernel<false, true, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+                           as_stream(stream), gp);
     else if (has_dw)
         hipLaunchKernelGGL((gemm_group_kernel<false, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+                           as_stream(stream), gp);
+    else if (x3)
+        hipLaunchKernelGGL((gemm_group_kernel<false, false, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
                            as_stream(stream), gp);
     else
         hipLaunchKernelGGL((gemm_group_kernel<false, false>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, GEMM_DW, GEMM_DX, GEMM_DX_ACC, GEMM_FWD, GEMM_GROUP_MAX, PREC_BF16, PREC_BF16X3,
+from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, GEMM_DW, GEMM_DX, GEMM_DX_ACC, GEMM_FWD, GEMM_GROUP_MAX, GEMM_X3, PREC_BF16, PREC_BF16X3,
                    PREC_F32, PREC_SCREENED, GemmDesc, check, lib, ptr, require_device, stream)
 
 F32 = torch.float32
@@ -151,7 +151,41 @@ def _timed_gemm(flops, launch):
     t[1](tok, flops, 1)
 
 
+# Arithmetic of the MLP GEMMs: exact fp32 MFMA (default: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain) or bf16x3 (operands split
+# into bf16 hi + lo in registers, three bf16 MFMAs per product, fp32 accumulate - fp32-equivalent at the GEMM tests' tolerances,
+# ~2x faster on the MFMA-bound layers; csrc/gemm_f32.hip).  A model sets it around its forward (BaseCVAE.set_mlp_precision); an
+# autograd node remembers the arithmetic of its forward and runs its backward in the same one.
+_MLP_X3 = False
+
+
+class mlp_arith:
+    """``with mlp_arith(True):`` the GEMMs launched inside run in bf16x3 (False: exact fp32)"""
+
+    def __init__(self, x3):
+        self.x3 = bool(x3)
+
+    def __enter__(self):
+        global _MLP_X3
+        self.prev, _MLP_X3 = _MLP_X3, self.x3
+        return self
+
+    def __exit__(self, *exc):
+        global _MLP_X3
+        _MLP_X3 = self.prev
+        return False
+
+
+def _one(build):
+    """a single GEMM through the grouped entry point (the only one that carries the bf16x3 flag)"""
+    grp = GemmGroup()
+    out = build(grp)
+    grp.launch()
+    return out
+
+
 def linear_fwd_raw(x, W, b, act, out=None):
+    if _MLP_X3:
+        return _one(lambda g: g.fwd(x, W, b, act, out=out))
     x = _c2d(x)
     M, K = x.shape
     N = W.shape[0]
@@ -166,6 +200,8 @@ def linear_fwd_raw(x, W, b, act, out=None):
 
 
 def linear_bwd_input_raw(gy, W, xact=None, out=None):
+    if _MLP_X3:
+        return _one(lambda g: g.dx(gy, W, xact=xact, out=out))
     gy = _c2d(gy)
     M, N = gy.shape
     K = W.shape[1]
@@ -193,9 +229,10 @@ class GemmGroup:
 
     def __init__(self):
         self.descs, self.keep, self.flops = [], [], 0.0
+        self.x3 = _MLP_X3
 
     def _add(self, kind, act, a, b, c, aux, aux_out, M, N, K):
-        d = GemmDesc(kind, act, a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), c.data_ptr(), _ld(c),
+        d = GemmDesc(kind | (GEMM_X3 if self.x3 else 0), act, a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), c.data_ptr(), _ld(c),
                      aux.data_ptr() if aux is not None else None, (_ld(aux) if aux is not None and aux.dim() == 2 else 0),
                      aux_out.data_ptr() if aux_out is not None else None, M, N, K)
         for x in (a, b, c, aux, aux_out):
@@ -262,6 +299,7 @@ class _MLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, last_linear, *params):
+        ctx.x3 = _MLP_X3
         with gemm_span():
             return _MLP._forward_impl(ctx, x, last_linear, *params)
 
@@ -286,7 +324,7 @@ class _MLP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        with gemm_span():
+        with gemm_span(), mlp_arith(ctx.x3):
             return _MLP._backward_impl(ctx, g)
 
     @staticmethod
@@ -319,6 +357,8 @@ class _MLP(torch.autograd.Function):
 
 def linear_bwd_input_acc_raw(gy, W, xact, out):
     """out = (out + gy @ W) * LeakyReLU'(xact)   (xact may be None: no mask)."""
+    if _MLP_X3:
+        return _one(lambda g: g.dx(gy, W, xact=xact, out=out, accumulate=True))
     gy = _c2d(gy)
     M, N = gy.shape
     K = W.shape[1]
@@ -338,6 +378,7 @@ class _MLPHeads(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_trunk, *params):
+        ctx.x3 = _MLP_X3
         with gemm_span():
             return _MLPHeads._forward_impl(ctx, x, n_trunk, *params)
 
@@ -361,7 +402,7 @@ class _MLPHeads(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ga, gb):
-        with gemm_span():
+        with gemm_span(), mlp_arith(ctx.x3):
             return _MLPHeads._backward_impl(ctx, ga, gb)
 
     @staticmethod
@@ -474,6 +515,7 @@ class _StacksPacked(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, *tensors):
+        ctx.x3 = _MLP_X3
         with gemm_span():
             return _StacksPacked._forward_impl(ctx, spec, *tensors)
 
@@ -507,7 +549,7 @@ class _StacksPacked(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gs):
-        with gemm_span():
+        with gemm_span(), mlp_arith(ctx.x3):
             return _StacksPacked._backward_impl(ctx, *gs)
 
     @staticmethod
@@ -621,6 +663,7 @@ class _MLPInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, out_buf, col0, grad_cols, *params):
+        ctx.x3 = _MLP_X3
         with gemm_span():
             return _MLPInto._forward_impl(ctx, x, out_buf, col0, grad_cols, *params)
 
@@ -645,7 +688,7 @@ class _MLPInto(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        with gemm_span():
+        with gemm_span(), mlp_arith(ctx.x3):
             return _MLPInto._backward_impl(ctx, g)
 
     @staticmethod
@@ -707,12 +750,14 @@ class _DenseScores(torch.autograd.Function):
     def forward(ctx, rx, E):
         require_device(rx, E)
         ctx.save_for_backward(E)
-        return linear_fwd_raw(rx, E, None, ACT_NONE)
+        with mlp_arith(False):   # the dense logits a caller asks for are the exact fp32 ones, whatever the stacks compute in
+            return linear_fwd_raw(rx, E, None, ACT_NONE)
 
     @staticmethod
     def backward(ctx, g):
         (E,) = ctx.saved_tensors
-        return linear_bwd_input_raw(g, E), None
+        with mlp_arith(False):
+            return linear_bwd_input_raw(g, E), None
 
 
 def dense_scores(rx, E):

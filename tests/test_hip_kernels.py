@@ -886,3 +886,68 @@ def test_split_hand_off_stress_two_thousand_grouped_launches(ops):
             for rep in range(1, REPS):
                 assert torch.equal(yf[rep], yf[0])
     assert launches >= 2000 and max_splits == 64
+
+
+@pytest.mark.parametrize("tiles", ["default", "dma_tiles_only"])
+def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
+    """Round 3: the MLP GEMMs in bf16x3 (ops.mlp_arith(True): operands split into bf16 hi + lo in registers, three bf16 MFMAs per
+    product, fp32 accumulate) - forward, input gradient (plain / accumulating / LeakyReLU-masked), weight + bias gradient, alone
+    and grouped, ragged everything, against fp64.  Tolerance: rtol 1e-4 as for the exact-f32 kernel; the absolute term is 3x the
+    f32 kernel's: an operand carries 16 mantissa bits (hi + lo), so a product is good to ~6e-6 relative (fp32: 6e-8) and a sum of
+    n such products to ~6e-6 sqrt(n) |typical product| - measured 4.6e-4 on the 8192-slate weight gradient of enc_1 with
+    uniform(-1, 1) operands, i.e. 1.5e-5 of the tensor's scale (the catalog bf16x3 kernel's gradient is held to 2e-5 of scale).
+    With PCVAE_GEMM_SMALL_BELOW=0 every launch takes the 64 x 64 tiles, i.e. the bf16x3 body (small launches otherwise run the
+    f32 K-split tiles, whatever was asked)."""
+    import random
+    if tiles == "dma_tiles_only":
+        monkeypatch.setenv("PCVAE_GEMM_SMALL_BELOW", "0")
+    rng = random.Random(4321)
+    shapes = [(8192, 256, 1419), (4096, 1152, 256), (2048, 32, 256)]
+    for _ in range(24):
+        shapes.append((rng.choice([1, 31, 64, 65, 200, 1000, 1300, 2100]), rng.choice([1, 16, 33, 64, 65, 130, 256]),
+                       rng.choice([1, 7, 32, 33, 64, 97, 283, 300])))
+    with ops.mlp_arith(True):
+        for case, (M, N, K) in enumerate(shapes):
+            padx, pady = rng.choice([0, 1, 3]), rng.choice([0, 5])
+            xb, Wb = rnd(M, K + padx, seed=1100 + case), rnd(N, K, seed=1200 + case, scale=0.3)
+            b, g = rnd(N, seed=1300 + case), rnd(M, N + pady, seed=1400 + case)
+            xd, Wd, bd, gd = xb.to(DEV)[:, padx:], Wb.to(DEV), b.to(DEV), g.to(DEV)[:, :N]
+            x64, W64, g64 = xb[:, padx:].double(), Wb.double(), g[:, :N].double()
+            tol = dict(rtol=1e-4, atol=6e-5 * max(1.0, (max(K, N, M) / 64.0) ** 0.5))
+            y64 = x64 @ W64.t() + b.double()
+            want_y = torch.nn.functional.leaky_relu(y64, 0.01).float()
+            y = ops.linear_fwd_raw(xd, Wd, bd, 1)
+            torch.testing.assert_close(y.cpu(), want_y, **tol)
+            torch.testing.assert_close(ops.linear_bwd_input_raw(gd, Wd).cpu(), (g64 @ W64).float(), **tol)
+            xact = rnd(M, K, seed=1500 + case).to(DEV)   # LeakyReLU mask keyed on another activated tensor
+            want_m = ((g64 @ W64) * torch.where(xact.cpu().double() > 0, 1.0, 0.01)).float()
+            torch.testing.assert_close(ops.linear_bwd_input_raw(gd, Wd, xact=xact).cpu(), want_m, **tol)
+            acc = torch.full((M, K), 0.25, device=DEV)
+            ops.linear_bwd_input_acc_raw(gd, Wd, None, acc)
+            torch.testing.assert_close(acc.cpu(), (g64 @ W64 + 0.25).float(), **tol)
+            outs = []
+            for rep in range(2):
+                grp = ops.GemmGroup()
+                assert grp.x3
+                dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+                ybuf = torch.full((M, N + 3), 9.0, device=DEV)
+                grp.dw(gd, xd, dW, db)
+                grp.fwd(xd, Wd, bd, 0, out=ybuf[:, 3:])
+                grp.launch()
+                outs.append((dW, db, ybuf))
+            torch.testing.assert_close(outs[0][0].cpu(), (g64.t() @ x64).float(), **tol)
+            torch.testing.assert_close(outs[0][1].cpu(), g64.sum(0).float(), **tol)
+            torch.testing.assert_close(outs[0][2][:, 3:].cpu(), y64.float(), **tol)
+            assert torch.equal(outs[0][2][:, :3], torch.full((M, 3), 9.0, device=DEV))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # bitwise reproducible
+    assert not ops.GemmGroup().x3
+    # the two arithmetics really differ (the flag reaches the kernel) and agree to fp32-equivalent accuracy on a large layer
+    M, N, K = 4096, 256, 1419
+    xd, Wd = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=0.1).to(DEV)
+    y32 = ops.linear_fwd_raw(xd, Wd, None, 0)
+    with ops.mlp_arith(True):
+        y3 = ops.linear_fwd_raw(xd, Wd, None, 0)
+    y64 = xd.double() @ Wd.double().t()
+    e32, e3 = (y32.double() - y64).abs().max().item(), (y3.double() - y64).abs().max().item()
+    scale = y64.abs().max().item()
+    assert not torch.equal(y32, y3) and e32 < 2e-6 * scale and e3 < 2e-5 * scale, (e32, e3, scale)
