@@ -382,6 +382,10 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
     if eval_fn is None:
         eval_fn = lambda m: recommendation_test(m, resp_model, bs, n_test_trial=n_test_trial, seed=seed)
 
+    dropped = sum((min(bs, L - lo) % world) for lo in range(0, L, bs))
+    if dropped:   # runs at different world sizes see the same slates only if every batch divides
+        log(f"data parallel over {world} ranks: {dropped} of {L} training slates per epoch are cut (batches are trimmed to a multiple "
+            f"of the world size)")
     gen = torch.Generator(device=device)
     best_val = float("inf")
     temper = 2
@@ -405,6 +409,8 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
             n_batches += 1
         history["train"].append(float(acc) / max(n_batches, 1))
         log("train loss: " + str(history["train"][-1]))
+        if epoch == 0 and getattr(trainer, "capture_failed", None):
+            log("hipGraph capture was asked for and failed (" + trainer.capture_failed + "): every step is launched eagerly")
 
         # validation: every rank evaluates its slice of each batch; the sums are combined once
         sums = torch.zeros(4, dtype=torch.float64, device=device)   # loss, rec, kld, batches

@@ -5,14 +5,21 @@ headline kernel from the PMC passes (with the gfx950 FETCH_SIZE x2 correction) t
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles")
 names = {"bench.json": f"{rnd}_config4_bench.json"}
-for a in ("x3_config4", "f32_config4", "bf16_config4", "nneg_config4", "bf16_config3", "bf16_config5"):
+for a in ("x3_config4", "f32_config4", "bf16_config4", "nneg_config4", "bf16_config3", "bf16_config5", "f32_config2", "f32_config1"):
     names[f"{a}_kernel_stats.csv"] = f"{rnd}_{a}_kernel_stats.csv"
     names[f"{a}_bench_under_rocprof.json"] = f"{rnd}_{a}_bench_under_rocprof.json"
 for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ1", "SQ2"):
     names[f"x3_config4_pmc_{n}.csv"] = f"{rnd}_x3_config4_pmc_{n}.csv"
+for n in ("FETCH_SIZE", "WRITE_SIZE"):
+    names[f"nneg_config4_pmc_{n}.csv"] = f"{rnd}_nneg_config4_pmc_{n}.csv"
+    names[f"gather_pmc_{n}.csv"] = f"{rnd}_gather_pmc_{n}.csv"
+names["gather_kernel_stats.csv"] = f"{rnd}_gather_kernel_stats.csv"
+names["gather_kernel_timer.txt"] = f"{rnd}_gather_kernel_timer.txt"
+for a in ("f32_config2", "bf16_config3", "bf16x3_config4"):
+    names[f"{a}_step_launches.txt"] = f"{rnd}_{a}_step_launches.txt"
 for a, b in names.items():
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, b))
@@ -49,5 +56,20 @@ t["_source"] = {
                              "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES") if k in c},
     "derived": {"gpu_cycles_per_launch": cycles, "clock_GHz_under_load": cycles / avg_ns, "mfma_issued": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 16,
                 "mfma_pipe_utilisation": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cycles)}}
+# the sparse kernel (n_neg = 1000): the L2's memory-side bytes per launch (Infinity-Cache hits included on gfx950)
+try:
+    cn = {}
+    for n in ("FETCH_SIZE", "WRITE_SIZE"):
+        for r in csv.DictReader(open(os.path.join(src, f"nneg_config4_pmc_{n}.csv"))):
+            if "catalog_ce_sparse" in r["kernel"]:
+                cn[n] = float(r["mean_per_dispatch"])
+    # FETCH_SIZE x2: the gather reads rows with 16-byte-per-lane loads of whole 512-B rows, the access class the guide calibrated
+    t["config4_nneg1000_gpus1"] = cn["FETCH_SIZE"] * 1024 * 2 + cn["WRITE_SIZE"] * 1024
+    t["_nneg_source"] = {"round": rnd, "kernel": "catalog_ce_sparse_kernel<128>", "FETCH_SIZE_KB_mean": cn["FETCH_SIZE"],
+                         "WRITE_SIZE_KB_mean": cn["WRITE_SIZE"], "fetch_correction": "x2 (16 B/lane row reads)",
+                         "note": "L2 memory-side requests (TCC_EA0_RDREQ/WRREQ): Infinity-Cache hits are counted, so this is an upper "
+                                 "bound of the HBM traffic; requested by the kernel: R (n_neg + 1) 4 D = 42 GB per launch"}
+except (OSError, KeyError) as e:
+    print("no sparse-kernel counters:", e)
 json.dump(t, open(tpath, "w"), indent=1)
 print(json.dumps(t["_source"]["derived"], indent=1), t["config4_bf16x3_gpus1"])

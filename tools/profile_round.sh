@@ -5,7 +5,7 @@
 #      and the other arithmetics / modes the same way                         -> f32_, bf16_, nneg_ _config4_kernel_stats.csv
 #   3. separate --pmc passes (kernel-trace only) for HBM traffic and SQ        -> x3_config4_pmc_<set>.csv (per-kernel means)
 #   4. kernel stats of config 3 and config 5 (their stated arithmetic: bf16)
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
@@ -37,6 +37,30 @@ pmc FETCH_SIZE "FETCH_SIZE"
 pmc WRITE_SIZE "WRITE_SIZE"
 pmc SQ1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 pmc SQ2 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT"
+# round 3: memory-side counters of the SPARSE kernel (the reference's default n_neg = 1000 mode)
+pmcn() {
+  rm -rf $OUT/pmcn_$1
+  timeout -k 10 600 rocprofv3 --pmc $1 --kernel-trace --output-format csv -d $OUT/pmcn_$1 -- python3 $ROOT/bench.py --n_neg 1000 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-variants > $OUT/pmcn_$1.log 2>&1
+  python3 $ROOT/tools/summarize_pmc.py $OUT/pmcn_$1 > $OUT/nneg_config4_pmc_$1.csv
+  rm -rf $OUT/pmcn_$1
+  echo "[pmc nneg] $1 done" | tee -a $OUT/progress.log
+}
+pmcn FETCH_SIZE
+pmcn WRITE_SIZE
+stats f32_config2 --config 2 --steps 20 --warmup 5 --no-variants --no-graph
+stats f32_config1 --config 1 --steps 20 --warmup 5 --no-variants --no-graph --no-extras
 stats bf16_config3 --config 3 --steps 5 --warmup 2 --no-variants
 stats bf16_config5 --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-variants
+# one traced EAGER step per config: the launch listing (tools/step_trace_list.py)
+for spec in "2 1024 f32" "3 4096 bf16" "4 8192 bf16x3"; do
+  set -- $spec
+  rm -rf $OUT/t
+  timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $ROOT/tools/step_trace_run.py $1 $2 $3 8 > $OUT/t$1.log 2>&1 &&
+  python3 $ROOT/tools/step_trace_list.py $(find $OUT/t -name "*kernel_trace.csv") > $OUT/$3_config$1_step_launches.txt
+  rm -rf $OUT/t
+  echo "[trace] config $1 done" | tee -a $OUT/progress.log
+done
+bash $ROOT/tools/profile_gather.sh > $OUT/gather_profile.log 2>&1
+cp $ROOT/gpurun_out/prof_gather/plain.txt $OUT/gather_kernel_timer.txt
+cp $ROOT/gpurun_out/prof_gather/gather_kernel_stats.csv $ROOT/gpurun_out/prof_gather/gather_pmc_FETCH_SIZE.csv $ROOT/gpurun_out/prof_gather/gather_pmc_WRITE_SIZE.csv $OUT/
 ls -la $OUT
