@@ -91,7 +91,7 @@ def kernel_name(R, N, D, dtype):
         D = ops.x3_width(D)    # narrower tables run the 128-wide kernel on zero columns
     v = _hip.lib().pcvae_catalog_ce_variant(R, N, D, _hip.PREC_NAMES[dtype])
     return {0: f"catalog_ce_f32_kernel<{D}>", 1: f"catalog_ce_bf16_fast_kernel<{D}>",
-            2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>", 3: f"catalog_ce_x3_pipe_kernel<{D}, 2>"}.get(v, "?")
+            2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>", 3: f"catalog_ce_x3_pipe_kernel<{D}, {1 if D == 256 else 2}>"}.get(v, "?")
 
 
 TIMER_GATHER, TIMER_ASSEMBLE = 1, 2   # include/pcvae.h: PCVAE_TIMER_*

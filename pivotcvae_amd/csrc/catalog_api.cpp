@@ -17,7 +17,7 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
         need = std::max(need, std::max(ce, am) + (size_t)pl.nrb + 64);
     }
     need = std::max(need, (size_t)R * (8 + 4 + 4 + 64 * 4) + 64);  // screened argmax: keys, thresholds, <= 64 partial maxima
-    if (D == 128) need = std::max(need, catalog_x3_ws_bytes(R, N, D));
+    if (D == 128 || D == 256) need = std::max(need, catalog_x3_ws_bytes(R, N, D));
     return need + 256;
 }
 
@@ -31,7 +31,7 @@ size_t pcvae::catalog_x3_ws_bytes(int64_t R, int64_t N, int D) {
 extern "C" int pcvae_catalog_ce_variant(int64_t R, int64_t N, int D, int prec) {
     if (R <= 0 || N <= 0 || !supported_d(D)) return -1;
     if (prec == PCVAE_PREC_F32) return 0;
-    if (prec == PCVAE_PREC_BF16X3) return D == 128 ? 3 : -1;
+    if (prec == PCVAE_PREC_BF16X3) return (D == 128 || D == 256) ? 3 : -1;
     if (prec != PCVAE_PREC_BF16 || (D != 64 && D != 128 && D != 256)) return -1;
     return catalog_bf16_pipelined(D, catalog_plan(R, N, D, PCVAE_PREC_BF16).tiles_per_split) ? 2 : 1;
 }
@@ -73,8 +73,8 @@ extern "C" int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E
     if (prec == PCVAE_PREC_BF16X3) {
         // E = the [N, 2 D] bf16 hi | lo image (pcvae_split_bf16x2), E_lo = the fp32 table itself (exact target logit / target
         // row, and the exact f32 kernel for masked calls and for row blocks whose norms rule out the max-free kernel)
-        PCVAE_REQUIRE(D == 128 && E_lo && ((uintptr_t)E_lo % 16 == 0) && e_max_norm > 0.f,
-                      "catalog_ce(bf16x3): needs D = 128, the fp32 table in E_lo and e_max_norm > 0");
+        PCVAE_REQUIRE((D == 128 || D == 256) && E_lo && ((uintptr_t)E_lo % 16 == 0) && e_max_norm > 0.f,
+                      "catalog_ce(bf16x3): needs D = 128 or 256, the fp32 table in E_lo and e_max_norm > 0");
         if (keep_mask || keep_prob < 1.0f)
             return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E_lo), N, D, target, keep_prob, seed, row_offset,
                                   keep_mask, nll, lse, dx, dx_scale, ws, as_stream(stream));

@@ -1275,6 +1275,8 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
         t = 1;
         // steady state: TR slots per trip, every LDS offset an immediate
         for (; PG::DUMMY ? (t + TR <= T) : ((t + TR - 1) / SUB + 3 <= Cn - 1); t += TR) {
+            pipe_fence();   // loop entry: hipcc's preheader copies of the loop-carried values (plain v_mov's) need wait states before the
+                            // first asm MFMA reads them (catalog_x3.h, round 3: a stale fragment in the first MFMA of the first trip)
 #define PCVAE_P2(UU)                                                                                                      \
             if constexpr (UU < TR) {                                                                                      \
                 constexpr int TL = 1 + UU, TG = UU, TN = 2 + UU;                                                          \
@@ -1302,6 +1304,8 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
         constexpr bool REM_FAST = D == 64;
         if constexpr (!SPLIT_REM) {
         for (; REM_FAST && t + TR2 <= T; t += TR2) {
+            pipe_fence();   // loop entry: hipcc's preheader copies of the loop-carried values (plain v_mov's) need wait states before the
+                            // first asm MFMA reads them (catalog_x3.h, round 3: a stale fragment in the first MFMA of the first trip)
 #define PCVAE_P2R(UU)                                                                                                     \
             if constexpr (UU < TR2) {                                                                                     \
                 constexpr bool SEAM = ((1 + UU) % SUB) == SUB - 1;                                                        \
@@ -1941,6 +1945,8 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
         }
         int t = 1;
         for (; t + TR <= T; t += TR) {   // steady state: every LDS offset an immediate
+            pipe_fence();   // loop entry: hipcc's preheader copies of the loop-carried values (plain v_mov's) need wait states before the
+                            // first asm MFMA reads them (catalog_x3.h, round 3: a stale fragment in the first MFMA of the first trip)
 #define PCVAE_SP(UU)                                                                                                      \
             if constexpr (UU < TR) {                                                                                      \
                 constexpr int TL = 1 + UU, TN = 2 + UU;                                                                   \
@@ -2048,14 +2054,11 @@ __global__ void catalog_screen_decode_kernel(ScreenParams p, int64_t* __restrict
 
 namespace pcvae {
 
-int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
-                  const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
-    if (D != 128) {
-        set_error("catalog_ce(bf16x3): D=%d (the kernel exists for D = 128)", D);
-        return PCVAE_EINVAL;
-    }
-    constexpr int CT = X3_CT;
-    using XG = X3Geo<128, CT>;
+template <int D>
+static int launch_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, float e_max_norm,
+                        const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
+    constexpr int CT = x3_ct(D);
+    using XG = X3Geo<D, CT>;
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16X3);
     CatParamsB p{};
     p.rx = rx; p.E = Ex; p.target = target; p.R = R; p.N = N; p.dx_scale = dx_scale;
@@ -2066,25 +2069,34 @@ int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* E
     p.pU = p.pl + ns * R;
     uint8_t* flags = reinterpret_cast<uint8_t*>(p.pU + ns * R * D);   // [nrb] behind the partials
     // row blocks whose logit bound allows raw exp2 run the max-free bf16x3 kernel; the others (flag 1) the exact f32 kernel
-    hipLaunchKernelGGL((catalog_row_bound_kernel<128>), dim3((unsigned)p.nrb), dim3(256), 0, st, rx, R, e_max_norm, flags);
+    hipLaunchKernelGGL((catalog_row_bound_kernel<D>), dim3((unsigned)p.nrb), dim3(256), 0, st, rx, R, e_max_norm, flags);
     p.safe_flags = flags;
-    constexpr int lds_pipe = XG::NB * 16384;
+    constexpr int lds_pipe = XG::NB * XG::CB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_x3_pipe_kernel<128, CT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_x3_pipe_kernel<D, CT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
         attr_set = true;
     }
     const dim3 grid((unsigned)(cdiv(R, XG::ROWS) * p.nsplit));
-    hipLaunchKernelGGL((catalog_ce_x3_pipe_kernel<128, CT>), grid, dim3(256), lds_pipe, st, p);
+    hipLaunchKernelGGL((catalog_ce_x3_pipe_kernel<D, CT>), grid, dim3(256), lds_pipe, st, p);
     int rc = check_launch("catalog_ce_x3");
     if (rc != PCVAE_OK) return rc;
-    hipLaunchKernelGGL((catalog_ce_merge_x3_kernel<128>), dim3((unsigned)cdiv(R, 4)), dim3(256), 0, st, p, Ef, nll, lse, dx);
+    hipLaunchKernelGGL((catalog_ce_merge_x3_kernel<D>), dim3((unsigned)cdiv(R, 4)), dim3(256), 0, st, p, Ef, nll, lse, dx);
     rc = check_launch("catalog_ce_merge_x3");
     if (rc != PCVAE_OK) return rc;
     // flagged row blocks (normally none): the exact f32 kernel on its own partials behind the flags, rows of flag 1 only
     char* ws2 = reinterpret_cast<char*>(flags) + ((p.nrb + 255) / 256) * 256;
     return catalog_ce_f32_flagged(rx, R, Ef, N, D, target, nll, lse, dx, dx_scale, ws2, flags, st);
+}
+
+// Ex: the bf16x3 table image (pcvae_split_bf16x2): D / 128 images of [N, 256] bf16, image i = hi | lo of dims 128 i .. 128 i + 127
+int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
+                  const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
+    if (D == 128) return launch_ce_x3<128>(rx, R, Ex, Ef, N, e_max_norm, target, nll, lse, dx, dx_scale, ws, st);
+    if (D == 256) return launch_ce_x3<256>(rx, R, Ex, Ef, N, e_max_norm, target, nll, lse, dx, dx_scale, ws, st);
+    set_error("catalog_ce(bf16x3): D=%d (the kernel exists for D = 128 and 256)", D);
+    return PCVAE_EINVAL;
 }
 
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,

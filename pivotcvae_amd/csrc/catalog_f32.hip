@@ -441,6 +441,7 @@ int catalog_ce_f32_flagged(const float* rx, int64_t R, const float* E, int64_t N
     p.pl = p.pm + (int64_t)pl.nsplit * R;
     p.pU = p.pl + (int64_t)pl.nsplit * R;
     if (D == 128) return launch_ce<128>(p, MASK_NONE, dx != nullptr, nll, lse, dx, st);
+    if (D == 256) return launch_ce<256>(p, MASK_NONE, dx != nullptr, nll, lse, dx, st);
     set_error("catalog_ce_f32_flagged: D=%d", D);
     return PCVAE_EINVAL;
 }

@@ -8,6 +8,10 @@
 #ifndef X3_CT
 #define X3_CT 2   // column tiles of 16 rows per wave of the bf16x3 kernel: 32 rows per wave, 128 per workgroup (3 and 4 spill: DESIGN 3.1b)
 #endif
+#ifndef X3_CT256
+#define X3_CT256 1   // D = 256: 16 rows per wave, 64 per workgroup (U alone is 128 accumulator registers at 32 rows: hipcc then spills)
+#endif
+static inline constexpr int x3_ct(int D) { return D == 256 ? X3_CT256 : X3_CT; }
 
 namespace pcvae {
 
@@ -35,7 +39,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // Ranges stay long enough that the per-range prologue (rx fragments) and epilogue (partials) are amortised.
     const int64_t slots = 256 * (f32 ? 2 : 1);
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
-    const int64_t nblk = x3 ? cdiv(R, 64 * X3_CT) : ((!f32 && D == 256) ? cdiv(R, 128) : p.nrb);
+    const int64_t nblk = x3 ? cdiv(R, 64 * x3_ct(D)) : ((!f32 && D == 256) ? cdiv(R, 128) : p.nrb);
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
     int64_t best_cost = -1;
     for (int64_t ns = 1; ns <= cap; ++ns) {
@@ -58,10 +62,12 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
         p.tiles_per_split = (int)tps;
         p.nsplit = (int)cdiv(p.ntiles, tps);
     }
-    // bf16x3: one fill slot + steady-state trips of 6 slots; 6k+1 tiles leave no fenced slot at all
+    // bf16x3: one fill slot + steady-state trips of 6 slots (4 at D = 256: two ring chunks per slot); 6k+1 (4k+1) tiles leave no
+    // fenced slot at all
     if (x3 && p.tiles_per_split >= 64) {
+        const int64_t trip = D == 256 ? 4 : 6;
         int64_t tps = p.tiles_per_split;
-        tps += ((1 - tps % 6) + 6) % 6;
+        tps += ((1 - tps % trip) + trip) % trip;
         p.tiles_per_split = (int)tps;
         p.nsplit = (int)cdiv(p.ntiles, tps);
     }

@@ -823,22 +823,26 @@ extern "C" int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint1
     return check_launch("split_bf16");
 }
 
-// [N, D] fp32 -> [N, 2 D] bf16: row n = hi(E_n) | lo(E_n), the table image of the bf16x3 catalog kernel (an item's hi and lo
-// halves are one contiguous 4 D-byte row: one LDS-DMA stream, k-steps 0 .. D/32-1 multiply the hi half, the rest the lo half)
+// [N, D] fp32 -> the table image of the bf16x3 catalog kernel.  D <= 128: [N, 2 D] bf16, row n = hi(E_n) | lo(E_n) (an item's hi
+// and lo halves are one contiguous 4 D-byte row: one LDS-DMA stream, k-steps 0 .. D/32-1 multiply the hi half, the rest the lo
+// half).  D = 256: TWO such images of 128 dims back to back, [2][N][256]: image i = hi | lo of dims 128 i .. 128 i + 127 (each
+// image has the 512-byte rows of the D = 128 kernel; a slot of the D = 256 kernel walks both).
 __global__ void split_bf16x2_kernel(const float* __restrict__ src, int64_t N, int D, uint16_t* __restrict__ out) {
     const int64_t n = N * (int64_t)D;
+    const int W = D > 128 ? 128 : D;   // dims per image
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = i / D;
-        const int col = (int)(i - row * D);
+        const int col = (int)(i - row * D), img = col / W, c = col - img * W;
         const float x = src[i];
         const uint16_t h = f32_to_bf16_rne(x);
-        out[row * 2 * D + col] = h;
-        out[row * 2 * D + D + col] = f32_to_bf16_rne(x - bf16_bits_to_f32(h));
+        uint16_t* o = out + ((int64_t)img * N + row) * 2 * W;
+        o[c] = h;
+        o[W + c] = f32_to_bf16_rne(x - bf16_bits_to_f32(h));
     }
 }
 
 extern "C" int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* out, pcvae_stream_t stream) {
-    PCVAE_REQUIRE(src && out && N >= 0 && D > 0, "split_bf16x2: bad arguments");
+    PCVAE_REQUIRE(src && out && N >= 0 && D > 0 && (D <= 128 || D % 128 == 0), "split_bf16x2: bad arguments (D <= 128 or a multiple of 128)");
     if (N == 0) return PCVAE_OK;
     const int64_t blocks = std::min<int64_t>(cdiv(N * D, 256), 4096);
     hipLaunchKernelGGL(split_bf16x2_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, N, D, out);

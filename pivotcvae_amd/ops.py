@@ -999,7 +999,7 @@ def _as_table(E):
 
 
 BF16_DIMS = (64, 128, 256)  # the bf16 MFMA kernels exist for these widths; narrower tables are tiny: exact f32 path
-X3_DIMS = (128,)            # widths the bf16x3 (fp32-equivalent) kernel is instantiated for ...
+X3_DIMS = (128, 256)        # widths the bf16x3 (fp32-equivalent) kernel is instantiated for (256: two images of 128 dims) ...
 X3_MAX_PADDED = 128         # ... and any narrower table runs it on zero columns (a zero column adds exactly 0 to every product of the
 #                             three-MFMA split: same logits, same gradient in the real columns).  D = 64 does 2x, D = 32 4x the
 #                             necessary MFMAs and is still 2.2x / 1.6x faster than the exact f32-MFMA kernel at its tolerances

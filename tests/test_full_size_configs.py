@@ -65,7 +65,7 @@ def model_rx(model, s, r, u, eps):
 
 # per arithmetic: (lse/nll rtol, atol, gradient tolerance relative to its scale)
 TOL = {"f32": (2e-6, 4e-6, 2e-5), "bf16x3": (2e-6, 4e-6, 2e-5), "bf16": (2e-3, 3e-2, 2e-2)}
-CASES = [("2", ["f32", "bf16x3"]), ("3", ["bf16", "bf16x3", "f32"]), ("4", ["bf16x3", "bf16", "f32"]), ("5", ["bf16"])]
+CASES = [("2", ["f32", "bf16x3"]), ("3", ["bf16", "bf16x3", "f32"]), ("4", ["bf16x3", "bf16", "f32"]), ("5", ["bf16", "bf16x3"])]
 
 
 @pytest.mark.parametrize("config,dtypes", CASES)

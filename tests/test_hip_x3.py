@@ -209,3 +209,51 @@ def test_x3_narrow_tables_ride_the_128_wide_kernel(ops, Dn, R, N):
     loss.backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), wd / R, rtol=2e-5, atol=2e-6 / R)
     np.testing.assert_allclose(loss.item(), wn.mean(), rtol=2e-6)
+
+
+# D = 256 (round 3): two [N, 256] hi | lo images, one slot walks both; 16 rows per wave, 64 per workgroup; trips of 4 slots.
+# tiles per range T = N // 32: 0 (tail only), 1 (fill + drain), 2..4 (fenced slots), 5.. (steady-state trips of 4), ragged tails,
+# row counts around the 64-row workgroup and the 256-row flag blocks
+SHAPES_256 = [(35, 20), (70, 32), (64, 33), (257, 64), (100, 100), (64, 161), (130, 225), (300, 4099), (129, 9000), (65, 333),
+              (513, 1024 + 96), (100, 150000), (1, 70000), (129, 40001)]
+
+
+@pytest.mark.parametrize("R,N", SHAPES_256)
+def test_x3_ce_d256_is_fp32_equivalent(ops, R, N):
+    from pivotcvae_amd._hip import PREC_BF16X3
+    D2 = 256
+    assert ops.x3_width(D2) == 256 and ops.effective_precision(PREC_BF16X3, D2) == PREC_BF16X3
+    rx, E = rnd(R, D2, seed=21, scale=1.5), orc.normalize_rows(rnd(N, D2, seed=22))
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(23))
+    tgt[0], tgt[-1] = 0, N - 1
+    table = ops.CatalogTable(E.to(DEV))
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), table, tgt.to(DEV), prec=PREC_BF16X3)
+    assert dx.shape == (R, D2) and torch.isfinite(dx).all()
+    if R * N <= 40_000_000:
+        wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+        np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    en, el, ed = emulate_x3(rx, E, tgt)
+    torch.testing.assert_close(lse.cpu(), el, rtol=1e-6, atol=2e-6)
+    torch.testing.assert_close(nll.cpu(), en, rtol=1e-6, atol=3e-6)
+    assert (dx.cpu() - ed).abs().max() < 2e-6
+    nll2, lse2, none = ops.catalog_ce_raw(rx.to(DEV), table, tgt.to(DEV), prec=PREC_BF16X3, want_dx=False)
+    assert none is None and torch.equal(nll2, nll) and torch.equal(lse2, lse)
+
+
+def test_x3_d256_large_norms_fall_back_per_row_block(ops):
+    from pivotcvae_amd._hip import PREC_BF16X3
+    R, N, D2 = 600, 4096, 256
+    E = orc.normalize_rows(rnd(N, D2, seed=2))
+    rx = rnd(R, D2, seed=1, scale=0.1)
+    rx[3] = E[N - 5] * 60.0
+    rx[300] = E[400] * 75.0       # block 1: over the bound -> exact f32 kernel
+    rx[599] = E[N - 1] * 59.0
+    tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(3))
+    tgt[3], tgt[300] = N - 5, 400
+    nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), ops.CatalogTable(E.to(DEV)), tgt.to(DEV), prec=PREC_BF16X3)
+    wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=2e-6 * 62.0)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
