@@ -41,8 +41,12 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
     const int64_t nblk = x3 ? cdiv(R, 64 * x3_ct(D)) : ((!f32 && D == 256) ? cdiv(R, 128) : p.nrb);
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
+    // fp32-grade results (exact f32, bf16x3): a range's row sums and U are ONE fp32 accumulation chain, and past ~1M items the
+    // running sum's ulp swallows the small terms of a peaked row (N = 10M, |logit| up to 6: lse 6e-5 low, round 3).  Ranges of at
+    // most 16 384 tiles (512K items); the merge adds the <= 64 partials.  (bf16: its own 2^-9 per term dwarfs that - plan unchanged.)
+    const int64_t ns_min = (f32 || x3) ? std::min<int64_t>(cap, cdiv(p.ntiles, 16384)) : 1;
     int64_t best_cost = -1;
-    for (int64_t ns = 1; ns <= cap; ++ns) {
+    for (int64_t ns = ns_min; ns <= cap; ++ns) {
         const int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;
         const int64_t ns_eff = cdiv(p.ntiles, tps);
         const int64_t rounds = cdiv(nblk * ns_eff, slots);
