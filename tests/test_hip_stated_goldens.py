@@ -162,4 +162,6 @@ def _whole_step_x3(name):
     sd = m2.state_dict()
     for k, v in g.sub("adam/step3").items():
         diff = (sd[k].cpu() - v).abs()
-        assert float(diff.max()) <= 2.001 * g.meta["lr"] * 3 and float((diff > 1e-4 * v.abs() + 1e-5).float().mean()) < 5e-3, k
+        # Adam's first steps move a weight by ~lr * g / (|g| + 1e-8): where |g| is within the arithmetic's error (1e-5 of scale here)
+        # the normalised step follows the noise - up to 2 % of a tensor's entries differ by more than 1e-5, none by more than the move
+        assert float(diff.max()) <= 2.001 * g.meta["lr"] * 3 and float((diff > 1e-4 * v.abs() + 1e-5).float().mean()) < 2e-2, k
