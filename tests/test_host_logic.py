@@ -208,8 +208,12 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels = mod.hot_loops()
-    assert len(kernels) >= 10, "pipelined kernels not found in the generated ISA"   # 3 CE + 1 bf16x3 CE + 6 screening instantiations
-    assert any("x3" in name for name in kernels)
+    assert len(kernels) >= 11, "pipelined kernels not found in the generated ISA"   # 3 CE + 2 bf16x3 CE + 6 screening instantiations
+    assert sum("x3" in name for name in kernels) == 2                              # D = 128 and D = 256
+    # no asm MFMA anywhere in these kernels reads a VGPR that a VALU instruction wrote fewer than two wait states earlier (hipcc
+    # does not protect inline-asm MFMAs; round 3 met a stale read behind the loop-entry copies of the bf16x3 kernel)
+    fresh, n_mfma = mod.mfma_fresh_operand_reads()
+    assert n_mfma > 5000 and not fresh, fresh[:5]
     for name, loops in kernels.items():
         assert loops, f"{name}: no steady-state loop found"
         for loop in loops:

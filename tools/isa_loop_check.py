@@ -82,6 +82,18 @@ def queued_operand_clobbers(loop, depth=4):
     return bad
 
 
+_ASM_CACHE = {}
+
+
+def _asm_of(src, extra=()):
+    """gfx950 ISA of one translation unit (hipcc -S), compiled once per process"""
+    key = (src, tuple(extra))
+    if key not in _ASM_CACHE:
+        _ASM_CACHE[key] = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                          "-x", "hip", *extra, src, "-o", "-"], capture_output=True, text=True, check=True).stdout
+    return _ASM_CACHE[key]
+
+
 def forbidden(line):   # kept for callers that test single lines: the conservative form
     return line.startswith(FORBIDDEN)
 
@@ -91,8 +103,7 @@ def hot_loops(pattern="pipe"):
     `s_nop 15`): those are the loops whose correctness depends on hipcc placing no register copy / spill inside."""
     src = os.path.join(ROOT, "pivotcvae_amd", "csrc", "catalog_bf16.hip")
     extra = os.environ.get("PCVAE_ISA_FLAGS", "").split()   # e.g. -DPIPE_OPS_MODE=0 when judging a variant
-    asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip",
-                          *extra, src, "-o", "-"], capture_output=True, text=True, check=True).stdout
+    asm = _asm_of(src, extra)
     out = {}
     for m in re.finditer(r"^(_Z\S+):\s*; @", asm, re.M):
         name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
@@ -147,6 +158,51 @@ def arrival_counter_waits(sources=("gemm_f32.hip", "elementwise.hip")):
     return bad, seen
 
 
+def mfma_fresh_operand_reads(pattern=("x3_pipe", "bf16_pipe", "screen_pipe"), wait_states=2):
+    """-> [(kernel, index, writer, mfma)]: MFMAs that read (A, B or C operand) a VGPR which a VALU instruction wrote fewer than
+    `wait_states` wait states earlier, anywhere in a kernel (straight-line order: fall-through paths, which is how a loop's
+    preheader reaches its header).  hipcc's hazard recogniser inserts these wait states for MFMAs it knows; an inline-asm MFMA is
+    opaque to it.  Round 3: the preheader copies of a steady-state loop's carried values (v_mov) ended right in front of the
+    loop's first asm MFMA - with one instruction between them the MFMA read a stale A fragment (column tile 0 of every wave
+    wrong); the loops now begin with a fence, and this check keeps every asm MFMA of the pipelined kernels two wait states
+    away from any VALU write of its operands."""
+    asm = _asm_of(os.path.join(ROOT, "pivotcvae_amd", "csrc", "catalog_bf16.hip"))
+    bad, seen = [], 0
+    for m in re.finditer(r"^(_Z\S+):\s*; @", asm, re.M):
+        if not any(p in m.group(1) for p in pattern):
+            continue
+        body = asm[m.end():asm.find(".Lfunc_end", m.end())].split("\n")
+        lines = [l.split(";")[0].strip() for l in body]
+        lines = [l for l in lines if l and not l.startswith(".") or re.match(r"\.LBB", l)]
+        for i, l in enumerate(lines):
+            if not l.startswith("v_mfma"):
+                continue
+            seen += 1
+            args = [a.strip().split(" ")[0] for a in l[len(l.split()[0]):].split(",")]
+            srcs = set()
+            for a in args[1:4]:
+                k, r = _regs(a)
+                if k == "v":
+                    srcs |= r
+            ws, j = 0, i - 1
+            while j >= 0 and ws < wait_states:
+                p = lines[j]
+                if p.endswith(":"):          # a label: not an instruction
+                    j -= 1
+                    continue
+                op = p.split()[0]
+                if op == "s_nop":
+                    ws += int(p.split()[1]) + 1
+                else:
+                    if op.startswith("v_") and not op.startswith(("v_mfma", "v_cmp")):
+                        k, dst = _regs(p[len(op):].split(",")[0].strip())
+                        if k == "v" and (dst & srcs):
+                            bad.append((m.group(1)[:60], i, p, l))
+                    ws += 1
+                j -= 1
+    return bad, seen
+
+
 def main():
     ok = True
     for name, loops in hot_loops().items():
@@ -162,6 +218,11 @@ def main():
             # enforced for the bf16x3 kernel, whose schedule has MFMA-dense stretches where the hazard was observed; the round-1
             # kernels (parity-tested on hardware at every size) are reported only
             ok = ok and not bad and not (clob and "x3" in name)
+    fresh, nm = mfma_fresh_operand_reads()
+    print(f"asm MFMAs of the pipelined kernels: {nm}, {len(fresh)} reading a VGPR a VALU op wrote < 2 wait states earlier")
+    for b in fresh[:10]:
+        print("   ", b)
+    ok = ok and nm > 0 and not fresh
     bad, seen = arrival_counter_waits()
     print(f"arrival counters behind sc1 stores: {seen} hand-offs, {len(bad)} without s_waitcnt vmcnt(0)")
     for b in bad[:10]:
