@@ -14,6 +14,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: what
 #ifndef GATHER_UNROLL
 #define GATHER_UNROLL 16  // rows in flight per lane group: 16 measured best of {2,4,8,16} (tools/bench_gather.py)
 #endif
+#ifndef GATHER_NT_LOAD
+#define GATHER_NT_LOAD 1
+#endif
+#ifndef GATHER_NT_STORE
+#define GATHER_NT_STORE 1
+#endif
 #ifndef GATHER_MAXBLOCKS
 #define GATHER_MAXBLOCKS (256 * 8)
 #endif
@@ -45,10 +51,13 @@ __global__ void __launch_bounds__(256) gather_rows_vec4_kernel(const f32x4* __re
             f32x4 v[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                if (src[u] >= 0) v[u] = __builtin_nontemporal_load(&table[src[u] * chunks + c]);
+                if (src[u] >= 0) v[u] = GATHER_NT_LOAD ? __builtin_nontemporal_load(&table[src[u] * chunks + c]) : table[src[u] * chunks + c];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                if (src[u] >= 0) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(out + dst[u] + c * 4));
+                if (src[u] >= 0) {
+                    if (GATHER_NT_STORE) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(out + dst[u] + c * 4));
+                    else *reinterpret_cast<f32x4*>(out + dst[u] + c * 4) = v[u];
+                }
         }
     }
 }
@@ -585,6 +594,9 @@ __global__ void __launch_bounds__(256) assemble_inputs_kernel(const float* __res
 // with six chunks per lane in flight and 16-byte aligned row starts were measured and change nothing.  Destination rows start on 4-byte boundaries only (row widths like 1419):
 // dword-aligned 16-byte accesses, which gfx950 takes.  The lanes that hold a slate's first row also write its one-hot
 // click count.
+#ifndef ASSEMBLE_NT_LOAD
+#define ASSEMBLE_NT_LOAD 1
+#endif
 template <int UNROLL>
 __global__ void __launch_bounds__(256) assemble_inputs_vec_kernel(const float* __restrict__ E, const float* __restrict__ U,
                                                                   const int64_t* __restrict__ s, const float* __restrict__ r,
@@ -617,8 +629,20 @@ __global__ void __launch_bounds__(256) assemble_inputs_vec_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < UNROLL; ++k) {
         const float* src = (jc[k] < S ? E : U) + id[k] * (int64_t)D;   // (rows past the end re-read the last row)
-        v[k] = *reinterpret_cast<const f32x4u*>(src + c4);
+        // table rows are read once and are 16-byte aligned (D % 4 == 0, checked by the host): a non-temporal load - the standalone
+        // gather measures 21.5 us with it against 31.5 us without (round 3)
+        const f32x4 q = ASSEMBLE_NT_LOAD ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + c4))
+                                         : *reinterpret_cast<const f32x4*>(src + c4);
+        v[k] = q;
     }
+#ifndef ASSEMBLE_NT_STORE
+#define ASSEMBLE_NT_STORE 0
+#endif
+#define ASM_ST(ptr_, val_)                                                                                   \
+    do {                                                                                                     \
+        if (ASSEMBLE_NT_STORE) __builtin_nontemporal_store((val_), reinterpret_cast<f32x4u*>(ptr_));         \
+        else *reinterpret_cast<f32x4u*>(ptr_) = (val_);                                                      \
+    } while (0)
 #pragma unroll
     for (int k = 0; k < UNROLL; ++k) {
         const int j = jj[k];
@@ -628,15 +652,15 @@ __global__ void __launch_bounds__(256) assemble_inputs_vec_kernel(const float* _
         float* pri = prior_in + b * ld_prior;
         float* scm = scm_in + b * ld_scm;
         if (j < S) {
-            *reinterpret_cast<f32x4u*>(enc + (int64_t)j * D + c4) = v[k];
+            ASM_ST(enc + (int64_t)j * D + c4, v[k]);
             if (j == 0) {
-                *reinterpret_cast<f32x4u*>(scm + Z + C + c4) = v[k];
-                *reinterpret_cast<f32x4u*>(rx + b * ld_rx + c4) = v[k];
+                ASM_ST(scm + Z + C + c4, v[k]);
+                ASM_ST(rx + b * ld_rx + c4, v[k]);
             }
         } else {
-            *reinterpret_cast<f32x4u*>(enc + (int64_t)S * D + C + c4) = v[k];
-            *reinterpret_cast<f32x4u*>(pri + C + c4) = v[k];
-            *reinterpret_cast<f32x4u*>(scm + Z + C + D + c4) = v[k];
+            ASM_ST(enc + (int64_t)S * D + C + c4, v[k]);
+            ASM_ST(pri + C + c4, v[k]);
+            ASM_ST(scm + Z + C + D + c4, v[k]);
         }
         if (j == 0) {   // this slate's one-hot click count, by the cpr lanes that hold its first row (a lane walking ncols
                         // dependent loads alone held its wave for ten memory round trips)
@@ -667,7 +691,8 @@ extern "C" int pcvae_assemble_inputs(const float* E, int64_t n_items, const floa
                   "assemble_inputs: a leading dimension is narrower than its row");
     if (B == 0) return PCVAE_OK;
     const int cpr = D / 4;
-    if (D % 4 == 0 && cpr <= 64 && 64 % cpr == 0 && B * (S + 1) < (1LL << 31))   // a row = an aligned group of <= 64 lanes
+    if (D % 4 == 0 && cpr <= 64 && 64 % cpr == 0 && B * (S + 1) < (1LL << 31) && ((uintptr_t)E % 16 == 0) &&
+        (!U || (uintptr_t)U % 16 == 0))   // a row = an aligned group of <= 64 lanes, 16-byte aligned in its table
         PCVAE_LAUNCH_TIMED(PCVAE_TIMER_ASSEMBLE, assemble_inputs_vec_kernel<4>, dim3((unsigned)cdiv(B * (S + (U ? 1 : 0)), (256 / cpr) * 4)),
                            dim3(256), 0, as_stream(stream), E, U, s, r, u, B, S, D, ncols, Z, enc_in, ld_enc, prior_in, ld_prior, scm_in,
                            ld_scm, rx, ld_rx);

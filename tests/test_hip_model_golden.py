@@ -165,8 +165,15 @@ def test_graph_captured_step_equals_eager_step():
         m = build_from_golden(g)
         m.rng_seed = 1234
         tr = Trainer(m, lr=1e-3, beta=g.meta["beta"], capture_graph=capture)
-        stats = [[float(x) for x in tr.step(s, r, u)] for _ in range(4)]
+        s2, r2 = s.clone(), r.clone()
+        stats = [[float(x) for x in tr.step(s2, r2, u)] for _ in range(4)]
         assert tr.capture_graph == capture  # capture really happened (no silent fallback)
+        # the replayed graph skips its input copies while the caller steps on the same, unmodified tensors: an IN-PLACE change of
+        # those tensors must still reach it (tensor version counters), and so must a new tensor object
+        s2[0] = s2[1]
+        r2[0] = 1.0 - r2[0]
+        stats.append([float(x) for x in tr.step(s2, r2, u)])
+        stats.append([float(x) for x in tr.step(torch.flip(s2, [0]).contiguous(), torch.flip(r2, [0]).contiguous(), torch.flip(u, [0]).contiguous())])
         outs.append((stats, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-5)
     assert outs[0][0][0] != outs[0][0][1]  # eps (and the parameters) really changed from step to step
