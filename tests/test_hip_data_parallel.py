@@ -16,7 +16,8 @@ playing all ranks IS the W-rank job.  Checked against the single-process step on
     activations = one config-4 batch); that mode is held to 1e-3 of scale;
   * the in-kernel Philox streams - eps, the sparse kept set, candidate draws, sampled pivots - bitwise independent of W;
   * the fused train path and the operator-by-operator path (FUSED_TRAIN_PATH = False) under sharding;
-  * once at config 4's STATED size with W = 8, B_local = 1024 (the driver's 8-GPU run, one rank at a time).
+  * once at config 4's STATED size with W = 8, B_local = 1024 (the driver's 8-GPU run, one rank at a time);
+  * and as two REAL processes on the one GPU, all_reduce included (gloo as the transport: RCCL refuses two ranks on one device).
 
 Reference semantics preserved: /root/reference/train_generative.py:59-63 (recLoss is a MEAN over B S rows, KLD a SUM over B).
 """
@@ -229,3 +230,54 @@ def test_config4_stated_size_eight_ranks_of_1024_slates(tile_mode):
     grads_close(tr, gW, g1, tol=max(tile_mode, 5e-5))
     diff = (pW - p1).abs()
     assert float(diff.max()) <= 2.001 * bench.LR and float((diff > 3e-6).float().mean()) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# two REAL processes on one GPU: the product's Trainer.step end to end - shard, HIP compute, the one all_reduce over the flat
+# gradient buffer + statistics tail, Adam - with gloo as the transport (RCCL refuses two ranks on one device; the collective call
+# and everything around it are the ones the 8-GPU run makes)
+def _two_proc_worker(rank, world, port, out):
+    import os
+    import torch.distributed as dist
+    from pivotcvae_amd.train_generative import Trainer
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, S, D, B = 20011, 10, 128, 512
+        s, r, u = batch(N, S, B)
+        m = make_model(N, S, D, "bf16x3")
+        m.rng_seed = 4242
+        tr = Trainer(m, lr=3e-4, beta=0.001)
+        assert tr.world == world and tr.rank == rank and tr.dist is not None
+        (ss, rr, uu), lo = tr.shard(s, r, u)
+        stats = [[float(x) for x in tr.step(ss.contiguous(), rr.contiguous(), uu.contiguous(), global_batch=B, row_offset=lo)]
+                 for _ in range(3)]
+        torch.cuda.synchronize()
+        out[rank] = (stats, tr.opt.flat.detach().cpu(), lo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_on_one_gpu_equal_the_single_process_step():
+    import socket
+    import torch.multiprocessing as mp
+    from pivotcvae_amd.train_generative import Trainer
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_proc_worker, args=(2, port, out), nprocs=2, join=True)
+    (st0, p0, lo0), (st1, p1, lo1) = out[0], out[1]
+    assert (lo0, lo1) == (0, 256)
+    assert st0 == st1 and torch.equal(p0, p1)            # replicas bit-identical after three steps
+    N, S, D, B = 20011, 10, 128, 512
+    s, r, u = batch(N, S, B)
+    m = make_model(N, S, D, "bf16x3")
+    m.rng_seed = 4242
+    tr = Trainer(m, lr=3e-4, beta=0.001)
+    want = [[float(x) for x in tr.step(s, r, u)] for _ in range(3)]
+    np.testing.assert_allclose(st0, want, rtol=2e-6)
+    diff = (p0 - tr.opt.flat.cpu()).abs()
+    assert float(diff.max()) <= 2.001 * 3e-4 * 3 and float((diff > 3e-6).float().mean()) < 2e-3
