@@ -1108,15 +1108,24 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     return nll, lse, dx
 
 
-_unit_seeds = set()   # data_ptr of the tensors a Trainer seeds backward with (value exactly 1)
+_unit_seeds = {}   # data_ptr -> weak reference to the seed tensor (a dead tensor's address may be reused: then it no longer counts)
 
 
 def register_unit_seed(t):
     """``t``: a 0-d device tensor holding exactly 1.0 that the caller will pass as the upstream gradient of a ``unit_upstream`` loss
     (Trainer does).  Only then does backward hand the saved direction on without a scaling launch; any other upstream gradient
     (a scaled loss, accumulation with loss / k) is applied."""
-    _unit_seeds.add(t.data_ptr())
+    import weakref
+    for k in [k for k, r in _unit_seeds.items() if r() is None]:
+        del _unit_seeds[k]
+    _unit_seeds[t.data_ptr()] = weakref.ref(t)
     return t
+
+
+def _is_unit_seed(g):
+    r = _unit_seeds.get(g.data_ptr())
+    t = r() if r is not None else None
+    return t is not None and t.data_ptr() == g.data_ptr()
 
 
 class _CatalogCE(torch.autograd.Function):
@@ -1141,7 +1150,7 @@ class _CatalogCE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
-        if ctx.unit and g.data_ptr() in _unit_seeds:   # the registered constant 1: the kernel already wrote dx * inv_count
+        if ctx.unit and _is_unit_seed(g):   # the registered constant 1: the kernel already wrote dx * inv_count
             return (dx,) + (None,) * 9
         g = g.contiguous()
         out = torch.empty_like(dx)

@@ -520,3 +520,24 @@ def test_fused_train_path_equals_the_operator_by_operator_path(name):
         close(res[True][1][k], gf, rtol=1e-5, atol=1e-8)
         if k in want:
             close(res[True][1][k], want[k], rtol=2e-4, atol=2e-6)
+
+
+def test_terms_only_loss_applies_any_upstream_gradient():
+    """``loss(..., terms_only=True)`` lets the catalog kernel pre-scale the gradient direction for a backward seeded
+    with the Trainer's registered constant 1; ANY other upstream gradient (a scaled loss, loss / k accumulation) must still be
+    applied - half the seed gives half the gradient."""
+    g = load("pivotcvae_gt_pi_s10")
+    s, r, u, eps = dev(g.t("s")), dev(g.t("r")), dev(g.t("u")), dev(g.t("full/eps"))
+    grads = []
+    for mode in ("plain", "terms_only"):
+        m = build_from_golden(g)
+        if mode == "plain":
+            _, rec, _ = m.loss(s, r, u, g.meta["beta"], eps=eps)
+            (0.5 * rec).backward()
+        else:
+            _, rec, kld = m.loss(s, r, u, g.meta["beta"], eps=eps, terms_only=True)
+            torch.autograd.backward([rec], [torch.full((), 0.5, device=DEV)])
+        grads.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and any(k.startswith("scm_") for k in grads[0])
+    for k in grads[0]:
+        close(grads[1][k], grads[0][k], rtol=1e-5, atol=1e-8)
