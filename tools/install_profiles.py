@@ -8,7 +8,7 @@ tag = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles")
 names = {"bench.json": f"{rnd}_config4_bench.json"}
-for a in ("x3_config4", "f32_config4", "bf16_config4", "nneg_config4", "bf16_config3", "bf16_config5", "f32_config2", "f32_config1"):
+for a in ("x3_config4", "f32_config4", "bf16_config4", "nneg_config4", "bf16_config3", "bf16_config5", "f32_config2", "f32_config1", "x3_config5", "x3_config3"):
     names[f"{a}_kernel_stats.csv"] = f"{rnd}_{a}_kernel_stats.csv"
     names[f"{a}_bench_under_rocprof.json"] = f"{rnd}_{a}_bench_under_rocprof.json"
 for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ1", "SQ2"):
@@ -17,6 +17,7 @@ for n in ("FETCH_SIZE", "WRITE_SIZE"):
     names[f"nneg_config4_pmc_{n}.csv"] = f"{rnd}_nneg_config4_pmc_{n}.csv"
     names[f"gather_pmc_{n}.csv"] = f"{rnd}_gather_pmc_{n}.csv"
 names["gather_kernel_stats.csv"] = f"{rnd}_gather_kernel_stats.csv"
+names["x3_config4_B1024_rccl1_bench.json"] = f"{rnd}_x3_config4_B1024_rccl1_bench.json"
 names["gather_kernel_timer.txt"] = f"{rnd}_gather_kernel_timer.txt"
 for a in ("f32_config2", "bf16_config3", "bf16x3_config4"):
     names[f"{a}_step_launches.txt"] = f"{rnd}_{a}_step_launches.txt"

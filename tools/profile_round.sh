@@ -51,6 +51,11 @@ stats f32_config2 --config 2 --steps 20 --warmup 5 --no-variants --no-graph
 stats f32_config1 --config 1 --steps 20 --warmup 5 --no-variants --no-graph --no-extras
 stats bf16_config3 --config 3 --steps 5 --warmup 2 --no-variants
 stats bf16_config5 --config 5 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-variants
+stats x3_config5 --config 5 --dtype bf16x3 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-variants
+stats x3_config3 --config 3 --dtype bf16x3 --steps 5 --warmup 2 --no-cpu-baseline --no-extras --no-variants
+# the 8-GPU run's per-rank load on one GPU, through a 1-rank RCCL group (the collective path of Trainer.step)
+PCVAE_BENCH_FORCE_DIST=1 python3 $ROOT/bench.py --global-batch 1024 --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-variants > $OUT/shard1024.log 2>&1
+grep '^{"metric"' $OUT/shard1024.log | tail -1 > $OUT/x3_config4_B1024_rccl1_bench.json
 # one traced EAGER step per config: the launch listing (tools/step_trace_list.py)
 for spec in "2 1024 f32" "3 4096 bf16" "4 8192 bf16x3"; do
   set -- $spec
