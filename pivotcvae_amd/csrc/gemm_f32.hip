@@ -143,7 +143,9 @@ __device__ __forceinline__ void store_c(const GemmParams& p, int64_t m, int64_t 
 // groups); a row-contiguous image is read with 8 ds_read_b32 whose two 32-lane halves hit disjoint bank halves (the 32-row
 // rotation of the lines with k bit 2 set).  A wave's 32 x 32 tile = 2 x 2 MFMA tiles of 16 x 16: 12 MFMAs of 16 cycles per
 // 32-deep chunk against 16 of 64 cycles for v_mfma_f32_32x32x2_f32 - the loop turns from matrix-pipe-bound to VALU-bound (the
-// splits: ~96 vector ops per chunk), about 2x faster on the large layers.
+// splits: ~96 vector ops per chunk), about 1.75x faster on the large layers.  (Measured and dropped, round 3: splitting each staged tile
+// ONCE per workgroup into bf16 LDS images - half the vector ops, plain 16-byte operand reads - needs a second barrier per chunk and
+// 16 KB more LDS (three workgroups per CU instead of five): enc_1 forward 49.0 us against 36.8 us for the in-register split.)
 template <bool A_KC, bool B_KC, int EPI, bool X3>
 __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx, const int by, const int bz, char* smem) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
