@@ -41,9 +41,10 @@ extern "C" {
 #define PCVAE_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact k-ordered fmaf chain (bit-exact ids) */
 #define PCVAE_PREC_BF16 1   /* v_mfma_f32_32x32x16_bf16 on a bf16 copy of the table, fp32 accumulate */
 #define PCVAE_PREC_BF16X3 2 /* fp32-equivalent on the bf16 MFMA pipe: hi/lo bf16 split of both operands, 3 MFMAs per product
-                               (D = 128; E = [N, 2D] bf16 image of pcvae_split_bf16x2, E_lo = the fp32 table) */
+                               (D = 128 or 256; E = the bf16 image of pcvae_split_bf16x2, E_lo = the fp32 table.  Narrower
+                               tables: the caller zero-pads table and rx to 128 columns - a zero column adds exactly 0) */
 #define PCVAE_PREC_SCREENED 3 /* argmax only: bf16 MFMA screening + exact fp32 rescoring of the few candidates;
-                                results identical to PCVAE_PREC_F32 (E = bf16 table, E_lo = fp32 table, D = 128) */
+                                results identical to PCVAE_PREC_F32 (E = bf16 table, E_lo = fp32 table, D = 64 / 128 / 256) */
 
 typedef void* pcvae_stream_t;
 
@@ -198,8 +199,9 @@ int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t
  *        dx_r  = sum_n keep_n * (softmax(z)_n - [n == target_r]) * E_n        (optional, [R,D])
  *     i.e. loss AND its gradient direction in one streaming pass (online softmax over catalog
  *     tiles, flash-style), so the backward pass is dx * (upstream / R).
- *     E_lo: second table for PCVAE_PREC_BF16X3 (residual), E is the bf16 table for BF16/BF16X3 and
- *     the fp32 table for F32.  `ws` is scratch of at least pcvae_catalog_ws_bytes().
+ *     E is the fp32 table for F32, its bf16 copy for BF16, the hi | lo image of pcvae_split_bf16x2 for BF16X3; E_lo (BF16X3
+ *     only) is the fp32 table again: exact target logit / target row, and the exact f32 kernel for masked calls and for
+ *     256-row blocks whose norms rule out the max-free kernel.  `ws` is scratch of at least pcvae_catalog_ws_bytes().
  *     e_max_norm: max_n ||E_n||_2 of the table (the model's table is row-normalised: 1.0).  The bf16
  *     path uses it to prove, per 256-row block, that exp2(logit) cannot leave the fp32 range and then
  *     skips the running-max machinery; pass <= 0 when unknown (always take the running-max kernel).
@@ -278,8 +280,9 @@ int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E
 /* fp32 table -> bf16 hi (round-to-nearest-even) and optional bf16 lo (residual) copies */
 int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, pcvae_stream_t stream);
 
-/* fp32 table [N, D] -> the bf16x3 catalog kernel's table image [N, 2 D] bf16: row n = hi(E_n) | lo(E_n) with
- * hi = RNE bf16(E), lo = RNE bf16(E - hi)  (hi + lo carries 16 mantissa bits of E)                           */
+/* fp32 table [N, D] -> the bf16x3 catalog kernel's table image, hi = RNE bf16(E), lo = RNE bf16(E - hi) (hi + lo carries 16
+ * mantissa bits of E).  D <= 128: [N, 2 D] bf16, row n = hi(E_n) | lo(E_n).  D = 256: two such images of 128 dims back to back,
+ * [2][N][256]: image i = hi | lo of dims 128 i .. 128 i + 127 (N * 2 D elements either way)                                  */
 int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* out, pcvae_stream_t stream);
 
 /* a13  simulator click models as in-loop evaluators     env/response_model.py:129-150 (URM), 286-295 (URM_P), 315-323 (URM_P_MR)
