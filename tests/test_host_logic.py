@@ -214,6 +214,9 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
     # does not protect inline-asm MFMAs; round 3 met a stale read behind the loop-entry copies of the bf16x3 kernel)
     fresh, n_mfma = mod.mfma_fresh_operand_reads()
     assert n_mfma > 5000 and not fresh, fresh[:5]
+    # ... and no VALU instruction / store takes an MFMA result fewer than five wait states behind the MFMA that wrote it
+    early, n2 = mod.mfma_result_early_reads()
+    assert n2 == n_mfma and not early, early[:5]
     for name, loops in kernels.items():
         assert loops, f"{name}: no steady-state loop found"
         for loop in loops:

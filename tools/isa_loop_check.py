@@ -203,6 +203,42 @@ def mfma_fresh_operand_reads(pattern=("x3_pipe", "bf16_pipe", "screen_pipe"), wa
     return bad, seen
 
 
+def mfma_result_early_reads(pattern=("x3_pipe", "bf16_pipe", "screen_pipe"), wait_states=5):
+    """-> [(kernel, index, mfma, reader)]: a VALU / LDS-write / store instruction that reads a VGPR (or AGPR) which an MFMA wrote
+    fewer than `wait_states` wait states earlier (straight-line order; an instruction counts 1, `s_nop n` n + 1, an MFMA 4 - its
+    issue alone holds the port that long).  The matrix pipe delivers a 16x16x32 result a few passes after issue; hipcc pads
+    such reads for MFMAs it knows, not for inline asm - the pipelined kernels keep them apart by schedule (the numerators are
+    taken >= 2 CT MFMAs behind the logits' last MFMA), and this check holds every one of them to it."""
+    asm = _asm_of(os.path.join(ROOT, "pivotcvae_amd", "csrc", "catalog_bf16.hip"))
+    bad, seen = [], 0
+    for m in re.finditer(r"^(_Z\S+):\s*; @", asm, re.M):
+        if not any(p in m.group(1) for p in pattern):
+            continue
+        body = asm[m.end():asm.find(".Lfunc_end", m.end())].split("\n")
+        lines = [l.split(";")[0].strip() for l in body]
+        lines = [l for l in lines if l and not l.startswith(".")]
+        recent = []   # (wait states since, dst regs, text) of the last MFMAs
+        for i, l in enumerate(lines):
+            op = l.split()[0]
+            args = [a.strip().split(" ")[0] for a in l[len(op):].split(",")] if " " in l else []
+            if op.startswith(("v_", "ds_write", "global_store", "buffer_store", "scratch_store")) and not op.startswith("v_mfma"):
+                srcs = set()
+                for a in (args[1:] if op.startswith("v_") else args):
+                    k, r = _regs(a)
+                    if k:
+                        srcs |= {(k, x) for x in r}
+                for ws, dst, text in recent:
+                    if ws < wait_states and (srcs & dst):
+                        bad.append((m.group(1)[:60], i, text, l))
+            step = (int(l.split()[1]) + 1) if op == "s_nop" else (4 if op.startswith("v_mfma") else 1)
+            recent = [(ws + step, d, t) for ws, d, t in recent if ws + step < wait_states]
+            if op.startswith("v_mfma"):
+                seen += 1
+                k, r = _regs(args[0])
+                recent.append((0, {(k, x) for x in r}, l))
+    return bad, seen
+
+
 def main():
     ok = True
     for name, loops in hot_loops().items():
@@ -223,6 +259,11 @@ def main():
     for b in fresh[:10]:
         print("   ", b)
     ok = ok and nm > 0 and not fresh
+    early, nm2 = mfma_result_early_reads()
+    print(f"MFMA results read by VALU / stores fewer than 5 wait states behind the MFMA: {len(early)} (of {nm2} MFMAs)")
+    for b in early[:10]:
+        print("   ", b)
+    ok = ok and not early
     bad, seen = arrival_counter_waits()
     print(f"arrival counters behind sc1 stores: {seen} hand-offs, {len(bad)} without s_waitcnt vmcnt(0)")
     for b in bad[:10]:
