@@ -257,3 +257,27 @@ def test_x3_d256_large_norms_fall_back_per_row_block(ops):
     np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=2e-6 * 62.0)
     np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("Dx", [128, 256])
+def test_x3_random_shapes_fuzz(ops, Dx):
+    """24 random (R, N) per width - every combination of fill / fenced / steady / drain / tail lengths and row-block raggedness the
+    plan produces for small catalogs - against the C oracle at the f32 kernel's tolerances"""
+    import random
+    from pivotcvae_amd._hip import PREC_BF16X3
+    rng = random.Random(77 + Dx)
+    for case in range(24):
+        N = rng.choice([rng.randint(1, 400), rng.randint(401, 6000), rng.randint(6001, 60000)])
+        R = rng.randint(1, max(1, min(700, 12_000_000 // N)))
+        scale = rng.choice([0.5, 2.0, 4.0])
+        # 16-bit-mantissa operands: a logit is good to ~2^-17 of ITS magnitude, so rows with |logit| up to ~25 (scale 4) are held
+        # to twice the f32 kernel's relative tolerance; the model's own rows (|rx| ~ 1) and the other tests use 2e-6
+        k = 2.0 if scale > 2.0 else 1.0
+        rx, E = rnd(R, Dx, seed=500 + case, scale=scale), orc.normalize_rows(rnd(N, Dx, seed=600 + case))
+        tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(700 + case))
+        nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), ops.CatalogTable(E.to(DEV)), tgt.to(DEV), prec=PREC_BF16X3)
+        wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+        np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6 * k, atol=2e-6, err_msg=f"D={Dx} R={R} N={N}")
+        np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6 * k, atol=4e-6 + 2e-6 * k * float(np.abs(wl).max()),
+                                   err_msg=f"D={Dx} R={R} N={N}")   # nll = lse - z_t cancels: the lse's ABSOLUTE error is what it carries
+        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5 * k, atol=2e-6 * k, err_msg=f"D={Dx} R={R} N={N}")
