@@ -454,6 +454,14 @@ __device__ __forceinline__ void store_tile_s_v4(float* S, const float (&v)[STPT]
     }
 }
 
+#ifdef GEMM_STAMPS   // probe builds only: shader-clock stamps of workgroup 0 of a small-tile launch
+__device__ unsigned long long g_gemm_stamps[64];
+#define GSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_gemm_stamps[i] = clock64(); } while (0)
+extern "C" int pcvae_gemm_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps)); }
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
+
 template <bool A_KC, bool B_KC, int EPI>
 __device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int bx, const int by, char* smem) {
     static_assert(EPI == EPI_FWD || EPI == EPI_DX, "the weight-gradient GEMM is already split over workgroups");
@@ -470,58 +478,125 @@ __device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int b
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
     const bool rows_in = m0 + SM <= p.M && n0 + SM <= p.N;   // workgroup-uniform
-    float va[STPT], vb[STPT];
-    bool vec = rows_in && SBK <= p.K;
-    if (vec) {
-        load_tile_s_v4<A_KC>(p.A, p.lda, m0, 0, va);
-        load_tile_s_v4<B_KC>(p.B, p.ldb, n0, 0, vb);
-    } else {
-        load_tile_s<A_KC>(p.A, p.lda, m0, p.M, 0, p.K, va);
-        load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, 0, p.K, vb);
-    }
-    for (int64_t k0 = 0; k0 < p.K; k0 += SBK) {
-        __syncthreads();
-        if (vec) {
-            store_tile_s_v4<A_KC>(As, va);
-            store_tile_s_v4<B_KC>(Bs, vb);
+    GSTAMP(0);
+    int stamp_i = 1;
+
+    // What the epilogue reads from memory - the bias (forward), the activated input and, for the second of two layers sharing an
+    // input, the running sum (input gradient) - is requested HERE, ahead of the K loop: read at the end it was a fully exposed
+    // round trip, 0.5 us of a 4 us workgroup (shader-clock stamps, round 3).  Element i of this thread: row (tid >> 5) + 8 i,
+    // column tid & 31.
+    float epi_bias = 0.f, epi_aux[4] = {1.f, 1.f, 1.f, 1.f}, epi_c[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int64_t n = n0 + (threadIdx.x & 31);
+        if (EPI == EPI_FWD) {
+            if (p.bias && n < p.N) epi_bias = p.bias[n];
         } else {
-            store_tile_s<A_KC>(As, va);
-            store_tile_s<B_KC>(Bs, vb);
-        }
-        __syncthreads();
-        if (k0 + SBK < p.K) {
-            vec = rows_in && k0 + 2 * SBK <= p.K;
-            if (vec) {
-                load_tile_s_v4<A_KC>(p.A, p.lda, m0, k0 + SBK, va);
-                load_tile_s_v4<B_KC>(p.B, p.ldb, n0, k0 + SBK, vb);
-            } else {
-                load_tile_s<A_KC>(p.A, p.lda, m0, p.M, k0 + SBK, p.K, va);
-                load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + SBK, p.K, vb);
-            }
-        }
-        {   // operand reads run PRE k-steps ahead of the MFMAs: hipcc's schedule of the plain loop was read, read,
-            // s_waitcnt lgkmcnt(0), mfma - a fully exposed LDS latency per MFMA
-            constexpr int NS = SBK / 8, PRE = 4;
-            float ar[NS], br[NS];
 #pragma unroll
-            for (int s = 0; s < PRE && s < NS; ++s) {
-                const int k = wave * (SBK / 4) + 2 * s + h;
-                ar[s] = As[k * SLD + li];
-                br[s] = Bs[k * SLD + li];
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                if (s + PRE < NS) {
-                    const int k = wave * (SBK / 4) + 2 * (s + PRE) + h;
-                    ar[s + PRE] = As[k * SLD + li];
-                    br[s + PRE] = Bs[k * SLD + li];
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = m0 + (threadIdx.x >> 5) + 8 * i;
+                if (m < p.M && n < p.N) {
+                    if (p.aux) epi_aux[i] = p.aux[m * p.ldaux + n];
+                    if (p.accumulate) epi_c[i] = p.C[m * p.ldc + n];
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s], br[s], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             }
         }
     }
+
+    auto mfma_chunk = [&](const float* As, const float* Bs) {
+        // operand reads run PRE k-steps ahead of the MFMAs: hipcc's schedule of the plain loop was read, read,
+        // s_waitcnt lgkmcnt(0), mfma - a fully exposed LDS latency per MFMA
+        constexpr int NS = SBK / 8, PRE = 4;
+        float ar[NS], br[NS];
+#pragma unroll
+        for (int s = 0; s < PRE && s < NS; ++s) {
+            const int k = wave * (SBK / 4) + 2 * s + h;
+            ar[s] = As[k * SLD + li];
+            br[s] = Bs[k * SLD + li];
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (s + PRE < NS) {
+                const int k = wave * (SBK / 4) + 2 * (s + PRE) + h;
+                ar[s + PRE] = As[k * SLD + li];
+                br[s + PRE] = Bs[k * SLD + li];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s], br[s], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+    };
+
+    constexpr int NPRE = 4;
+    const int nchunks = (int)((p.K + SBK - 1) / SBK);
+    if (nchunks <= NPRE) {
+        // short reductions (K <= 256: every layer of the model but the encoder's first): ALL chunks are requested up front, one memory
+        // round trip for the tile instead of one per chunk (each chunk waited ~0.6 us for the loads issued one chunk earlier)
+        float va[NPRE][STPT], vb[NPRE][STPT];
+#pragma unroll
+        for (int c = 0; c < NPRE; ++c) {
+            if (c < nchunks) {   // workgroup-uniform
+                if (rows_in && (int64_t)(c + 1) * SBK <= p.K) {
+                    load_tile_s_v4<A_KC>(p.A, p.lda, m0, (int64_t)c * SBK, va[c]);
+                    load_tile_s_v4<B_KC>(p.B, p.ldb, n0, (int64_t)c * SBK, vb[c]);
+                } else {
+                    load_tile_s<A_KC>(p.A, p.lda, m0, p.M, (int64_t)c * SBK, p.K, va[c]);
+                    load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, (int64_t)c * SBK, p.K, vb[c]);
+                }
+            }
+        }
+        // (two LDS stages - chunk c + 1 written while chunk c is multiplied, one barrier per chunk - were measured: 1100 against 1250
+        // ticks per chunk, the launch unchanged at 5.7 us, a workgroup less per CU: not kept)
+#pragma unroll
+        for (int c = 0; c < NPRE; ++c) {
+            if (c < nchunks) {
+                if (c) __syncthreads();
+                GSTAMP(stamp_i++);
+                if (rows_in && (int64_t)(c + 1) * SBK <= p.K) {
+                    store_tile_s_v4<A_KC>(As, va[c]);
+                    store_tile_s_v4<B_KC>(Bs, vb[c]);
+                } else {
+                    store_tile_s<A_KC>(As, va[c]);
+                    store_tile_s<B_KC>(Bs, vb[c]);
+                }
+                __syncthreads();
+                mfma_chunk(As, Bs);
+            }
+        }
+    } else {
+        float va[STPT], vb[STPT];
+        bool vec = rows_in && SBK <= p.K;
+        if (vec) {
+            load_tile_s_v4<A_KC>(p.A, p.lda, m0, 0, va);
+            load_tile_s_v4<B_KC>(p.B, p.ldb, n0, 0, vb);
+        } else {
+            load_tile_s<A_KC>(p.A, p.lda, m0, p.M, 0, p.K, va);
+            load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, 0, p.K, vb);
+        }
+        for (int64_t k0 = 0; k0 < p.K; k0 += SBK) {
+            __syncthreads();
+            GSTAMP(stamp_i++);
+            if (vec) {
+                store_tile_s_v4<A_KC>(As, va);
+                store_tile_s_v4<B_KC>(Bs, vb);
+            } else {
+                store_tile_s<A_KC>(As, va);
+                store_tile_s<B_KC>(Bs, vb);
+            }
+            __syncthreads();
+            if (k0 + SBK < p.K) {
+                vec = rows_in && k0 + 2 * SBK <= p.K;
+                if (vec) {
+                    load_tile_s_v4<A_KC>(p.A, p.lda, m0, k0 + SBK, va);
+                    load_tile_s_v4<B_KC>(p.B, p.ldb, n0, k0 + SBK, vb);
+                } else {
+                    load_tile_s<A_KC>(p.A, p.lda, m0, p.M, k0 + SBK, p.K, va);
+                    load_tile_s<B_KC>(p.B, p.ldb, n0, p.N, k0 + SBK, p.K, vb);
+                }
+            }
+            mfma_chunk(As, Bs);
+        }
+    }
+    GSTAMP(stamp_i++);
     // partial tiles -> LDS as [wave][row][col]
 #pragma unroll
     for (int r = 0; r < 16; ++r) Red[wave * SM * SM + ((r & 3) + 8 * (r >> 2) + 4 * h) * SM + li] = acc[r];
@@ -531,9 +606,18 @@ __device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int b
         const int e = threadIdx.x + 256 * i, row = e >> 5, col = e & 31;
         const int64_t m = m0 + row, n = n0 + col;
         if (m >= p.M || n >= p.N) continue;
-        const float v = ((Red[e] + Red[SM * SM + e]) + Red[2 * SM * SM + e]) + Red[3 * SM * SM + e];
-        store_c<EPI>(p, m, n, v, (EPI == EPI_FWD && p.bias) ? p.bias[n] : 0.f);
+        float v = ((Red[e] + Red[SM * SM + e]) + Red[2 * SM * SM + e]) + Red[3 * SM * SM + e];
+        if (EPI == EPI_FWD) {   // as store_c, on the operands requested ahead of the loop
+            v += epi_bias;
+            if (p.act == PCVAE_ACT_LEAKY) v = leaky(v);
+            else if (p.act == PCVAE_ACT_RELU) v = fmaxf(v, 0.f);
+        } else {
+            v += epi_c[i];
+            if (p.aux && !(epi_aux[i] > 0.f)) v *= kLeakySlope;
+        }
+        p.C[m * p.ldc + n] = v;
     }
+    GSTAMP(stamp_i++);
 }
 
 // ---- the kernel: one or several independent problems ---------------------------------------------------------------------
