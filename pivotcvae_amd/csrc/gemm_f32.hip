@@ -132,6 +132,16 @@ __device__ __forceinline__ void store_c(const GemmParams& p, int64_t m, int64_t 
     }
 }
 
+#ifdef GEMM_STAMPS   // probe builds only: shader-clock stamps of workgroup 0 (slots 0..31; the weight gradient's last arriver of tile 0: slots 32..)
+__device__ unsigned long long g_gemm_stamps[64];
+#define GSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_gemm_stamps[i] = clock64(); } while (0)
+#define GSTAMP_IF(c, i) do { if ((c) && threadIdx.x == 0) g_gemm_stamps[i] = clock64(); } while (0)
+extern "C" int pcvae_gemm_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps)); }
+#else
+#define GSTAMP(i) do { } while (0)
+#define GSTAMP_IF(c, i) do { } while (0)
+#endif
+
 // ---- 64 x 64 tile, LDS-DMA --------------------------------------------------------------------------------------------------
 // X3 (round 3): the same tile, staging and epilogues, but the contraction runs on the bf16 matrix cores at fp32-EQUIVALENT precision:
 // every operand value v is split in registers into hi = RNE bf16(v), lo = RNE bf16(v - hi) and a product is three
@@ -208,6 +218,9 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
         }
     };
 
+    if (EPI == EPI_DW) GSTAMP(0);
+    // (four stages for weight-gradient launches of one workgroup per CU were measured, round 3: the K loop stayed at 0.93 us per
+    // 32-deep chunk - it is bound by the 32 ds_read_b32 + 16 MFMAs of a row-contiguous chunk, not by the chunk's round trip)
     if (nch > 0) issue(0);
 
     // operand fetch addresses inside a stage (bytes)
@@ -303,6 +316,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
 
     const int64_t nw = n0 + wn * 32, mw = m0 + wm * 32;   // origin of this wave's 32 x 32 tile
     if (EPI == EPI_DW) {
+        GSTAMP(1);
         // NO fp32 atomics on the output.  HIP's atomicAdd(float*) is an agent-scope global_atomic_add_f32 that the issuing XCD's L2
         // executes, and workgroups of different XCDs adding into one cache line lose updates (common.h: atomic_add_f32; the batch
         // splits of a tile run on different XCDs by construction).  The nz splits of an output tile store their partial tiles in
@@ -326,6 +340,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             // mode it emits no vmcnt wait: the ISA had the stores, s_barrier and the global_atomic_add back to back, so the last
             // workgroup of another XCD could read a stale partial).  tools/isa_loop_check.py asserts the wait is in the ISA.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GSTAMP(2);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             int* s_last = reinterpret_cast<int*>(smem);
@@ -335,9 +350,21 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                 if (old == (unsigned)(p.nz - 1)) atomicExch(&p.ws_cnt[tile], 0u);   // every split has arrived: ready for the next launch
             }
             __syncthreads();
+            GSTAMP(3);
             if (!*s_last) return;
+            GSTAMP_IF(tile == 0, 32);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             float* all = p.ws_part + (int64_t)tile * p.nz * 4096 + tid;
+            // what the final add reads - this tile of C and the bias gradient - is requested FIRST, and the bias partials of every
+            // split together: behind the reduction they were one exposed round trip each (shader-clock stamps, round 3: 5.9 us of
+            // a 17.5 us launch between the last partial tile and the end of the workgroup)
+            float cold[16], bold = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = mw + dm_of(r), n = nw + dn_of(r);
+                cold[r] = (m < p.M && n < p.N) ? p.C[m * p.ldc + n] : 0.f;
+            }
+            if (do_bias && m0 + tid < p.M) bold = p.bias_grad[m0 + tid];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #ifndef PCVAE_GEMM_RB
@@ -359,11 +386,30 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[r] += v[u][r];
             }
+            GSTAMP_IF(tile == 0, 33);
             if (do_bias) {
                 bsum = 0.f;
-                for (int z = 0; z < p.nz; ++z)
-                    bsum += __hip_atomic_load(&p.ws_bias[((int64_t)by * p.nz + z) * 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                constexpr int BB = 8;   // bias partials requested together (fixed order of the sum: bitwise reproducible)
+                for (int z0 = 0; z0 < p.nz; z0 += BB) {
+                    float bv[BB];
+#pragma unroll
+                    for (int u = 0; u < BB; ++u) {
+                        const int z = z0 + u < p.nz ? z0 + u : p.nz - 1;
+                        bv[u] = __hip_atomic_load(&p.ws_bias[((int64_t)by * p.nz + z) * 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int u = 0; u < BB; ++u)
+                        if (z0 + u < p.nz) bsum += bv[u];
+                }
             }
+            if (do_bias && m0 + tid < p.M) p.bias_grad[m0 + tid] = bold + bsum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = mw + dm_of(r), n = nw + dn_of(r);
+                if (m < p.M && n < p.N) p.C[m * p.ldc + n] = cold[r] + acc[r];
+            }
+            GSTAMP_IF(tile == 0, 34);
+            return;
         }
         if (do_bias && m0 + tid < p.M) p.bias_grad[m0 + tid] += bsum;
 #pragma unroll
@@ -371,6 +417,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
             const int64_t m = mw + dm_of(r), n = nw + dn_of(r);
             if (m < p.M && n < p.N) p.C[m * p.ldc + n] += acc[r];
         }
+        GSTAMP_IF(tile == 0, 34);
         return;
     }
 
@@ -453,14 +500,6 @@ __device__ __forceinline__ void store_tile_s_v4(float* S, const float (&v)[STPT]
         }
     }
 }
-
-#ifdef GEMM_STAMPS   // probe builds only: shader-clock stamps of workgroup 0 of a small-tile launch
-__device__ unsigned long long g_gemm_stamps[64];
-#define GSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_gemm_stamps[i] = clock64(); } while (0)
-extern "C" int pcvae_gemm_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gemm_stamps), sizeof(g_gemm_stamps)); }
-#else
-#define GSTAMP(i) do { } while (0)
-#endif
 
 template <bool A_KC, bool B_KC, int EPI>
 __device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int bx, const int by, char* smem) {
@@ -700,7 +739,13 @@ static DwPlan dw_plan(const pcvae_gemm_desc& d, bool have_ws) {
         const int64_t rounds = cdiv(rounds_total, sp), nsp = cdiv(rounds_total, rounds);   // splits actually launched
         // +1: prologue / epilogue; the last term is the last workgroup's reduction of the nsp partial tiles, four per memory
         // round trip (a round of 64 batch rows ~ 0.5 us ~ 64 units; a round trip ~ 1.5-2 us)
-        constexpr int64_t red = 192;   // (96 .. 384 measured within 3 % of each other on the model's layers)
+        // red: 96 .. 384 measured within 3 % of each other on config 4's layers (round 2); round 3 took the serial loads out of the last
+        // workgroup's tail (5.9 -> 0.85 us) and a batch of four partials now costs 1.6 us = 55 units: the low end, which at M = 1024
+        // picks 8 splits of 4 chunks instead of 4 of 8
+#ifndef PCVAE_DW_RED
+#define PCVAE_DW_RED 96
+#endif
+        constexpr int64_t red = PCVAE_DW_RED;
         const int64_t cost = cdiv(tiles * nsp, 512) * (rounds + 1) * 64 + nsp + (nsp > 1 ? red * cdiv(nsp, 4) : 0);
         if (cost < best) { best = cost; splits = nsp; }
     }
