@@ -89,6 +89,14 @@ __device__ __forceinline__ int nloc(int reg, int h) { return (reg & 3) + 8 * (re
 // =============================================================================================
 // fused softmax-CE over a catalog range
 // =============================================================================================
+#ifdef CAT_STAMPS   // probe builds only: shader-clock stamps of workgroup 0 and of the LAST workgroup of the launch
+__device__ unsigned long long g_cat_stamps[64];
+#define CSTAMP(i) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1)) g_cat_stamps[(blockIdx.x ? 32 : 0) + (i)] = wall_clock64(); } while (0)
+extern "C" int pcvae_cat_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cat_stamps), sizeof(g_cat_stamps)); }
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+
 template <int D, int MASK, bool WANT_DX>
 __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_ce_f32_kernel(CatParams p) {
     using G = Geo<D>;
@@ -96,6 +104,7 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_ce_f32_kernel
     float* Es0 = smem;
     float* Es1 = smem + 32 * G::LDE;
 
+    CSTAMP(0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -136,6 +145,7 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_ce_f32_kernel
     stage_load<D>(p.E, p.N, (int64_t)t_beg * 32, stg);
     stage_store<D>(Es0, stg);
     __syncthreads();
+    CSTAMP(1);
 
     for (int t = t_beg; t < t_end; ++t) {
         float* Es = ((t - t_beg) & 1) ? Es1 : Es0;
@@ -228,6 +238,7 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_ce_f32_kernel
         __syncthreads();
     }
 
+    CSTAMP(2);
     // ---- per-split partials
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
     if (row_ok) {
@@ -245,6 +256,7 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_ce_f32_kernel
                 }
         }
     }
+    CSTAMP(3);
 }
 
 // one wave per row: merge the split partials, target logit, nll, lse, gradient direction
@@ -257,10 +269,19 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_f32_kernel(CatParams p, 
     const int64_t r = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (r >= p.R) return;
     if (p.flags && p.flags[r >> 8] != 1) return;
-    float M = -INFINITY;
-    for (int j = 0; j < p.nsplit; ++j) M = fmaxf(M, p.pm[(int64_t)j * p.R + r]);
+    // The ranges' partials are requested TOGETHER - (m, l) of range j by lane j (nsplit <= 64: catalog_plan), the U rows eight ranges
+    // at a time - and combined in the order j = 0, 1, ..: the same sums, bit for bit, as the loops over j that paid a memory round
+    // trip per range (three loops of 12 at config 2: 13.5 us for a 5 120-row merge).
+    const int ns = p.nsplit;
+    const float pm_l = lane < ns ? p.pm[(int64_t)lane * p.R + r] : -INFINITY;
+    const float pl_l = lane < ns ? p.pl[(int64_t)lane * p.R + r] : 0.f;
+    float M = pm_l;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
+    const float sc_l = lane < ns ? __expf(pm_l - M) : 0.f;
+    const float term_l = pl_l * sc_l;
     float L = 0.f;
-    for (int j = 0; j < p.nsplit; ++j) L += p.pl[(int64_t)j * p.R + r] * __expf(p.pm[(int64_t)j * p.R + r] - M);
+    for (int j = 0; j < ns; ++j) L += __shfl(term_l, j, 64);
     const int64_t t = p.target[r];
     const bool t_ok = t >= 0 && t < p.N;
     // target logit, same k order as the MFMA chain (lane 0 result is used; D <= 256 is cheap)
@@ -274,11 +295,24 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_f32_kernel(CatParams p, 
     }
     if (dx) {
         const float invL = 1.f / L;
-        for (int d = lane; d < D; d += 64) {
+        for (int d0 = 0; d0 < D; d0 += 64) {   // wave-uniform trip count: the shuffles below need every lane
+            const int d = d0 + lane;
+            const bool d_ok = d < D;
             float u = 0.f;
-            for (int j = 0; j < p.nsplit; ++j)
-                u += p.pU[((int64_t)j * p.R + r) * D + d] * __expf(p.pm[(int64_t)j * p.R + r] - M);
-            dx[r * D + d] = t_ok ? (u * invL - p.E[t * D + d]) * p.dx_scale : NAN;
+            for (int j0 = 0; j0 < ns; j0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int j = j0 + q < ns ? j0 + q : ns - 1;
+                    v[q] = d_ok ? p.pU[((int64_t)j * p.R + r) * D + d] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float sc = __shfl(sc_l, j0 + q < ns ? j0 + q : 0, 64);
+                    if (j0 + q < ns) u += v[q] * sc;
+                }
+            }
+            if (d_ok) dx[r * D + d] = t_ok ? (u * invL - p.E[t * D + d]) * p.dx_scale : NAN;
         }
     }
 }

@@ -341,6 +341,10 @@ __device__ unsigned int g_kld_done = 0;
 
 // block partial t (valid in thread 0) -> out[0] = -0.5 * sum over blocks, combined in block order by the block that finishes last
 __device__ __forceinline__ void kld_combine(const float t, float* __restrict__ out) {
+    if (gridDim.x == 1) {   // one block (small batches): nothing to combine - no partial, no arrival, no second round trip
+        if (threadIdx.x == 0) out[0] = -0.5f * t;
+        return;
+    }
     __shared__ bool last;
     // device-scope (sc1) store / loads of the partials instead of __threadfence(): a device-scope fence writes back and invalidates
     // the whole L2 of the XCD, once per block - 10 of this kernel's 16 us at config 4.  The explicit s_waitcnt vmcnt(0) holds the
@@ -499,7 +503,9 @@ extern "C" int pcvae_latent_fwd_packed(const float* y_enc, const float* y_prior,
                                        pcvae_stream_t stream) {
     PCVAE_REQUIRE(y_enc && y_prior && z && eps_out && kld_out && Z > 0 && ld >= 2 * Z && ldz >= Z && B > 0,
                   "latent_fwd_packed: bad arguments");
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(KLD_MAX_BLOCKS, cdiv(B * Z, 2048)));
+    // one element per thread up to 64 blocks: the kernel's loop pays a memory round trip per iteration (a single block walking the
+    // 16 384 elements of config 2 in 16 iterations: 30 us; 8 blocks of 2 iterations: 9.2 us), the cross-block combine about 3 us once
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(KLD_MAX_BLOCKS, cdiv(B * Z, 1024)));
     hipLaunchKernelGGL(latent_fwd_packed_kernel, dim3((unsigned)blocks), dim3(1024), 0, as_stream(stream), y_enc, y_prior, ld, eps_in,
                        seed, offset, z, ldz, eps_out, kld_out, B, Z);
     return check_launch("latent_fwd_packed");
