@@ -621,6 +621,7 @@ __global__ void __launch_bounds__(256) assemble_inputs_vec_kernel(const float* _
     f32x4u v[UNROLL];
     int bb[UNROLL], jj[UNROLL], jc[UNROLL];
     int64_t id[UNROLL];
+    float r0[UNROLL];
     // three branch-free phases, so that the UNROLL index loads, then the UNROLL row loads, are in flight together (rows past the
     // end are clamped for the loads and skipped by the stores): as one loop hipcc serialises index -> row -> index -> row
 #pragma unroll
@@ -628,6 +629,8 @@ __global__ void __launch_bounds__(256) assemble_inputs_vec_kernel(const float* _
         const unsigned row = row0 + k * rpw, rc = row < total_rows ? row : total_rows - 1;
         const int b = (int)(rc / (unsigned)rps), j = (int)(rc - (unsigned)b * rps);
         id[k] = j < S ? s[(int64_t)b * S + j] : u[b];
+        // the first click flags of the slate, with the index loads (behind the stores they were a third exposed round trip)
+        r0[k] = (j == 0 && (c4 >> 2) < ncols) ? r[(int64_t)b * ncols + (c4 >> 2)] : 0.f;
         bb[k] = b;
         jc[k] = j;
         jj[k] = row < total_rows ? j : -1;
@@ -671,8 +674,8 @@ __global__ void __launch_bounds__(256) assemble_inputs_vec_kernel(const float* _
         if (j == 0) {   // this slate's one-hot click count, by the cpr lanes that hold its first row (a lane walking ncols
                         // dependent loads alone held its wave for ten memory round trips)
             const int c = c4 >> 2;
-            float cnt = 0.f;
-            for (int i = c; i < ncols; i += cpr) cnt += r[b * ncols + i];
+            float cnt = r0[k];
+            for (int i = c + cpr; i < ncols; i += cpr) cnt += r[b * ncols + i];
             for (int o = cpr >> 1; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
             const int c1 = (int)cnt;   // torch: sum(r).to(long) truncates
             for (int i = c; i < C; i += cpr) {
