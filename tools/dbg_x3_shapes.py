@@ -1,3 +1,5 @@
+"""dbg_x3_shapes.py [D]: the bf16x3 kernel against the C oracle over the shapes of tests/test_hip_x3.py, one line per shape (which
+fill / drain / tail path is off)."""
 import sys; sys.path.insert(0,'/root/repo')
 import torch, numpy as np
 from pivotcvae_amd import ops

@@ -1,3 +1,5 @@
+"""evt_graph_probe.py: can a HIP event be recorded inside a captured hipGraph?  (ROCm 7.2: hipErrorInvalidHandle - why bench.py times
+the catalog kernel over eager steps after a graph-replayed timed region.)"""
 import torch, time
 x = torch.randn(4096, 4096, device="cuda")
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
