@@ -3,6 +3,8 @@
 Tolerances (fp32 path): GEMM-class results rtol 1e-5 (different summation order from the CPU BLAS),
 catalog CE nll/lse rtol 2e-6 and gradient 2e-5 against the double-precision C oracle, greedy ids BIT-EXACT.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -263,9 +265,15 @@ def test_weight_gradient_many_batch_splits_repeated(ops, M, N, K):
 def test_linear_random_ragged_shapes(ops):
     """forty random (M, N, K) with ragged everything - K below one 32-chunk, M / N below one tile, odd leading dimensions, column
     windows - through forward, input gradient and weight gradient, each alone (32 x 32 or 64 x 64 tiles by size) and as one group
-    (64 x 64 LDS-DMA tiles), against fp64 on the CPU."""
+    (64 x 64 LDS-DMA tiles), against fp64 on the CPU.  PCVAE_FUZZ_SEEDS="1,2,.." runs other shape sequences as well (one-off
+    campaigns; the default is the committed sequence)."""
+    for seed in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "1234").split(",")]:
+        _linear_ragged_sequence(ops, 1234 if seed == 1234 else 1234 + 7919 * seed)
+
+
+def _linear_ragged_sequence(ops, seed):
     import random
-    rng = random.Random(1234)
+    rng = random.Random(seed)
     for case in range(40):
         M = rng.choice([1, 2, 31, 33, 63, 64, 65, 127, 200, 1000, 1300])
         N = rng.choice([1, 3, 16, 31, 32, 33, 64, 65, 100, 130])
@@ -951,3 +959,37 @@ def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
     e32, e3 = (y32.double() - y64).abs().max().item(), (y3.double() - y64).abs().max().item()
     scale = y64.abs().max().item()
     assert not torch.equal(y32, y3) and e32 < 2e-6 * scale and e3 < 2e-5 * scale, (e32, e3, scale)
+
+
+def _f32_catalog_sequence(ops, seed, cases=20):
+    import random
+    rng = random.Random(seed)
+    for case in range(cases):
+        D = rng.choice([8, 16, 24, 32, 64, 100, 128, 256])
+        N = rng.choice([rng.randint(1, 70), rng.randint(71, 3000), rng.randint(3001, 80000)])
+        R = rng.randint(1, max(1, min(600, 6_000_000 // N)))
+        scale = rng.choice([0.5, 2.0, 6.0])
+        rx, E = rnd(R, D, seed=seed + 11 + case, scale=scale), unit_rows(N, D, seed=seed + 12 + case)
+        tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(seed + 13 + case))
+        msg = f"seed={seed} case={case} R={R} N={N} D={D} scale={scale}"
+        nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV))
+        wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
+        np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6, err_msg=msg)
+        np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6 + 2e-6 * float(np.abs(wl).max()), err_msg=msg)
+        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6, err_msg=msg)
+        # greedy ids: bit-exact, plain f32 route and (for the widths that have it) the bf16-screened route
+        wi, wb = co.argmax(rx.numpy(), E.numpy())
+        idx, best = ops.catalog_argmax(rx.to(DEV), E.to(DEV), return_best=True, screened=False)
+        np.testing.assert_array_equal(idx.cpu().numpy(), wi, err_msg=msg)
+        np.testing.assert_array_equal(best.cpu().numpy(), wb, err_msg=msg)
+        if D in ops.BF16_DIMS:
+            idx2 = ops.catalog_argmax(rx.to(DEV), E.to(DEV), screened=True)
+            np.testing.assert_array_equal(idx2.cpu().numpy(), wi, err_msg=msg + " (screened)")
+
+
+def test_f32_catalog_random_shapes_fuzz(ops):
+    """20 random (R, N, D, scale) - widths with and without a native kernel, catalogs from one item to 80 000, one row to 600 -
+    through the exact-f32 CE (C oracle, 2e-6 / 2e-5) and both argmax routes (ids and winning scores bit-exact).
+    PCVAE_FUZZ_SEEDS="1,2,.." runs other sequences as well (one-off campaigns; the default is the committed sequence)."""
+    for seed in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "4242").split(",")]:
+        _f32_catalog_sequence(ops, seed)

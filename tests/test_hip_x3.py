@@ -7,6 +7,8 @@ Both operands of both contractions are split into bf16 hi + lo halves and every 
   * an emulation of the kernel's own arithmetic on the CPU, which pins indexing / ring / fill / drain / tail logic on
     shapes where those paths are most of the work.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -259,25 +261,36 @@ def test_x3_d256_large_norms_fall_back_per_row_block(ops):
     np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
 
 
-@pytest.mark.parametrize("Dx", [128, 256])
-def test_x3_random_shapes_fuzz(ops, Dx):
-    """24 random (R, N) per width - every combination of fill / fenced / steady / drain / tail lengths and row-block raggedness the
-    plan produces for small catalogs - against the C oracle at the f32 kernel's tolerances"""
+def _x3_fuzz_sequence(ops, Dx, seed, cases=24):
     import random
     from pivotcvae_amd._hip import PREC_BF16X3
-    rng = random.Random(77 + Dx)
-    for case in range(24):
+    rng = random.Random(seed + Dx)
+    for case in range(cases):
         N = rng.choice([rng.randint(1, 400), rng.randint(401, 6000), rng.randint(6001, 60000)])
         R = rng.randint(1, max(1, min(700, 12_000_000 // N)))
         scale = rng.choice([0.5, 2.0, 4.0])
-        # 16-bit-mantissa operands: a logit is good to ~2^-17 of ITS magnitude, so rows with |logit| up to ~25 (scale 4) are held
-        # to twice the f32 kernel's relative tolerance; the model's own rows (|rx| ~ 1) and the other tests use 2e-6
-        k = 2.0 if scale > 2.0 else 1.0
-        rx, E = rnd(R, Dx, seed=500 + case, scale=scale), orc.normalize_rows(rnd(N, Dx, seed=600 + case))
-        tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(700 + case))
+        rx, E = rnd(R, Dx, seed=seed + 423 + case, scale=scale), orc.normalize_rows(rnd(N, Dx, seed=seed + 523 + case))
+        tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(seed + 623 + case))
+        # 16-bit-mantissa operands: a product is good to 2^-16 of ITS magnitude, a logit to ~1e-6 |x| |E| (2e-6 |x| at three sigma over a few
+        # hundred rows; worst case 1.5e-5 |x| |E|).
+        # Over a large catalog that averages away in lse and dx; over a handful of items with |x| = 26 .. 37 (scale 4: logits up to
+        # +-25) it IS the error of the lse (25-seed campaign, round 3: 3.6e-5 at N = 140, 2.4e-5 at N = 7, 8.8e-6 at N = 1 and |x| = 5).  So the tolerances carry
+        # the row norm: the f32 kernel's own (2e-6 / 2e-5) at the model's scale (|x| <= 8), k = |x| / 8 times that beyond.
+        xn = float(rx.norm(dim=1).max())
+        k = max(1.0, xn / 8.0)
         nll, lse, dx = ops.catalog_ce_raw(rx.to(DEV), ops.CatalogTable(E.to(DEV)), tgt.to(DEV), prec=PREC_BF16X3)
         wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy())
-        np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6 * k, atol=2e-6, err_msg=f"D={Dx} R={R} N={N}")
-        np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6 * k, atol=4e-6 + 2e-6 * k * float(np.abs(wl).max()),
-                                   err_msg=f"D={Dx} R={R} N={N}")   # nll = lse - z_t cancels: the lse's ABSOLUTE error is what it carries
-        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5 * k, atol=2e-6 * k, err_msg=f"D={Dx} R={R} N={N}")
+        msg = f"seed={seed} D={Dx} R={R} N={N} |x|={xn:.1f}"
+        np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6 * k, atol=2e-6 + 2e-6 * xn, err_msg=msg)
+        np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6 * k, atol=4e-6 + 2e-6 * xn + 2e-6 * k * float(np.abs(wl).max()),
+                                   err_msg=msg)   # nll = lse - z_t cancels: the lse's ABSOLUTE error is what it carries
+        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5 * k, atol=2e-6 * k, err_msg=msg)
+
+
+@pytest.mark.parametrize("Dx", [128, 256])
+def test_x3_random_shapes_fuzz(ops, Dx):
+    """24 random (R, N) per width - every combination of fill / fenced / steady / drain / tail lengths and row-block raggedness the
+    plan produces for small catalogs - against the C oracle at the f32 kernel's tolerances.  PCVAE_FUZZ_SEEDS="1,2,.." runs other
+    sequences as well (one-off campaigns; the default is the committed sequence)."""
+    for seed in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "77").split(",")]:
+        _x3_fuzz_sequence(ops, Dx, seed)
