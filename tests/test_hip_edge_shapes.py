@@ -110,3 +110,22 @@ def test_step_and_recommend_at_edge_shapes(shape):
         ok = safe.view(B, S) & same_pivot[:, None]
         assert bool((got[ok] == exp[ok]).all()), f"{shape} {prec}: ids differ on margin-safe rows"
         assert float(same_pivot.float().mean()) >= 0.9 and float(ok.float().mean()) >= 0.8
+
+
+def random_shape(rng):
+    model = rng.choice(["pivotcvae_gt_pi", "pivotcvae_gt_pi", "pivotcvae_pt_pi", "listcvae"])
+    S = rng.choice([2, 3, 5, 7, 10])
+    D = rng.choice([8, 16, 24, 32, 64, 128])
+    N = rng.choice([rng.randint(S + 1, 40), rng.randint(41, 400), rng.randint(401, 3000)])
+    B = rng.choice([1, 2, rng.randint(3, 40), rng.randint(41, 200)])
+    return (model, B, S, D, N, rng.choice([2, 5, 8, 16]), rng.choice([8, 20, 32, 64]), rng.choice([8, 16, 24]), rng.random() < 0.3)
+
+
+def test_step_and_recommend_at_random_shapes():
+    """six random (model, B, S, D, N, Z, hidden, user tower) per sequence through the same checks as the fixed edge shapes.
+    PCVAE_FUZZ_SEEDS="1,2,.." runs other sequences as well (one-off campaigns; the default is the committed sequence)."""
+    import random
+    for seed in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "2026").split(",")]:
+        rng = random.Random(seed)
+        for _ in range(6):
+            test_step_and_recommend_at_edge_shapes(random_shape(rng))
