@@ -993,3 +993,27 @@ def test_f32_catalog_random_shapes_fuzz(ops):
     PCVAE_FUZZ_SEEDS="1,2,.." runs other sequences as well (one-off campaigns; the default is the committed sequence)."""
     for seed in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "4242").split(",")]:
         _f32_catalog_sequence(ops, seed)
+
+
+def test_catalog_ce_sparse_random_shapes_fuzz(ops):
+    """ten random (R, N, D, keep probability, seed, row offset) per sequence through the exactness check of
+    test_catalog_ce_sparse_is_the_documented_stream (kept sets rebuilt on the host from the documented Philox stream).
+    PCVAE_FUZZ_SEEDS="1,2,.." runs other sequences as well (one-off campaigns; the default is the committed sequence)."""
+    import random
+    for sd in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "31337").split(",")]:
+        rng = random.Random(sd)
+        for case in range(10):
+            D = rng.choice([8, 16, 24, 32, 64, 128, 256])
+            N = rng.choice([rng.randint(1, 200), rng.randint(201, 5000), rng.randint(5001, 60000)])
+            R = rng.randint(1, 48)
+            p = rng.choice([0.5, 0.1, 0.02, min(0.9, 300.0 / N), min(0.9, 3000.0 / N)])
+            seed, off = rng.randint(0, 2 ** 40), rng.randint(0, 2 ** 33)
+            rx, E = rnd(R, D, seed=sd + case, scale=2.0), unit_rows(N, D, seed=sd + 100 + case)
+            tgt = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(sd + 200 + case))
+            msg = f"seed={sd} case={case} R={R} N={N} D={D} p={p:.4f}"
+            nll, lse, dx = ops.catalog_ce_sparse_raw(rx.to(DEV), E.to(DEV), tgt.to(DEV), p, seed=seed, row_offset=off)
+            keep = philox_ref.sparse_keep_mask(R, N, p, seed, off)
+            wn, wl, wd = co.ce(rx.numpy(), E.numpy(), tgt.numpy(), keep)
+            np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6, err_msg=msg)
+            np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6 + 2e-6 * float(np.abs(wl).max()), err_msg=msg)
+            np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6, err_msg=msg)
