@@ -1,3 +1,4 @@
+# configs 1-3 on the final tree: kernel stats (eager), step listings, and the hipGraph-replay bench lines -> gpurun_out/prof_small/
 cd /tmp && export TMPDIR=/tmp
 ROOT=$GRAFT_REPO_ROOT; OUT=$ROOT/gpurun_out/prof_small; rm -rf $OUT; mkdir -p $OUT
 stats() {
