@@ -394,11 +394,14 @@ def make_stated_case(name, model, S, D, Z, N, NU, B, H, HP, seed, beta=0.001, lr
 
 
 def make_stated():
-    """round 3: configs 1 and 2 at their stated sizes + the D = 128 case"""
+    """round 3: configs 1 and 2 at their stated sizes + one case per width with MFMA bf16 / bf16x3 kernels (D = 128, 64, 256)"""
     make_stated_case("stated_config1_listcvae", "listcvae", S=5, D=16, Z=16, N=1000, NU=100, B=64, H=256, HP=128, seed=801,
                      n_neg_part=100)
     make_stated_case("stated_config2_gt_pi", "pivotcvae_gt_pi", S=5, D=32, Z=16, N=10000, NU=200, B=1024, H=256, HP=128, seed=802)
     make_stated_case("stated_d128_gt_pi", "pivotcvae_gt_pi", S=10, D=128, Z=16, N=5003, NU=50, B=64, H=128, HP=64, seed=803)
+    # the other two widths with MFMA bf16 kernels (config 3's D = 64, config 5's D = 256 and its slate size), catalogs kept small
+    make_stated_case("stated_d64_gt_pi", "pivotcvae_gt_pi", S=10, D=64, Z=16, N=2003, NU=50, B=64, H=64, HP=32, seed=804)
+    make_stated_case("stated_d256_gt_pi", "pivotcvae_gt_pi", S=6, D=256, Z=16, N=1501, NU=40, B=48, H=64, HP=32, seed=805)
 
 
 def make_response_model(name, N, NU, D, S, B, H, seed):
