@@ -277,7 +277,7 @@ def make_case(name, model, S, D, Z, N, NU, B, H, HP, no_user, seed, beta=0.001, 
     print(f"{name}: {len(out)} arrays, none_grads={len(none_grads)}")
 
 
-def make_stated_case(name, model, S, D, Z, N, NU, B, H, HP, seed, beta=0.001, lr=3e-4, n_neg_part=None):
+def make_stated_case(name, model, S, D, Z, N, NU, B, H, HP, seed, beta=0.001, lr=3e-4, n_neg_part=None, tables_from_seed=False):
     """Round 3: the reference at a BASELINE config's STATED size (configs 1 and 2 of SURVEY.md 8d) and one D = 128 case - the
     width that takes the MFMA bf16 / bf16x3 catalog kernels and the fused train path.  Same recipe as make_case but without the
     dense [R, N] logits: raw tables, state, inputs, recorded eps, the three loss terms at n_neg = N, every .grad, the trained
@@ -301,6 +301,16 @@ def make_stated_case(name, model, S, D, Z, N, NU, B, H, HP, seed, beta=0.001, lr
     out = {"raw_doc": raw_doc.weight.detach().numpy().copy(), "raw_user": raw_user.weight.detach().numpy().copy()}
     for k, v in m.state_dict().items():
         out["sd/" + k] = v.detach().numpy().copy()
+    if tables_from_seed:
+        # a catalog of 10^6 rows is 0.5 GB: the fixture keeps the SEED of the tables and fingerprints of what it produced; the loader
+        # (tests/helpers.py) redraws them with the same torch calls and checks the fingerprints before anything is compared
+        def table_fingerprint(a):   # the same function as in tests/helpers.py
+            sub = np.asarray(a[::97], dtype=np.float64)
+            mid = a.shape[0] // 2
+            return [float(sub.sum()), float(np.abs(sub).sum())] + [float(v) for v in a[0, :3]] + [float(v) for v in a[-1, -3:]] + \
+                   [float(v) for v in a[mid, 1:4]]
+        fp = {key: table_fingerprint(out.pop(key)) for key in ("raw_doc", "raw_user", "sd/docEmbed.weight", "sd/userEmbed.weight")}
+        out["tables/fingerprints"] = np.array(json.dumps(fp))
     out["s"], out["r"], out["u"] = s.numpy(), r.numpy(), u.numpy()
     batch = {"slates": s.numpy(), "users": u.numpy(), "responses": r.numpy()}
     CEL = torch.nn.CrossEntropyLoss()
@@ -386,7 +396,8 @@ def make_stated_case(name, model, S, D, Z, N, NU, B, H, HP, seed, beta=0.001, lr
         out["rec/pivot"] = pivots[0].numpy()
 
     meta = dict(name=name, model=model, S=S, D=D, Z=Z, N=N, NU=NU, B=B, no_user=False, beta=beta, lr=lr,
-                n_neg_part=n_neg_part, structs=st, none_grads=none_grads, seed=seed, torch=torch.__version__)
+                n_neg_part=n_neg_part, structs=st, none_grads=none_grads, seed=seed, torch=torch.__version__,
+                tables_from_seed=bool(tables_from_seed))
     out["meta"] = np.array(json.dumps(meta))
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)
@@ -402,6 +413,13 @@ def make_stated():
     # the other two widths with MFMA bf16 kernels (config 3's D = 64, config 5's D = 256 and its slate size), catalogs kept small
     make_stated_case("stated_d64_gt_pi", "pivotcvae_gt_pi", S=10, D=64, Z=16, N=2003, NU=50, B=64, H=64, HP=32, seed=804)
     make_stated_case("stated_d256_gt_pi", "pivotcvae_gt_pi", S=6, D=256, Z=16, N=1501, NU=40, B=48, H=64, HP=32, seed=805)
+    # config 4's catalog, slate and width AS STATED (N = 10^6, S = 10, D = 128) with 16 slates and narrow hidden layers: the size at
+    # which the headline kernels run their real plans (catalog ranges, ring trips, screened argmax) meets the reference itself
+    make_stated_case("stated_config4_catalog_gt_pi", "pivotcvae_gt_pi", S=10, D=128, Z=16, N=1_000_000, NU=50, B=16, H=64, HP=32,
+                     seed=806, tables_from_seed=True)
+    # ... and config 3's (N = 10^5, S = 10, D = 64: the width and size of the bf16 pipelined kernel), 64 slates
+    make_stated_case("stated_config3_catalog_gt_pi", "pivotcvae_gt_pi", S=10, D=64, Z=16, N=100_000, NU=50, B=64, H=64, HP=32,
+                     seed=807, tables_from_seed=True)
 
 
 def make_response_model(name, N, NU, D, S, B, H, seed):

@@ -9,11 +9,50 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def table_fingerprint(a):
+    """13 numbers of a [rows, D] float32 table: fp64 sum and absolute sum of every 97th row, nine sampled entries (the same function
+    as in tests/golden/make_goldens.py)"""
+    sub = np.asarray(a[::97], dtype=np.float64)
+    mid = a.shape[0] // 2
+    return [float(sub.sum()), float(np.abs(sub).sum())] + [float(v) for v in a[0, :3]] + [float(v) for v in a[-1, -3:]] + \
+           [float(v) for v in a[mid, 1:4]]
+
+
+_TABLES = {}   # golden name -> the four table arrays redrawn from the golden's seed (drawn once per process)
+
+
+def tables_from_seed(meta, fingerprints):
+    """Redraw the raw item / user tables of a golden that keeps only their SEED (a 10^6-row catalog is 0.5 GB), with the same torch
+    calls as tests/golden/make_goldens.py::make_stated_case, normalise them as the reference's constructor does
+    (models/cvae.py:14-36: F.normalize, eps 1e-12) and check every fingerprint the golden recorded - a torch whose CPU generator
+    drew something else fails HERE, loudly, not as a parity mismatch later."""
+    if meta["name"] in _TABLES:
+        return _TABLES[meta["name"]]
+    N, NU, D = meta["N"], meta["NU"], meta["D"]
+    torch.manual_seed(meta["seed"])
+    a = (2.0 / D) ** 0.5
+    raw_doc = torch.nn.Embedding(N, D)
+    raw_doc.weight.data.uniform_(-a, a)
+    raw_user = torch.nn.Embedding(NU, D)
+    raw_user.weight.data.uniform_(-a, a)
+    out = {"raw_doc": raw_doc.weight.detach().numpy(), "raw_user": raw_user.weight.detach().numpy()}
+    out["sd/docEmbed.weight"] = torch.nn.functional.normalize(raw_doc.weight.detach(), p=2, dim=1).numpy()
+    out["sd/userEmbed.weight"] = torch.nn.functional.normalize(raw_user.weight.detach(), p=2, dim=1).numpy()
+    for key, want in fingerprints.items():
+        if not np.allclose(table_fingerprint(out[key]), want, rtol=1e-9, atol=0.0):
+            raise RuntimeError(f"{meta['name']}: tables redrawn from seed {meta['seed']} do not match the golden's fingerprint of {key} "
+                               f"(torch {torch.__version__} here, {meta.get('torch')} when it was minted)")
+    _TABLES[meta["name"]] = out
+    return out
+
+
 class Golden:
     def __init__(self, path):
         z = np.load(path, allow_pickle=False)
         self.meta = json.loads(str(z["meta"]))
-        self.a = {k: z[k] for k in z.files if k != "meta"}
+        self.a = {k: z[k] for k in z.files if k not in ("meta", "tables/fingerprints")}
+        if self.meta.get("tables_from_seed"):
+            self.a.update(tables_from_seed(self.meta, json.loads(str(z["tables/fingerprints"]))))
 
     def t(self, key):
         return torch.from_numpy(np.ascontiguousarray(self.a[key]))

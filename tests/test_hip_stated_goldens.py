@@ -1,6 +1,7 @@
 """-m gpu: the HIP path against goldens minted from the REAL reference at a BASELINE config's stated size (round 3):
 config 1 (List-CVAE N = 1000 S = 5 D = 16 B = 64), config 2 (PivotCVAE gt_pi N = 10 000 S = 5 D = 32 B = 1024) and one case per
-width that takes the MFMA kernels (D = 128, 64, 256), so the bf16x3 (fp32-equivalent) catalog kernel and the fused train route meet
+width that takes the MFMA kernels (D = 128, 64, 256) and the catalogs of configs 3 and 4 as stated (N = 100K / 1M, tables redrawn
+from the golden's seed: tests/helpers.py), so the bf16x3 (fp32-equivalent) catalog kernel and the fused train route meet
 the reference itself, not only the oracle.  Tolerances are the existing ones (tests/test_hip_model_golden.py): ELBO terms
 1e-4 relative, gradients rtol 2e-4, parameters after Adam steps rtol 1e-4 + atol 3e-6, greedy ids bit-exact on rows whose
 top-2 margin is not a rounding tie.  Reference: train_generative.py:44-65, 103, 124-134; models/pivotcvae.py:242-296;

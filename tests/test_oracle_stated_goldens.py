@@ -17,8 +17,13 @@ def close(a, b, rtol, atol):
 
 
 def test_the_stated_cases_exist():
-    assert CASES == ["stated_config1_listcvae", "stated_config2_gt_pi", "stated_d128_gt_pi", "stated_d256_gt_pi", "stated_d64_gt_pi"]
-    assert sorted(load(n).meta["D"] for n in CASES[2:]) == [64, 128, 256]   # every width with MFMA bf16 / bf16x3 catalog kernels
+    assert CASES == ["stated_config1_listcvae", "stated_config2_gt_pi", "stated_config3_catalog_gt_pi", "stated_config4_catalog_gt_pi",
+                     "stated_d128_gt_pi", "stated_d256_gt_pi", "stated_d64_gt_pi"]
+    assert sorted(load(n).meta["D"] for n in CASES[4:]) == [64, 128, 256]   # every width with MFMA bf16 / bf16x3 catalog kernels
+    # configs[2]'s and configs[3]'s catalog, slate and width as stated (64 / 16 slates; tables redrawn from the seed: helpers.py)
+    m3, m4 = load(CASES[2]).meta, load(CASES[3]).meta
+    assert (m3["N"], m3["S"], m3["D"], m3["tables_from_seed"]) == (100_000, 10, 64, True)
+    assert (m4["N"], m4["S"], m4["D"], m4["tables_from_seed"]) == (1_000_000, 10, 128, True)
     m1, m2 = load(CASES[0]).meta, load(CASES[1]).meta
     assert (m1["model"], m1["N"], m1["S"], m1["D"], m1["B"]) == ("listcvae", 1000, 5, 16, 64)          # BASELINE.json configs[0]
     assert (m2["model"], m2["N"], m2["S"], m2["D"], m2["B"]) == ("pivotcvae_gt_pi", 10000, 5, 32, 1024)  # configs[1]
