@@ -18,8 +18,8 @@ def close(a, b, rtol, atol):
 
 def test_the_stated_cases_exist():
     assert CASES == ["stated_config1_listcvae", "stated_config2_gt_pi", "stated_config3_catalog_gt_pi", "stated_config4_catalog_gt_pi",
-                     "stated_d128_gt_pi", "stated_d256_gt_pi", "stated_d64_gt_pi"]
-    assert sorted(load(n).meta["D"] for n in CASES[4:]) == [64, 128, 256]   # every width with MFMA bf16 / bf16x3 catalog kernels
+                     "stated_config4_catalog_pt_pi", "stated_d128_gt_pi", "stated_d256_gt_pi", "stated_d64_gt_pi"]
+    assert sorted(load(n).meta["D"] for n in CASES[5:]) == [64, 128, 256]   # every width with MFMA bf16 / bf16x3 catalog kernels
     # configs[2]'s and configs[3]'s catalog, slate and width as stated (64 / 16 slates; tables redrawn from the seed: helpers.py)
     m3, m4 = load(CASES[2]).meta, load(CASES[3]).meta
     assert (m3["N"], m3["S"], m3["D"], m3["tables_from_seed"]) == (100_000, 10, 64, True)
