@@ -354,6 +354,23 @@ def make_stated_case(name, model, S, D, Z, N, NU, B, H, HP, seed, beta=0.001, lr
             if prm.grad is not None:
                 out["part/grad/" + k] = prm.grad.detach().numpy().copy()
 
+    # ... and where it is not: the draw kept SPARSELY (row, column of every kept entry; ~n_neg per row) - the reference's default
+    # training mode (train_generative.py:44, n_neg = 1000) at a 10^6-item catalog
+    if n_neg_part and B * S * N > 2_000_000:
+        torch.manual_seed(seed + 3)
+        m.zero_grad()
+        with Recorder() as rec:
+            loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m, CEL, beta, n_neg=n_neg_part)
+            loss.backward()
+        nz = rec.masks[0].nonzero()
+        out["part/eps"] = rec.eps[0].numpy()
+        out["part/neg_rows"], out["part/neg_cols"] = nz[:, 0].numpy().astype(np.int32), nz[:, 1].numpy().astype(np.int32)
+        out["part/neg_shape"] = np.array([B * S, N], dtype=np.int64)
+        out["part/loss"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+        for k, prm in m.named_parameters():
+            if prm.grad is not None:
+                out["part/grad/" + k] = prm.grad.detach().numpy().copy()
+
     # three Adam steps
     m2 = build(model, st, raw_doc, raw_user, S, D, Z, False)
     m2.load_state_dict(m.state_dict())
@@ -416,7 +433,7 @@ def make_stated():
     # config 4's catalog, slate and width AS STATED (N = 10^6, S = 10, D = 128) with 16 slates and narrow hidden layers: the size at
     # which the headline kernels run their real plans (catalog ranges, ring trips, screened argmax) meets the reference itself
     make_stated_case("stated_config4_catalog_gt_pi", "pivotcvae_gt_pi", S=10, D=128, Z=16, N=1_000_000, NU=50, B=16, H=64, HP=32,
-                     seed=806, tables_from_seed=True)
+                     seed=806, tables_from_seed=True, n_neg_part=1000)
     # ... and config 3's (N = 10^5, S = 10, D = 64: the width and size of the bf16 pipelined kernel), 64 slates
     make_stated_case("stated_config3_catalog_gt_pi", "pivotcvae_gt_pi", S=10, D=64, Z=16, N=100_000, NU=50, B=64, H=64, HP=32,
                      seed=807, tables_from_seed=True)

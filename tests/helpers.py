@@ -53,6 +53,11 @@ class Golden:
         self.a = {k: z[k] for k in z.files if k not in ("meta", "tables/fingerprints")}
         if self.meta.get("tables_from_seed"):
             self.a.update(tables_from_seed(self.meta, json.loads(str(z["tables/fingerprints"]))))
+        if "part/neg_rows" in self.a:   # a recorded Bernoulli draw kept sparsely: the dense [R, N] mask the reference drew
+            R, N = (int(v) for v in self.a.pop("part/neg_shape"))
+            dense = np.zeros((R, N), dtype=np.uint8)
+            dense[self.a.pop("part/neg_rows"), self.a.pop("part/neg_cols")] = 1
+            self.a["part/neg_sample"] = dense
 
     def t(self, key):
         return torch.from_numpy(np.ascontiguousarray(self.a[key]))

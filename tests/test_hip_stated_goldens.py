@@ -80,8 +80,12 @@ def test_loss_and_gradients(name, prec, trainer_route):
             assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
 
 
-def test_config1_masked_mode_with_the_recorded_draw():
-    g = load("stated_config1_listcvae")
+@pytest.mark.parametrize("name", [n for n in stated_cases() if load(n).has("part/neg_sample")])
+def test_masked_mode_with_the_recorded_draw(name):
+    """the reference's masked mode (n_neg < N: kept logits + zeros elsewhere) on the Bernoulli draw the reference itself made:
+    config 1 (n_neg = 100 of 1000) and config 4's catalog at the reference's DEFAULT n_neg = 1000 of 10^6 (the draw kept as
+    (row, column) pairs in the fixture: ~1000 per row) - 999 000 masked-out zeros per row in the softmax denominator"""
+    g = load(name)
     m = _model(g, "f32")
     loss, rec, kld = m.loss(dev(g.t("s")), dev(g.t("r")), dev(g.t("u")), g.meta["beta"], eps=dev(g.t("part/eps")),
                             keep_mask=dev(g.t("part/neg_sample")))
