@@ -437,6 +437,9 @@ def make_stated():
     # ... and config 3's (N = 10^5, S = 10, D = 64: the width and size of the bf16 pipelined kernel), 64 slates
     make_stated_case("stated_config3_catalog_gt_pi", "pivotcvae_gt_pi", S=10, D=64, Z=16, N=100_000, NU=50, B=64, H=64, HP=32,
                      seed=807, tables_from_seed=True)
+    # ... config 5's slate and width (S = 20, D = 256) over a catalog long enough for the D = 256 kernels' steady-state trips
+    make_stated_case("stated_config5_width_gt_pi", "pivotcvae_gt_pi", S=20, D=256, Z=16, N=200_000, NU=50, B=8, H=32, HP=32,
+                     seed=809, tables_from_seed=True)
     # ... and the argmax-pivot rule in training (pt: the PSM stack trains, the pivot is a greedy id over the 10^6 items inside the loss)
     make_stated_case("stated_config4_catalog_pt_pi", "pivotcvae_pt_pi", S=10, D=128, Z=16, N=1_000_000, NU=50, B=16, H=64, HP=32,
                      seed=808, tables_from_seed=True)

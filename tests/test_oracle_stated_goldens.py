@@ -18,8 +18,11 @@ def close(a, b, rtol, atol):
 
 def test_the_stated_cases_exist():
     assert CASES == ["stated_config1_listcvae", "stated_config2_gt_pi", "stated_config3_catalog_gt_pi", "stated_config4_catalog_gt_pi",
-                     "stated_config4_catalog_pt_pi", "stated_d128_gt_pi", "stated_d256_gt_pi", "stated_d64_gt_pi"]
-    assert sorted(load(n).meta["D"] for n in CASES[5:]) == [64, 128, 256]   # every width with MFMA bf16 / bf16x3 catalog kernels
+                     "stated_config4_catalog_pt_pi", "stated_config5_width_gt_pi", "stated_d128_gt_pi", "stated_d256_gt_pi",
+                     "stated_d64_gt_pi"]
+    assert sorted(load(n).meta["D"] for n in CASES[6:]) == [64, 128, 256]   # every width with MFMA bf16 / bf16x3 catalog kernels
+    m5 = load("stated_config5_width_gt_pi").meta   # configs[4]'s slate and width over 200 000 items (steady-state trips at D = 256)
+    assert (m5["N"], m5["S"], m5["D"], m5["tables_from_seed"]) == (200_000, 20, 256, True)
     # configs[2]'s and configs[3]'s catalog, slate and width as stated (64 / 16 slates; tables redrawn from the seed: helpers.py)
     m3, m4 = load(CASES[2]).meta, load(CASES[3]).meta
     assert (m3["N"], m3["S"], m3["D"], m3["tables_from_seed"]) == (100_000, 10, 64, True)
@@ -57,7 +60,9 @@ def test_three_adam_steps_and_greedy_ids(name):
     g = load(name)
     cfg = g.cfg()
     sd, state = g.sd, {}
-    for step in range(3):
+    # a dense [160, 10^6] softmax costs the CPU seconds per evaluation (and this container's page allocator much more on a bad day):
+    # the 10^6-item cases check the FIRST step only here; the three-step trajectory is held by the other six
+    for step in range(1 if g.meta["N"] >= 500_000 else 3):
         (loss, rec, kld), grads = orc.loss_and_grads(sd, cfg, g.t("s"), g.t("r"), g.t("u"), g.t(f"adam/eps{step}"), g.meta["beta"])
         np.testing.assert_allclose([loss, rec, kld], g.a[f"adam/loss{step}"], rtol=3e-6)
         sd = orc.adam_step(sd, grads, state, g.meta["lr"])
