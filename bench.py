@@ -433,6 +433,13 @@ class StepTimer:
         for _ in range(warmup):
             tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
         graphed = tr.capture_graph and tr._graph is not None
+        # every rank must run the SAME number of steps (each step is an all-reduce): if the capture failed on some rank only, the
+        # eager steps behind the timed region still run on all of them
+        extra = graphed
+        if self.use_dist:
+            flag = torch.tensor([1.0 if graphed else 0.0], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            extra = bool(flag.item() > 0)
         if not graphed:
             ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
         self.sync_all()
@@ -446,17 +453,18 @@ class StepTimer:
             t = torch.tensor([dt], device=self.device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
-        if graphed:
+        if extra:
             # HIP events cannot be recorded inside a hipGraph (ROCm 7.2: hipErrorInvalidHandle, tools/evt_graph_probe.py),
             # so the dominant kernel is timed over the same number of EAGER steps right after the timed region:
             # same kernel, same inputs, same launch stream.
+            was = tr.capture_graph
             tr.capture_graph = False
             ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
             for _ in range(steps):
                 tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
             torch.cuda.synchronize()
             ops.CATALOG_CE_TIMING = None
-            tr.capture_graph = True
+            tr.capture_graph = was
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
         return dict(dt=dt, steps=steps, kern_ms=kern_ms, graphed=graphed, elbo=(loss, rec, kld))
 
