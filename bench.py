@@ -430,8 +430,12 @@ class StepTimer:
             pair[1].record()
             events.append(pair)
 
+        trace = [] if os.environ.get("PCVAE_BENCH_TRACE_ELBO") == "1" else None   # debugging aid: every step's terms on stderr
         for _ in range(warmup):
-            tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
+            if trace is not None:
+                trace.append(tr.step(s, r, u, global_batch=self.B, row_offset=self.lo))
+            else:
+                tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
         graphed = tr.capture_graph and tr._graph is not None
         # every rank must run the SAME number of steps (each step is an all-reduce): if the capture failed on some rank only, the
         # eager steps behind the timed region still run on all of them
@@ -446,8 +450,13 @@ class StepTimer:
         t0 = time.perf_counter()
         for _ in range(steps):
             loss, rec, kld = tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
+            if trace is not None:
+                trace.append((loss, rec, kld))
         self.sync_all()
         dt = time.perf_counter() - t0
+        if trace is not None:
+            for i, t in enumerate(trace):
+                print(f"[elbo trace] step {i}: " + " ".join(f"{float(v):.6f}" for v in t), file=sys.stderr, flush=True)
         ops.CATALOG_CE_TIMING = None
         if self.use_dist:
             t = torch.tensor([dt], device=self.device, dtype=torch.float64)
@@ -564,8 +573,12 @@ def main():
     args = ap.parse_args()
 
     dry = os.environ.get("PCVAE_BENCH_DRYRUN") == "1"
+    # PCVAE_BENCH_REHEARSAL=1: the N > 1 path with every rank on THE SAME GPU and gloo carrying the collectives (RCCL refuses two
+    # ranks on one device) - a rehearsal of sharding, per-rank capture, step counts and the JSON line where only one GPU exists
+    # (the builder's box); its throughput means nothing and the line says so
+    rehearsal = os.environ.get("PCVAE_BENCH_REHEARSAL") == "1"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        if not dry and torch.cuda.device_count() < args.gpus:   # counting devices does not initialise the GPU
+        if not dry and not rehearsal and torch.cuda.device_count() < args.gpus:   # counting devices does not initialise the GPU
             raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} visible")
         self_launch(args.gpus, sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -580,6 +593,8 @@ def main():
     from pivotcvae_amd import ops
     from pivotcvae_amd.train_generative import Trainer
 
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("PCVAE_BENCH_FORCE_DIST") == "1"  # 1-rank RCCL group: exercises the N>1 code on one GPU
@@ -589,7 +604,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29541")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     cfg = dict(CONFIGS[args.config])
     if args.global_batch:
@@ -640,6 +658,7 @@ def main():
                                f"global batch B={B}, full-catalog softmax" + ("" if args.n_neg is None else f" n_neg={args.n_neg}"),
                    "global_batch": B, "per_gpu_batch": B // world, "parallelism": f"dp{world}",
                    "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                   **({"rehearsal": "all ranks on ONE GPU, gloo collectives: checks the N > 1 path, not its speed"} if rehearsal else {}),
                    "catalog_arithmetic": X3_ARITHMETIC if args.dtype == "bf16x3" else args.dtype,
                    "mlp_arithmetic": args.mlp if args.mlp == "f32" else
                    "bf16x3 in the train step's 64 x 64-tile GEMM launches (operands split into bf16 hi + lo in registers, 3 bf16 MFMAs per "

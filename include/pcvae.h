@@ -337,7 +337,9 @@ int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, 
 int pcvae_kernel_timer(int enable);
 int pcvae_kernel_timer_read(float* ms, int* tags, int cap);
 
-/* optimizer.zero_grad() (train_generative.py:124) as a memset on the stream: the flat gradient buffer (+ its statistics tail) */
+/* optimizer.zero_grad() (train_generative.py:124): the flat gradient buffer (+ its statistics tail) zeroed by ONE fill kernel on the
+ * stream.  Deliberately not hipMemsetAsync: as a node of a captured hipGraph the memset is not ordered against its neighbours on
+ * ROCm 7.2 (replayed training drifted off the eager trajectory; csrc/elementwise.hip).  Any pointer / byte count.              */
 int pcvae_zero(void* p, size_t nbytes, pcvae_stream_t stream);
 
 /* the logged ELBO terms of a step (train_generative.py:62-63, :128): out[0..2] = (rec + beta * kld, rec, kld).  A data-parallel

@@ -751,13 +751,31 @@ extern "C" int pcvae_elbo_pack(const float* rec, const float* kld, float beta, f
     return check_launch("elbo_pack");
 }
 
-// zero a buffer on the stream (optimizer.zero_grad(), train_generative.py:124): a memset node, not a fill kernel
+// zero a buffer on the stream (optimizer.zero_grad(), train_generative.py:124).  A KERNEL, not hipMemsetAsync: captured into a hipGraph
+// the memset node is not ordered against its neighbours on ROCm 7.2 - replayed right behind an eager Adam launch on the same stream it
+// cleared gradients that Adam was still reading, or a later node's writes (round 3: hipGraph-replayed training at config 4 drifted
+// off the eager trajectory, KLD 611.33 against 533.36 after six steps, only when the host was NOT running ahead of the GPU;
+// tests/test_hip_model_golden.py::test_graph_replay_after_a_host_sync_follows_the_eager_trajectory).
+__global__ void __launch_bounds__(256) zero_kernel(uint4* __restrict__ p16, size_t n16, unsigned char* __restrict__ tail, size_t ntail) {
+    const uint4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = z;
+    if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 extern "C" int pcvae_zero(void* p, size_t nbytes, pcvae_stream_t stream) {
     PCVAE_REQUIRE(p || nbytes == 0, "zero: bad arguments");
     if (nbytes == 0) return PCVAE_OK;
-    const hipError_t e = hipMemsetAsync(p, 0, nbytes, as_stream(stream));
-    if (e != hipSuccess) { set_error("zero: %s", hipGetErrorString(e)); return PCVAE_ELAUNCH; }
-    return PCVAE_OK;
+    unsigned char* b = static_cast<unsigned char*>(p);
+    // bytes in front of the first 16-byte boundary and behind the last whole 16-byte word (at most 15 each) go one per thread
+    const size_t head = std::min<size_t>(nbytes, (16 - (reinterpret_cast<uintptr_t>(b) & 15)) & 15);
+    if (head) hipLaunchKernelGGL(zero_kernel, dim3(1), dim3(256), 0, as_stream(stream), nullptr, (size_t)0, b, head);
+    const size_t n16 = (nbytes - head) / 16, ntail = (nbytes - head) % 16;
+    if (n16 || ntail) {
+        const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>(cdiv((int64_t)n16, 256 * 4), 2048));
+        hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<uint4*>(b + head), n16,
+                           b + head + 16 * n16, ntail);
+    }
+    return check_launch("zero");
 }
 
 // =============================================================================================

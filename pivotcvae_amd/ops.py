@@ -1396,7 +1396,7 @@ def elbo_pack_(rec, kld, beta, out):
 
 
 def zero_(t):
-    """t[...] = 0 as a memset on the current stream (optimizer.zero_grad())"""
+    """t[...] = 0 by one fill kernel on the current stream (optimizer.zero_grad()); not a memset node: csrc/elementwise.hip"""
     require_device(t)
     if not t.is_contiguous():
         raise ValueError("zero_: contiguous tensor expected")

@@ -62,7 +62,7 @@ class FlatAdam:
 
     def zero_grad(self):
         if self.grad_ext.is_cuda:
-            ops.zero_(self.grad_ext)   # one memset node on the stream (gradients + the statistics tail)
+            ops.zero_(self.grad_ext)   # one fill launch on the stream (gradients + the statistics tail); NOT a memset: csrc/elementwise.hip
         else:
             self.grad_ext.zero_()      # the CPU tests' optimiser (collective logic only)
         for p, g in zip(self.params, self._grad_views()):

@@ -169,3 +169,42 @@ def test_config4_default_masked_mode_at_stated_size():
         assert torch.isfinite(t).item()
     # untrained model, unit-norm table: logits ~ 0, masked softmax over N entries -> rec ~ log N
     assert abs(r0.item() - np.log(cfg["N"])) < 0.2 and r1.item() < r0.item() + 1e-3
+
+
+def test_graph_replay_after_a_host_sync_follows_the_eager_trajectory():
+    """config 4 at its stated size, six optimisation steps: hipGraph replay against eager launches, with the host synchronised after
+    the second step and nothing read back afterwards - the call pattern of a benchmark loop, and the one in which a memset NODE in
+    the captured graph (zero-grad as hipMemsetAsync) raced with the eager Adam launch in front of it on ROCm 7.2: the replayed run
+    drifted off the eager trajectory (KLD 611.33 against 533.36 after six steps, parameters visibly different) in 8 of 8 runs.
+    The two trajectories must agree to rounding: same kernels, same eps stream.  Also: pcvae_zero on odd pointers / sizes."""
+    import bench
+    from pivotcvae_amd import ops
+    from pivotcvae_amd.train_generative import Trainer
+    cfg = bench.CONFIGS["4"]
+    B = cfg["B"]
+    res = {}
+    for mode in ("eager", "graph", "graph again"):
+        model, _ = bench.build_model(cfg, torch.device(DEV), "bf16x3")
+        model.set_mlp_precision("bf16x3")
+        tr = Trainer(model, lr=bench.LR, beta=bench.BETA, capture_graph=mode != "eager")
+        s, r, u = bench.synthetic_batch(cfg, B, torch.device(DEV))
+        for _ in range(2):
+            tr.step(s, r, u)
+        torch.cuda.synchronize()
+        for _ in range(4):
+            loss, rec, kld = tr.step(s, r, u)      # earlier results dropped at once, nothing read back
+        torch.cuda.synchronize()
+        assert mode == "eager" or (tr.capture_failed is None and tr._graph is not None)
+        res[mode] = (rec.item(), kld.item(), tr.opt.flat.clone())
+        del tr, model
+    for mode in ("graph", "graph again"):
+        np.testing.assert_allclose(res[mode][:2], res["eager"][:2], rtol=2e-6)
+        assert float((res[mode][2] - res["eager"][2]).abs().max()) <= 1e-6   # six steps of lr = 1e-3 moved the weights by ~6e-3
+    # the fill kernel behind optimizer.zero_grad(): any alignment, any length
+    buf = torch.full((1000,), 7, dtype=torch.uint8, device=DEV)
+    for lo, n in ((0, 1000), (1, 15), (3, 16), (5, 17), (16, 0), (7, 300), (33, 640), (999, 1)):
+        buf.fill_(7)
+        ops.zero_(buf[lo:lo + n])
+        want = torch.full((1000,), 7, dtype=torch.uint8)
+        want[lo:lo + n] = 0
+        assert torch.equal(buf.cpu(), want), (lo, n)
