@@ -187,12 +187,12 @@ def test_graph_replay_after_a_host_sync_follows_the_eager_trajectory():
         model, _ = bench.build_model(cfg, torch.device(DEV), "bf16x3")
         model.set_mlp_precision("bf16x3")
         tr = Trainer(model, lr=bench.LR, beta=bench.BETA, capture_graph=mode != "eager")
-        s, r, u = bench.synthetic_batch(cfg, B, torch.device(DEV))
-        for _ in range(2):
-            tr.step(s, r, u)
+        data = [bench.synthetic_batch(cfg, B, torch.device(DEV), seed=50 + i) for i in range(3)]   # a different batch every step:
+        for i in range(2):                                                                          # the graph's inputs are refilled
+            tr.step(*data[i % 3])                                                                   # by eager copies
         torch.cuda.synchronize()
-        for _ in range(4):
-            loss, rec, kld = tr.step(s, r, u)      # earlier results dropped at once, nothing read back
+        for i in range(2, 6):
+            loss, rec, kld = tr.step(*data[i % 3])      # earlier results dropped at once, nothing read back
         torch.cuda.synchronize()
         assert mode == "eager" or (tr.capture_failed is None and tr._graph is not None)
         res[mode] = (rec.item(), kld.item(), tr.opt.flat.clone())

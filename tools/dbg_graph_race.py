@@ -15,6 +15,7 @@ for mode in ["eager"] + ["graph"] * runs:
     model.set_mlp_precision("bf16x3")
     tr = Trainer(model, lr=bench.LR, beta=bench.BETA, capture_graph=mode != "eager")
     s, r, u = bench.synthetic_batch(cfg, B, dev)
+    alt = [bench.synthetic_batch(cfg, B, dev, seed=50 + i) for i in range(3)] if os.environ.get("ALT") == "1" else None
     flow = os.environ.get("BENCHFLOW", "")
     if flow:   # pieces of bench.py's StepTimer flow: s = shard + contiguous, k = global_batch / row_offset keywords, y = synchronize after 2 steps
         lo = 0
@@ -22,11 +23,13 @@ for mode in ["eager"] + ["graph"] * runs:
             (s, r, u), lo = tr.shard(s, r, u)
             s, r, u = s.contiguous(), r.contiguous(), u.contiguous()
         kw = dict(global_batch=B, row_offset=lo) if "k" in flow else {}
-        for _ in range(2):
+        for i in range(2):
+            if alt: s, r, u = alt[i % 3]
             tr.step(s, r, u, **kw)
         if "y" in flow:
             torch.cuda.synchronize()
-        for _ in range(steps - 2):
+        for i in range(2, steps):
+            if alt: s, r, u = alt[i % 3]   # a different batch every step: the graph's input buffers are refilled by eager copies
             loss, rec, kld = tr.step(s, r, u, **kw)
     else:
         for _ in range(steps - 1):
