@@ -541,3 +541,35 @@ def test_terms_only_loss_applies_any_upstream_gradient():
     assert grads[0].keys() == grads[1].keys() and any(k.startswith("scm_") for k in grads[0])
     for k in grads[0]:
         close(grads[1][k], grads[0][k], rtol=1e-5, atol=1e-8)
+
+
+def test_train_on_dataset_graph_replay_equals_eager(tmp_path):
+    """the epoch loop with hipGraph replay of the step against eager launches: same seed, same permutations, nothing read back inside
+    an epoch - histories and final parameters must agree to rounding (round 3: a memset node in the captured graph raced with the
+    eager Adam launch in front of it; the step-level tests, which read every step back, never saw it)."""
+    from pivotcvae_amd.train_generative import Trainer, train_on_dataset
+    g = load("pivotcvae_gt_pi_user")
+    gen = torch.Generator().manual_seed(3)
+    L, N, S = 256, g.meta["N"], g.meta["S"]
+    train = {"slates": torch.randint(0, N, (L, S), generator=gen).numpy(), "users": torch.randint(0, g.meta["NU"], (L, 1), generator=gen).numpy(),
+             "responses": (torch.rand(L, S, generator=gen) < 0.5).float().numpy(), "nCandidate": 40}
+    val = {k: v[:64] for k, v in train.items() if k != "nCandidate"}
+
+    class Log:
+        lines = []
+
+        def log(self, msg):
+            self.lines.append(msg)
+
+    res = {}
+    for graph in (False, True):
+        model = build_from_golden(g)
+        trainer = Trainer(model, lr=3e-3, beta=0.001, n_neg=None, capture_graph=graph)   # n_neg = None: the full softmax, capturable
+        hist = train_on_dataset(train, val, model, str(tmp_path / f"gen{int(graph)}.pkl"), Log(), None, bs=64, epochs=4, lr=3e-3, decay=0.0,
+                                beta=0.001, n_neg=N, seed=11, trainer=trainer)   # (no simulator, no eval_fn: the recommendation test is skipped)
+        assert trainer.capture_failed is None and (trainer._graph is not None) == graph
+        res[graph] = (hist, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    np.testing.assert_allclose(res[True][0]["train"], res[False][0]["train"], rtol=2e-6)
+    np.testing.assert_allclose(res[True][0]["val"], res[False][0]["val"], rtol=2e-6)
+    for k, v in res[False][1].items():
+        assert float((res[True][1][k] - v).abs().max()) <= 1e-6, k
