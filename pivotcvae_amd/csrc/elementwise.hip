@@ -1357,7 +1357,7 @@ extern "C" int pcvae_coverage_count(const int64_t* ids, int64_t n, int64_t N, un
                                     pcvae_stream_t stream) {
     PCVAE_REQUIRE(N > 0 && n >= 0 && bits && count && (ids || n == 0), "coverage_count: bad arguments");
     const int64_t words = cdiv(N, 32);
-    (void)hipMemsetAsync(bits, 0, (size_t)words * 4, as_stream(stream));
+    if (int rc = pcvae_zero(bits, (size_t)words * 4, stream)) return rc;   // the fill kernel, never a memset node (pcvae_zero)
     if (n > 0) {
         const int64_t blocks = std::min<int64_t>(cdiv(n, 256), 2048);
         hipLaunchKernelGGL(coverage_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), ids, n, N, bits);
