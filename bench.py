@@ -436,7 +436,9 @@ class StepTimer:
                 trace.append(tr.step(s, r, u, global_batch=self.B, row_offset=self.lo))
             else:
                 tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
-        graphed = tr.capture_graph and tr._graph is not None
+        # capture_graph set = the steps WILL be replayed (captured in the first step if --warmup 0 left that to the timed region): no
+        # event hooks then - an event record inside a capture is an error (hipErrorInvalidHandle)
+        graphed = bool(tr.capture_graph)
         # every rank must run the SAME number of steps (each step is an all-reduce): if the capture failed on some rank only, the
         # eager steps behind the timed region still run on all of them
         extra = graphed
@@ -475,6 +477,7 @@ class StepTimer:
             ops.CATALOG_CE_TIMING = None
             tr.capture_graph = was
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+        graphed = graphed and tr._graph is not None and tr.capture_failed is None   # what actually happened, for the line's label
         return dict(dt=dt, steps=steps, kern_ms=kern_ms, graphed=graphed, elbo=(loss, rec, kld))
 
 
