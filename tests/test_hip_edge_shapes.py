@@ -129,3 +129,27 @@ def test_step_and_recommend_at_random_shapes():
         rng = random.Random(seed)
         for _ in range(6):
             test_step_and_recommend_at_edge_shapes(random_shape(rng))
+
+
+def test_graph_replay_equals_eager_at_random_shapes():
+    """six random shapes per sequence (gt / pt / List-CVAE rules are the capturable ones), four optimisation steps each on two batches
+    in turn: hipGraph replay against eager launches - ELBO terms and final parameters to rounding, the graph really captured.
+    PCVAE_FUZZ_SEEDS as in the test above."""
+    import random
+    from pivotcvae_amd.train_generative import Trainer
+    for seed in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "2027").split(",")]:
+        rng = random.Random(seed)
+        for _ in range(6):
+            model, B, S, D, N, Z, H, HP, no_user = shape = random_shape(rng)
+            res = {}
+            for graph in (False, True):
+                m, cfg, NU = build(model, S, D, N, Z, H, HP, no_user, seed=B + S + D)
+                tr = Trainer(m, lr=LR, beta=BETA, capture_graph=graph)
+                data = [tuple(t.to(DEV) for t in batch(B, S, N, NU, Z, seed=N + i)[:3]) for i in range(2)]
+                for i in range(4):
+                    terms = tr.step(*data[i % 2])
+                torch.cuda.synchronize()
+                assert tr.capture_failed is None and (tr._graph is not None) == graph, shape
+                res[graph] = ([t.item() for t in terms], tr.opt.flat.clone())
+            np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-6, err_msg=str(shape))
+            assert float((res[True][1] - res[False][1]).abs().max()) <= 1e-6, shape
