@@ -124,8 +124,9 @@ int pcvae_linear_bwd_weight(const float* dY, int64_t lddy, const float* X, int64
  * ws == NULL: every weight gradient of the launch runs as ONE batch split - correct, and slow for large layers. */
 enum { PCVAE_GEMM_FWD = 0, PCVAE_GEMM_DX = 1, PCVAE_GEMM_DX_ACC = 2, PCVAE_GEMM_DW = 3 };
 /* OR-ed into `kind`: run this problem in bf16x3 arithmetic (operands split into bf16 hi + lo in registers, three bf16 MFMAs per
- * product, fp32 accumulate: fp32-equivalent at the GEMM tests' tolerances, ~2x faster on MFMA-bound layers).  Takes effect when
- * EVERY problem of a launch carries it and the launch uses the 64 x 64 tiles; otherwise the launch computes in exact fp32.      */
+ * product, fp32 accumulate: 16-bit-mantissa operands, held to the GEMM tests' tolerances, ~2x faster on MFMA-bound layers).  Takes
+ * effect when EVERY problem of a launch carries it (such a launch always uses the 64 x 64 tiles, whatever its size, so a layer's
+ * arithmetic does not depend on the batch); a launch with mixed flags computes in exact fp32.                                    */
 #define PCVAE_GEMM_X3 0x100
 typedef struct pcvae_gemm_desc {
     int32_t kind;

@@ -790,7 +790,11 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
         tiles64 += d.kind == PCVAE_GEMM_FWD ? cdiv(d.M, BM) * cdiv(d.N, BN)
                  : d.kind == PCVAE_GEMM_DW ? 256 : cdiv(d.M, BM) * cdiv(d.K, BN);
     }
-    const bool small = tiles64 < small_below() && !has_dw;   // the weight gradient exists for 64 x 64 tiles only
+    // The weight gradient exists for 64 x 64 tiles only.  A launch whose every problem asks for bf16x3 takes the 64 x 64 tiles at
+    // ANY size: the arithmetic of a layer is then a property of the model (set_mlp_precision), not of the per-rank batch - the
+    // same model at world = 1 and world = 8, or a ragged last batch, runs every GEMM in the same arithmetic (the 32 x 32 K-split
+    // tiles have no bf16x3 body, and launches this small are launch-bound either way).
+    const bool small = tiles64 < small_below() && !has_dw && !x3;
     const size_t ws_need = ws ? group_ws_bytes(descs, n) : 0;
     const bool have_ws = ws != nullptr && ws_need > 0;
     if (have_ws) PCVAE_REQUIRE(ws_bytes >= ws_need, "linear_group: workspace too small (pcvae_linear_group_ws_bytes)");
@@ -841,7 +845,7 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     }
     if (gp.n == 0) return PCVAE_OK;
     PCVAE_REQUIRE(total * 8 < (1LL << 31), "linear_group: launch too large");
-    if (small)   // (the K-split 32 x 32 tiles of small launches stay in exact f32: they are launch-bound, not MFMA-bound)
+    if (small)   // (exact f32 only: a launch that asks for bf16x3 never takes the K-split 32 x 32 tiles, see above)
         hipLaunchKernelGGL((gemm_group_kernel<true, false>), dim3((unsigned)(total * 8)), dim3(256), SMALL_LDS, as_stream(stream), gp);
     else if (has_dw && x3)
         hipLaunchKernelGGL((gemm_group_kernel<false, true, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,

@@ -8,6 +8,8 @@ Two ways in:
   * ``Trainer`` - zero_grad / loss / backward / (all-reduce) / Adam as one object, single GPU or one
     process per GPU over RCCL.
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -112,7 +114,7 @@ class Trainer:
     """
 
     def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None,
-                 capture_graph=False, world_size=None, rank=0):
+                 capture_graph=False, world_size=None, rank=0, resident_batch=False):
         import torch.distributed as dist
         self.model, self.beta, self.n_neg = model, float(beta), n_neg
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
@@ -140,8 +142,14 @@ class Trainer:
             getattr(model, "TRAIN_RULE", "gt") in ("gt", "pt")
         self._graph = None
         self._static = None
+        # hipGraph replay reads its own static input buffers.  Default: the caller's s / r / u are copied into them on EVERY step
+        # (three small launches).  ``resident_batch=True`` is the caller's promise that a batch passed again as the same tensor
+        # objects has not been rewritten in between - an epoch over one resident batch, the benchmark - and skips the copies then.
+        # It is opt-in because tensor._version cannot see writes through raw pointers (this library's own out= kernels, .data).
+        self.resident_batch = bool(resident_batch)
         self._stats, self._in_tail = None, False
         self.capture_failed = None   # the reason, if hipGraph capture was asked for and fell back to eager launches
+        self.on_capture_failed = None   # callable(reason): train_on_dataset routes the fallback into its logger
 
     def shard(self, *tensors):
         """Contiguous shard of a global batch for this rank (+ its offset in the global batch)."""
@@ -203,6 +211,23 @@ class Trainer:
             st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
         self._graph, self._static = graph, st
 
+    def prepare_graph(self, s, r, u, row_offset=0):
+        """Capture the hipGraph of a step for this batch shape now (no parameter update, no collective: two warm-up passes of
+        zero-grad + loss + backward, then the captured pass).  local_phase() calls it on the first step; a caller that times steps
+        calls it BEFORE its timed region (bench.py with --warmup 0).  A failed capture falls back to eager launches, loudly."""
+        if not self.capture_graph or self._graph is not None:
+            return
+        try:
+            self._capture(s, r, u, row_offset)
+        except Exception as e:  # capture is an optimisation: fall back to eager launches, and say so
+            import warnings
+            warnings.warn(f"hipGraph capture failed ({e}); running eagerly")
+            if self.on_capture_failed is not None:
+                self.on_capture_failed(str(e))
+            torch.cuda.synchronize()
+            self.capture_graph, self._graph = False, None
+            self.capture_failed = str(e)
+
     def local_phase(self, s, r, u, eps=None, global_batch=None, row_offset=0):
         """Phase 1 of a step - everything a rank does on its own: zero-grad, local loss (reconstruction term scaled by
         1 / (B_local S world), eps / mask / sampler streams at GLOBAL slate indices), backward into the flat gradient buffer, and
@@ -212,28 +237,20 @@ class Trainer:
         gb = global_batch if global_batch is not None else B * W
         Z = self.model.latent_size
         eps_offset = (self.global_step * gb + row_offset) * Z
-        if self.capture_graph:
-            if self._graph is None:
-                try:
-                    self._capture(s, r, u, row_offset)
-                except Exception as e:  # capture is an optimisation: fall back to eager launches, and say so
-                    import warnings
-                    warnings.warn(f"hipGraph capture failed ({e}); running eagerly")
-                    torch.cuda.synchronize()
-                    self.capture_graph, self._graph = False, None
-                    self.capture_failed = str(e)
+        self.prepare_graph(s, r, u, row_offset)
         if self.capture_graph and self._graph is not None and tuple(s.shape) == tuple(self._static["s"].shape) \
                 and row_offset == self._static["row_offset"]:
             st = self._static
-            # the graph reads its own input buffers; a caller that steps on the SAME (unmodified) tensors again - an epoch over a
-            # resident batch, the benchmark - does not pay three copy launches per step
+            # the graph reads its own input buffers: copy the caller's batch in, unless the caller promised (resident_batch) that
+            # tensors it passes again are unchanged - then only weak references to the last batch are kept, nothing is pinned
             src = (s, r, u)
-            same = st.get("src") is not None and all(a is b and a._version == v for a, (b, v) in zip(src, st["src"]))
+            same = self.resident_batch and st.get("src") is not None and \
+                all(ref() is a and a._version == v for a, (ref, v) in zip(src, st["src"]))
             if not same:
                 st["s"].copy_(s)
                 st["r"].copy_(r)
                 st["u"].copy_(u)
-                st["src"] = [(t, t._version) for t in src]
+                st["src"] = [(weakref.ref(t), t._version) for t in src] if self.resident_batch else None
             if eps is None:
                 ops.philox_normal_(st["eps"], seed=self.model.rng_seed, offset=eps_offset)
             else:
@@ -248,12 +265,12 @@ class Trainer:
         if (self.world > 1 or self.dist is not None) and tail is not None and tail.numel() >= 3:
             # (rec + beta KLD, rec, KLD) as ONE record behind the gradients: the gradient all-reduce sums the statistics with them -
             # a second, latency-bound collective for three floats would cost as much as the first
-            if rec.is_cuda:
+            if rec.is_cuda and loss is None:
                 ops.elbo_pack_(rec, kld, self.beta, tail)
-            else:   # the CPU tests' injected compute (collective logic only)
+            else:   # an injected loss_fn: ITS loss is what was back-propagated and is what gets logged (it may carry extra terms)
                 tail[:3].copy_(host_record())
             self._in_tail = True
-        elif rec.is_cuda:
+        elif rec.is_cuda and loss is None:
             self._stats = ops.elbo_pack_(rec, kld, self.beta, torch.empty(3, dtype=torch.float32, device=rec.device))
         else:
             self._stats = host_record()
@@ -379,6 +396,8 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
         else:
             trainer = Trainer(model, lr=lr, beta=beta, n_neg=None if n_neg >= N else n_neg, process_group=process_group,
                               capture_graph=capture_graph)
+    if getattr(trainer, "on_capture_failed", "absent") is None:   # a capture that falls back to eager launches is a logged event
+        trainer.on_capture_failed = lambda why: log(f"hipGraph capture failed ({why}): training continues with eager launches")
     if val_loss_fn is None:
         def val_loss_fn(m, s, r, u, row_offset):   # forward only, n_neg = the dataset's candidate count (reference :157)
             if m.candidateFlag:

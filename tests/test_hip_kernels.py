@@ -904,8 +904,9 @@ def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
     f32 kernel's: an operand carries 16 mantissa bits (hi + lo), so a product is good to ~6e-6 relative (fp32: 6e-8) and a sum of
     n such products to ~6e-6 sqrt(n) |typical product| - measured 4.6e-4 on the 8192-slate weight gradient of enc_1 with
     uniform(-1, 1) operands, i.e. 1.5e-5 of the tensor's scale (the catalog bf16x3 kernel's gradient is held to 2e-5 of scale).
-    With PCVAE_GEMM_SMALL_BELOW=0 every launch takes the 64 x 64 tiles, i.e. the bf16x3 body (small launches otherwise run the
-    f32 K-split tiles, whatever was asked)."""
+    A launch that asks for bf16x3 takes the 64 x 64 tiles (= the bf16x3 body) at any size (round 4: the arithmetic of a layer
+    does not depend on the batch), so both parametrisations run the same kernels here; PCVAE_GEMM_SMALL_BELOW=0 stays as the pin
+    the exact-f32 reference launches of this test use."""
     import random
     if tiles == "dma_tiles_only":
         monkeypatch.setenv("PCVAE_GEMM_SMALL_BELOW", "0")

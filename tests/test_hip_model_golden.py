@@ -160,25 +160,37 @@ def test_graph_captured_step_equals_eager_step():
     from pivotcvae_amd.train_generative import Trainer
     g = load("pivotcvae_gt_pi_s10")
     s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
-    outs = []
-    for capture in (False, True):
+
+    def run(capture, resident, raw_write):
         m = build_from_golden(g)
         m.rng_seed = 1234
-        tr = Trainer(m, lr=1e-3, beta=g.meta["beta"], capture_graph=capture)
+        tr = Trainer(m, lr=1e-3, beta=g.meta["beta"], capture_graph=capture, resident_batch=resident)
         s2, r2 = s.clone(), r.clone()
         stats = [[float(x) for x in tr.step(s2, r2, u)] for _ in range(4)]
         assert tr.capture_graph == capture  # capture really happened (no silent fallback)
-        # the replayed graph skips its input copies while the caller steps on the same, unmodified tensors: an IN-PLACE change of
-        # those tensors must still reach it (tensor version counters), and so must a new tensor object
+        # an IN-PLACE change of the caller's tensors must reach the replayed graph (by the per-step copy, or - resident_batch - by
+        # the tensor version counters), and so must a new tensor object
         s2[0] = s2[1]
         r2[0] = 1.0 - r2[0]
         stats.append([float(x) for x in tr.step(s2, r2, u)])
         stats.append([float(x) for x in tr.step(torch.flip(s2, [0]).contiguous(), torch.flip(r2, [0]).contiguous(), torch.flip(u, [0]).contiguous())])
-        outs.append((stats, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-5)
-    assert outs[0][0][0] != outs[0][0][1]  # eps (and the parameters) really changed from step to step
-    for k in outs[0][1]:
-        close(outs[1][1][k], outs[0][1][k], rtol=1e-4, atol=2e-6)
+        if raw_write:
+            # a write the version counter cannot see (.data here; this library's own out= kernels write through raw pointers the
+            # same way): the DEFAULT trainer copies its inputs every step, so a refilled persistent batch buffer is what it trains on
+            stats.append([float(x) for x in tr.step(s2, r2, u)])
+            v = s2._version
+            s2.data[2] = s2.data[3]
+            r2.data[2] = 1.0 - r2.data[2]
+            assert s2._version == v
+            stats.append([float(x) for x in tr.step(s2, r2, u)])
+        return stats, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    for resident, raw_write in ((False, True), (True, False)):
+        outs = [run(False, False, raw_write), run(True, resident, raw_write)]
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-5)
+        assert outs[0][0][0] != outs[0][0][1]  # eps (and the parameters) really changed from step to step
+        for k in outs[0][1]:
+            close(outs[1][1][k], outs[0][1][k], rtol=1e-4, atol=2e-6)
 
 
 def test_trainer_with_a_one_rank_rccl_group_equals_the_plain_trainer():
