@@ -87,11 +87,12 @@ def kernel_name(R, N, D, dtype):
     """the dominant kernel's name as rocprofv3 shows it (the library reports which variant a shape runs)"""
     from pivotcvae_amd import _hip
     from pivotcvae_amd import ops
-    if dtype == "bf16x3" and ops.x3_width(D):
-        D = ops.x3_width(D)    # narrower tables run the 128-wide kernel on zero columns
+    if dtype in ("bf16x3", "bf16x6") and ops.split_width(_hip.PREC_NAMES[dtype], D):
+        D = ops.split_width(_hip.PREC_NAMES[dtype], D)    # narrower tables run the 128-wide kernel on zero columns
     v = _hip.lib().pcvae_catalog_ce_variant(R, N, D, _hip.PREC_NAMES[dtype])
     return {0: f"catalog_ce_f32_kernel<{D}>", 1: f"catalog_ce_bf16_fast_kernel<{D}>",
-            2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>", 3: f"catalog_ce_x3_pipe_kernel<{D}, {1 if D == 256 else 2}>"}.get(v, "?")
+            2: f"catalog_ce_bf16_pipe_kernel<{D}, {2 if D == 256 else 4}>", 3: f"catalog_ce_x3_pipe_kernel<{D}, {1 if D == 256 else 2}, 2>",
+            4: f"catalog_ce_x3_pipe_kernel<{D}, 2, 3>"}.get(v, "?")
 
 
 TIMER_GATHER, TIMER_ASSEMBLE = 1, 2   # include/pcvae.h: PCVAE_TIMER_*
@@ -495,7 +496,7 @@ class StepTimer:
 # algorithmic MAC).  bf16x3 = hi/lo bf16 split of BOTH operands, three bf16 MFMAs per product with fp32 accumulation: fp32-
 # equivalent results (tests/test_hip_x3.py: same tolerances as the f32 kernel) on the bf16 pipe.
 ARITH = {"f32": ("f32", PEAK_TFLOPS["f32"], 1), "bf16": ("bf16", PEAK_TFLOPS["bf16"], 1),
-         "bf16x3": ("bf16x3", PEAK_TFLOPS["bf16"], 3)}
+         "bf16x3": ("bf16x3", PEAK_TFLOPS["bf16"], 3), "bf16x6": ("bf16x6", PEAK_TFLOPS["bf16"], 6)}
 
 
 # uniformly random row gathers, chip-wide (MI355X_MICROARCH.md "Indexed rows: gather into LDS"): rows served by the XCD's own L2,
@@ -544,8 +545,10 @@ def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None, traffi
            "ms_per_launch": kern_ms, "algorithmic_flops_per_launch": flops}
     if mult != 1:
         out["mfma_issue_frac"] = ach * mult / peak
-        out["note"] = (f"{mult} bf16 MFMAs per algorithmic multiply-add (hi*hi + hi*lo + lo*hi): `frac` prices the ALGORITHMIC "
-                       f"flops against the bf16 peak, `mfma_issue_frac` the MFMAs actually issued")
+        out["note"] = (f"{mult} bf16 MFMAs per algorithmic multiply-add (one per kept pair of operand components): `frac` prices the "
+                       f"ALGORITHMIC flops against the bf16 peak, `mfma_issue_frac` the MFMAs actually issued; in fp32 terms the "
+                       f"algorithmic rate is {ach / PEAK_TFLOPS['f32']:.2f}x the dense f32-MFMA peak of {PEAK_TFLOPS['f32']} TFLOP/s")
+        out["algorithmic_vs_f32_mfma_peak"] = ach / PEAK_TFLOPS["f32"]
     return out
 
 
@@ -563,13 +566,23 @@ X3_ARITHMETIC = ("bf16x3 - a stated-tolerance fast path, NARROWER than the refer
                  "(tests/test_hip_x3.py); row blocks over the Cauchy-Schwarz logit bound run the exact f32 kernel")
 
 
+X6_ARITHMETIC = ("bf16x6 - the reference's fp32 arithmetic on the bf16 matrix cores: every fp32 operand (table rows, rx rows, softmax "
+                 "numerators) as THREE bf16 components whose sum is the fp32 value exactly (3 x 8 = 24 significand bits), 6 bf16 MFMAs per "
+                 "product (c0c0, c0c1, c1c0, c1c1, c0c2, c2c0; the dropped c1c2, c2c1, c2c2 are <= 2^-25 relative: below the rounding of "
+                 "an fp32 product), every partial product exact, fp32 accumulate; target logit / target row in exact fp32.  Against fp64 "
+                 "its error is that of the exact f32-MFMA kernel on the same inputs (tests/test_hip_x6.py: err <= 2 x the f32 kernel's "
+                 "+ 1 ulp on every shape, on cancelling and large-norm rows; half the f32 kernel's test tolerances against the fp32 "
+                 "oracle); row blocks over the Cauchy-Schwarz logit bound run the exact f32 kernel.  `variants.f32` is the same "
+                 "workload on v_mfma_f32_32x32x2_f32")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="4", choices=sorted(CONFIGS))
-    ap.add_argument("--dtype", default=None, choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16"],
                     help="arithmetic of the catalog contraction of the HEADLINE line.  Default: the reference's own arithmetic - "
                          "exact f32 MFMA (configs 1, 2, 4); configs 3 and 5 are stated in bf16 (BASELINE.json).  The other "
                          "arithmetics - bf16x3 is a stated-tolerance fast path with 16-bit-mantissa operands, NOT fp32 - are "
@@ -638,6 +651,8 @@ def main():
         args.dtype = {"3": "bf16", "5": "bf16"}.get(args.config, "f32")
     if args.dtype == "bf16x3" and ops.x3_width(D) is None:
         raise SystemExit(f"bf16x3 exists for D <= {ops.X3_MAX_PADDED}")
+    if args.dtype == "bf16x6" and ops.x6_width(D) is None:
+        raise SystemExit("bf16x6 exists for D <= 128")
     if args.mlp is None:
         args.mlp = "f32" if args.dtype == "f32" else "bf16x3"
     model, st = build_model(cfg, device, args.dtype)
@@ -680,7 +695,7 @@ def main():
                    "global_batch": B, "per_gpu_batch": B // world, "parallelism": f"dp{world}",
                    "rccl_ranks": dist.get_world_size() if use_dist else 1,
                    **({"rehearsal": "all ranks on ONE GPU, gloo collectives: checks the N > 1 path, not its speed"} if rehearsal else {}),
-                   "catalog_arithmetic": X3_ARITHMETIC if args.dtype == "bf16x3" else args.dtype,
+                   "catalog_arithmetic": {"bf16x3": X3_ARITHMETIC, "bf16x6": X6_ARITHMETIC}.get(args.dtype, args.dtype),
                    "mlp_arithmetic": args.mlp if args.mlp == "f32" else
                    "bf16x3 in the train step's 64 x 64-tile GEMM launches (operands split into bf16 hi + lo in registers, 3 bf16 MFMAs per "
                    "product, fp32 accumulate: gradients within 1e-4 of each tensor's scale of the fp32 reference, ELBO ~1e-6; "
@@ -696,8 +711,9 @@ def main():
         variants = {}
         was_graph = trainer.capture_graph
         trainer.capture_graph = False
-        for dt_name in ("f32", "bf16x3", "bf16"):
+        for dt_name in ("f32", "bf16x6", "bf16x3", "bf16"):
             if dt_name == args.dtype or (dt_name == "bf16x3" and ops.x3_width(D) is None) or \
+                    (dt_name == "bf16x6" and (ops.x6_width(D) is None or D < 64)) or \
                     (dt_name == "bf16" and D not in ops.BF16_DIMS) or args.n_neg is not None:
                 continue
             if dt_name == "f32" and 4.0 * R_local * N * D > 2e14:   # config 5 in exact f32: minutes per step

@@ -43,6 +43,10 @@ extern "C" {
 #define PCVAE_PREC_BF16X3 2 /* fp32-equivalent on the bf16 MFMA pipe: hi/lo bf16 split of both operands, 3 MFMAs per product
                                (D = 128 or 256; E = the bf16 image of pcvae_split_bf16x2, E_lo = the fp32 table.  Narrower
                                tables: the caller zero-pads table and rx to 128 columns - a zero column adds exactly 0) */
+#define PCVAE_PREC_BF16X6 4 /* the reference's fp32 arithmetic on the bf16 MFMA pipe: both operands as THREE bf16 components
+                               (c0 + c1 + c2 = the fp32 value exactly), 6 MFMAs per product (the dropped pairs are <= 2^-25 relative),
+                               fp32 accumulate (D = 128; E = the image of pcvae_split_bf16x3, E_lo = the fp32 table; narrower tables
+                               zero-padded to 128 columns by the caller) */
 #define PCVAE_PREC_SCREENED 3 /* argmax only: bf16 MFMA screening + exact fp32 rescoring of the few candidates;
                                 results identical to PCVAE_PREC_F32 (E = bf16 table, E_lo = fp32 table, D = 64 / 128 / 256) */
 
@@ -285,6 +289,9 @@ int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, pc
  * mantissa bits of E).  D <= 128: [N, 2 D] bf16, row n = hi(E_n) | lo(E_n).  D = 256: two such images of 128 dims back to back,
  * [2][N][256]: image i = hi | lo of dims 128 i .. 128 i + 127 (N * 2 D elements either way)                                  */
 int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* out, pcvae_stream_t stream);
+/* the bf16x6 table image: [N, 3 D] bf16 (D <= 128), row n = c0(E_n) | c1(E_n) | c2(E_n) with c0 = RNE bf16(E), c1 = RNE bf16(E - c0),
+ * c2 = RNE bf16(E - c0 - c1): c0 + c1 + c2 == E exactly for every normal fp32 value.  (models/pivotcvae.py:274: the table operand) */
+int pcvae_split_bf16x3(const float* src, int64_t N, int D, uint16_t* out, pcvae_stream_t stream);
 
 /* a13  simulator click models as in-loop evaluators     env/response_model.py:129-150 (URM), 286-295 (URM_P), 315-323 (URM_P_MR)
  *     out[b, s] = sigmoid(<E[slate]/||E[slate]||, U[user]> + item_bias[slate] + user_bias[user])

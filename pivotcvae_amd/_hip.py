@@ -14,8 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCVAE_LIB") or os.path.join(_HERE, "lib", "libpcvae_hip.so")
 
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
-PREC_F32, PREC_BF16, PREC_BF16X3, PREC_SCREENED = 0, 1, 2, 3
-PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+PREC_F32, PREC_BF16, PREC_BF16X3, PREC_SCREENED, PREC_BF16X6 = 0, 1, 2, 3, 4
+PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
 
 GEMM_FWD, GEMM_DX, GEMM_DX_ACC, GEMM_DW = 0, 1, 2, 3
 GEMM_X3 = 0x100   # OR-ed into a problem's kind: bf16x3 arithmetic (include/pcvae.h: PCVAE_GEMM_X3)
@@ -71,6 +71,7 @@ SIGNATURES = {
     "pcvae_catalog_sample": [_P, _L, _P, _P, _L, _I, _I, _U64, _U64, _P, _P, _SZ, _P],
     "pcvae_split_bf16": [_P, _L, _P, _P, _P],
     "pcvae_split_bf16x2": [_P, _L, _I, _P, _P],
+    "pcvae_split_bf16x3": [_P, _L, _I, _P, _P],
     "pcvae_urm_forward": [_P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _F, _I, _L, _I, _I, _P, _P],
     "pcvae_candidate_draw": [_P, _L, _L, _I, _U64, _U64, _P, _P, _P, _P],
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],

@@ -32,6 +32,7 @@ extern "C" int pcvae_catalog_ce_variant(int64_t R, int64_t N, int D, int prec) {
     if (R <= 0 || N <= 0 || !supported_d(D)) return -1;
     if (prec == PCVAE_PREC_F32) return 0;
     if (prec == PCVAE_PREC_BF16X3) return (D == 128 || D == 256) ? 3 : -1;
+    if (prec == PCVAE_PREC_BF16X6) return D == 128 ? 4 : -1;
     if (prec != PCVAE_PREC_BF16 || (D != 64 && D != 128 && D != 256)) return -1;
     return catalog_bf16_pipelined(D, catalog_plan(R, N, D, PCVAE_PREC_BF16).tiles_per_split) ? 2 : 1;
 }
@@ -70,15 +71,17 @@ extern "C" int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E
         return catalog_ce_bf16(rx, R, reinterpret_cast<const uint16_t*>(E), N, D, e_max_norm, target, keep_prob, seed,
                                row_offset, keep_mask, nll, lse, dx, dx_scale, ws, as_stream(stream));
     }
-    if (prec == PCVAE_PREC_BF16X3) {
-        // E = the [N, 2 D] bf16 hi | lo image (pcvae_split_bf16x2), E_lo = the fp32 table itself (exact target logit / target
-        // row, and the exact f32 kernel for masked calls and for row blocks whose norms rule out the max-free kernel)
-        PCVAE_REQUIRE((D == 128 || D == 256) && E_lo && ((uintptr_t)E_lo % 16 == 0) && e_max_norm > 0.f,
-                      "catalog_ce(bf16x3): needs D = 128 or 256, the fp32 table in E_lo and e_max_norm > 0");
+    if (prec == PCVAE_PREC_BF16X3 || prec == PCVAE_PREC_BF16X6) {
+        // E = the split-bf16 image (pcvae_split_bf16x2: [N, 2 D] c0 | c1; pcvae_split_bf16x3: [N, 3 D] c0 | c1 | c2), E_lo = the
+        // fp32 table itself (exact target logit / target row, and the exact f32 kernel for masked calls and for row blocks whose
+        // norms rule out the max-free kernel)
+        const bool x6 = prec == PCVAE_PREC_BF16X6;
+        PCVAE_REQUIRE((D == 128 || (D == 256 && !x6)) && E_lo && ((uintptr_t)E_lo % 16 == 0) && e_max_norm > 0.f,
+                      "catalog_ce(bf16x3 / bf16x6): needs D = 128 (bf16x3: or 256), the fp32 table in E_lo and e_max_norm > 0");
         if (keep_mask || keep_prob < 1.0f)
             return catalog_ce_f32(rx, R, reinterpret_cast<const float*>(E_lo), N, D, target, keep_prob, seed, row_offset,
                                   keep_mask, nll, lse, dx, dx_scale, ws, as_stream(stream));
-        return catalog_ce_x3(rx, R, reinterpret_cast<const uint16_t*>(E), reinterpret_cast<const float*>(E_lo), N, D,
+        return catalog_ce_x3(rx, R, reinterpret_cast<const uint16_t*>(E), reinterpret_cast<const float*>(E_lo), N, D, x6 ? 3 : 2,
                              e_max_norm, target, nll, lse, dx, dx_scale, ws, as_stream(stream));
     }
     set_error("catalog_ce: precision mode %d not available in this build", prec);

@@ -2054,12 +2054,12 @@ __global__ void catalog_screen_decode_kernel(ScreenParams p, int64_t* __restrict
 
 namespace pcvae {
 
-template <int D>
+template <int D, int NC>
 static int launch_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, float e_max_norm,
                         const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
     constexpr int CT = x3_ct(D);
-    using XG = X3Geo<D, CT>;
-    const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_BF16X3);
+    using XG = X3Geo<D, CT, NC>;
+    const CatalogPlan pl = catalog_plan(R, N, D, NC == 3 ? PCVAE_PREC_BF16X6 : PCVAE_PREC_BF16X3);
     CatParamsB p{};
     p.rx = rx; p.E = Ex; p.target = target; p.R = R; p.N = N; p.dx_scale = dx_scale;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
@@ -2068,19 +2068,19 @@ static int launch_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const fl
     p.pl = p.pm + ns * R;
     p.pU = p.pl + ns * R;
     uint8_t* flags = reinterpret_cast<uint8_t*>(p.pU + ns * R * D);   // [nrb] behind the partials
-    // row blocks whose logit bound allows raw exp2 run the max-free bf16x3 kernel; the others (flag 1) the exact f32 kernel
+    // row blocks whose logit bound allows raw exp2 run the max-free split-bf16 kernel; the others (flag 1) the exact f32 kernel
     hipLaunchKernelGGL((catalog_row_bound_kernel<D>), dim3((unsigned)p.nrb), dim3(256), 0, st, rx, R, e_max_norm, flags);
     p.safe_flags = flags;
     constexpr int lds_pipe = XG::NB * XG::CB;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_x3_pipe_kernel<D, CT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_x3_pipe_kernel<D, CT, NC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
         attr_set = true;
     }
     const dim3 grid((unsigned)(cdiv(R, XG::ROWS) * p.nsplit));
-    hipLaunchKernelGGL((catalog_ce_x3_pipe_kernel<D, CT>), grid, dim3(256), lds_pipe, st, p);
-    int rc = check_launch("catalog_ce_x3");
+    hipLaunchKernelGGL((catalog_ce_x3_pipe_kernel<D, CT, NC>), grid, dim3(256), lds_pipe, st, p);
+    int rc = check_launch(NC == 3 ? "catalog_ce_x6" : "catalog_ce_x3");
     if (rc != PCVAE_OK) return rc;
     hipLaunchKernelGGL((catalog_ce_merge_x3_kernel<D>), dim3((unsigned)cdiv(R, 4)), dim3(256), 0, st, p, Ef, nll, lse, dx);
     rc = check_launch("catalog_ce_merge_x3");
@@ -2090,12 +2090,14 @@ static int launch_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const fl
     return catalog_ce_f32_flagged(rx, R, Ef, N, D, target, nll, lse, dx, dx_scale, ws2, flags, st);
 }
 
-// Ex: the bf16x3 table image (pcvae_split_bf16x2): D / 128 images of [N, 256] bf16, image i = hi | lo of dims 128 i .. 128 i + 127
-int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
+// Ex: the split-bf16 table image.  ncomp = 2 (bf16x3, pcvae_split_bf16x2): D / 128 images of [N, 256] bf16, image i = c0 | c1 of
+// dims 128 i .. 128 i + 127.  ncomp = 3 (bf16x6, pcvae_split_bf16x3): [N, 384] bf16, row n = c0 | c1 | c2 of E_n (D = 128)
+int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, int ncomp, float e_max_norm,
                   const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st) {
-    if (D == 128) return launch_ce_x3<128>(rx, R, Ex, Ef, N, e_max_norm, target, nll, lse, dx, dx_scale, ws, st);
-    if (D == 256) return launch_ce_x3<256>(rx, R, Ex, Ef, N, e_max_norm, target, nll, lse, dx, dx_scale, ws, st);
-    set_error("catalog_ce(bf16x3): D=%d (the kernel exists for D = 128 and 256)", D);
+    if (ncomp == 2 && D == 128) return launch_ce_x3<128, 2>(rx, R, Ex, Ef, N, e_max_norm, target, nll, lse, dx, dx_scale, ws, st);
+    if (ncomp == 2 && D == 256) return launch_ce_x3<256, 2>(rx, R, Ex, Ef, N, e_max_norm, target, nll, lse, dx, dx_scale, ws, st);
+    if (ncomp == 3 && D == 128) return launch_ce_x3<128, 3>(rx, R, Ex, Ef, N, e_max_norm, target, nll, lse, dx, dx_scale, ws, st);
+    set_error("catalog_ce(bf16x%d): D=%d (bf16x3 exists for D = 128 and 256, bf16x6 for D = 128)", ncomp == 3 ? 6 : 3, D);
     return PCVAE_EINVAL;
 }
 

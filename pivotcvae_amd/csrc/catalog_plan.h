@@ -27,7 +27,8 @@ struct CatalogPlan {
 //   bf16 kernels: 256-row workgroups (8 waves), 1 resident per CU, ranges are whole 128-item LDS chunks
 static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     const bool f32 = prec == PCVAE_PREC_F32;
-    const bool x3 = prec == PCVAE_PREC_BF16X3;   // table rows of 4 D bytes: the geometry of the D = 256 bf16 kernel
+    // split-bf16 kernels (bf16x3: table rows of 4 D bytes, the geometry of the D = 256 bf16 kernel; bf16x6: 6 D bytes): one plan
+    const bool x3 = prec == PCVAE_PREC_BF16X3 || prec == PCVAE_PREC_BF16X6;
     const int rows_wg = f32 ? 128 : 256;
     const int quant = (f32 || x3) ? 1 : 4;
     CatalogPlan p;
@@ -95,7 +96,7 @@ int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D,
 int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, int D, float e_max_norm,
                     const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
                     const uint8_t* keep_mask, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st);
-int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, float e_max_norm,
+int catalog_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const float* Ef, int64_t N, int D, int ncomp, float e_max_norm,
                   const int64_t* target, float* nll, float* lse, float* dx, float dx_scale, void* ws, hipStream_t st);
 // the exact f32 kernel restricted to the 256-row blocks whose flag is 1 (the fallback of the max-free bf16x3 kernel)
 int catalog_ce_f32_flagged(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target, float* nll,

@@ -901,6 +901,33 @@ extern "C" int pcvae_split_bf16x2(const float* src, int64_t N, int D, uint16_t* 
     return check_launch("split_bf16x2");
 }
 
+// [N, D] fp32 (D <= 128) -> the table image of the bf16x6 catalog kernel: [N, 3 D] bf16, row n = c0 | c1 | c2 of E_n, three RNE bf16
+// components whose sum is the fp32 value exactly (each difference is exact in fp32: the residual of an 8-bit rounding of a 24-bit
+// significand has at most 16, then at most 8 significant bits)
+__global__ void split_bf16x3_kernel(const float* __restrict__ src, int64_t N, int D, uint16_t* __restrict__ out) {
+    const int64_t n = N * (int64_t)D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / D;
+        const int c = (int)(i - row * D);
+        float x = src[i];
+        uint16_t* o = out + row * 3 * D;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint16_t h = f32_to_bf16_rne(x);
+            o[j * D + c] = h;
+            x -= bf16_bits_to_f32(h);
+        }
+    }
+}
+
+extern "C" int pcvae_split_bf16x3(const float* src, int64_t N, int D, uint16_t* out, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(src && out && N >= 0 && D > 0 && D <= 128, "split_bf16x3: bad arguments (D <= 128)");
+    if (N == 0) return PCVAE_OK;
+    const int64_t blocks = std::min<int64_t>(cdiv(N * D, 256), 4096);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), src, N, D, out);
+    return check_launch("split_bf16x3");
+}
+
 // =============================================================================================
 // downsample on a DENSE logits tensor (train_generative.py:36-42) for callers that hold one (small catalogs; the fused losses
 // never form it): out[r, n] = pred[r, n] if n == slate[r] or Bernoulli(keep_prob) else 0.  The Bernoulli stream is the one the

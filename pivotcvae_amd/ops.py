@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, GEMM_DW, GEMM_DX, GEMM_DX_ACC, GEMM_FWD, GEMM_GROUP_MAX, GEMM_X3, PREC_BF16, PREC_BF16X3,
+from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, GEMM_DW, GEMM_DX, GEMM_DX_ACC, GEMM_FWD, GEMM_GROUP_MAX, GEMM_X3, PREC_BF16, PREC_BF16X3, PREC_BF16X6,
                    PREC_F32, PREC_SCREENED, GemmDesc, check, lib, ptr, require_device, stream)
 
 F32 = torch.float32
@@ -897,7 +897,7 @@ class CatalogTable:
     def __init__(self, weight):
         self.weight = weight
         self._ver = None
-        self._hi = self._x3 = None
+        self._hi = self._x3 = self._x6 = None
         self._pad = {}
         self._emax = 0.0
 
@@ -905,7 +905,7 @@ class CatalogTable:
         w = self.weight
         key = (w.data_ptr(), w._version, tuple(w.shape))
         if self._ver != key:
-            self._hi = self._x3 = None
+            self._hi = self._x3 = self._x6 = None
             self._pad = {}
             self._emax = 0.0
             self._ver = key
@@ -945,6 +945,13 @@ class CatalogTable:
                 check(lib().pcvae_split_bf16x2(ptr(w32, F32), w32.shape[0], w32.shape[1], ptr(x3), stream()), "split_bf16x2")
                 self._x3 = x3
             return self._x3, w32   # E_lo carries the exact fp32 table: row blocks with large norms run the f32 kernel
+        if prec == PREC_BF16X6:
+            w32 = self.padded(x6_width(w.shape[1]))[0].detach()   # narrower tables ride the 128-wide kernel on zero columns
+            if self._x6 is None:
+                x6 = torch.empty(w32.shape[0], 3 * w32.shape[1], dtype=torch.int16, device=w.device)
+                check(lib().pcvae_split_bf16x3(ptr(w32, F32), w32.shape[0], w32.shape[1], ptr(x6), stream()), "split_bf16x3")
+                self._x6 = x6
+            return self._x6, w32
         if self._hi is None:
             hi = torch.empty(w32.shape, dtype=torch.int16, device=w.device)
             check(lib().pcvae_split_bf16(ptr(w32, F32), w32.numel(), ptr(hi), None, stream()), "split_bf16")
@@ -1005,6 +1012,20 @@ X3_MAX_PADDED = 128         # ... and any narrower table runs it on zero columns
 #                             necessary MFMAs and is still 2.2x / 1.6x faster than the exact f32-MFMA kernel at its tolerances
 
 
+X6_DIMS = (128,)            # bf16x6 (three bf16 components per operand = the fp32 operand exactly, 6 MFMAs per product): D = 128;
+#                             narrower tables ride it on zero columns; D = 256 has no such kernel (its ring would not fit a CU's LDS)
+
+
+def x6_width(D):
+    """table width the bf16x6 kernel runs a D-wide catalog at (None: no bf16x6 route for this width: exact f32 then)"""
+    return 128 if D <= 128 else None
+
+
+def split_width(prec, D):
+    """x3_width / x6_width by precision mode"""
+    return x6_width(D) if prec == PREC_BF16X6 else x3_width(D)
+
+
 def x3_width(D):
     """table width the bf16x3 kernel runs a D-wide catalog at (None: no bf16x3 route for this width)"""
     if D in X3_DIMS:
@@ -1055,6 +1076,8 @@ def effective_precision(prec, D):
         return PREC_BF16
     if prec == PREC_BF16X3 and x3_width(D) is not None:
         return PREC_BF16X3
+    if prec == PREC_BF16X6 and x6_width(D) is not None:
+        return PREC_BF16X6
     return PREC_F32
 
 
@@ -1087,9 +1110,9 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     if keep_mask is None and keep_prob < 1.0 and sparse_ce_applies(keep_prob, N):
         return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx, dx_scale)
     if keep_mask is not None or keep_prob < 1.0:
-        prec = PREC_F32 if prec == PREC_BF16X3 else prec   # masked calls: the x3 kernel is max-free / mask-free
+        prec = PREC_F32 if prec in (PREC_BF16X3, PREC_BF16X6) else prec   # masked calls: the split-bf16 kernels are max-free / mask-free
     E, E_lo = table.operands(prec)
-    D = x3_width(D0) if prec == PREC_BF16X3 else _padded_width(D0)
+    D = split_width(prec, D0) if prec in (PREC_BF16X3, PREC_BF16X6) else _padded_width(D0)
     rx = _pad_cols(rx, D)
     nll = torch.empty(R, dtype=F32, device=rx.device)
     lse = torch.empty(R, dtype=F32, device=rx.device)

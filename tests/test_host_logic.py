@@ -208,8 +208,9 @@ def test_pipelined_kernel_steady_state_loop_has_no_compiler_copies():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     kernels = mod.hot_loops()
-    assert len(kernels) >= 11, "pipelined kernels not found in the generated ISA"   # 3 CE + 2 bf16x3 CE + 6 screening instantiations
-    assert sum("x3" in name for name in kernels) == 2                              # D = 128 and D = 256
+    assert len(kernels) >= 12, "pipelined kernels not found in the generated ISA"   # 3 CE + 3 split-bf16 CE + 6 screening instantiations
+    assert sum("x3" in name for name in kernels) == 3                              # bf16x3 at D = 128 and D = 256, bf16x6 at D = 128
+    assert sum("x3_pipe_kernel<128, 2, 3>" in name for name in kernels) == 1       # (round 4) the bf16x6 instantiation
     # no asm MFMA anywhere in these kernels reads a VGPR that a VALU instruction wrote fewer than two wait states earlier (hipcc
     # does not protect inline-asm MFMAs; round 3 met a stale read behind the loop-entry copies of the bf16x3 kernel)
     fresh, n_mfma = mod.mfma_fresh_operand_reads()
@@ -257,6 +258,9 @@ def test_catalog_kernel_choice_and_range_alignment(monkeypatch):
     assert L.pcvae_catalog_ce_variant(64, 1000, 256, _hip.PREC_BF16) == 2
     assert L.pcvae_catalog_ce_variant(64, 1000, 32, _hip.PREC_BF16) == -1
     assert L.pcvae_catalog_ce_variant(0, 1000, 128, _hip.PREC_BF16) == -1
+    assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_BF16X3) == 3
+    assert L.pcvae_catalog_ce_variant(81920, 1_000_000, 128, _hip.PREC_BF16X6) == 4     # bf16x6: D = 128 only
+    assert L.pcvae_catalog_ce_variant(163840, 10_000_000, 256, _hip.PREC_BF16X6) == -1
     monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1")
     assert L.pcvae_catalog_ce_variant(256, 8192, 128, _hip.PREC_BF16) == 2
     monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1000000000")
