@@ -496,7 +496,7 @@ class StepTimer:
 # algorithmic MAC).  bf16x3 = hi/lo bf16 split of BOTH operands, three bf16 MFMAs per product with fp32 accumulation: fp32-
 # equivalent results (tests/test_hip_x3.py: same tolerances as the f32 kernel) on the bf16 pipe.
 ARITH = {"f32": ("f32", PEAK_TFLOPS["f32"], 1), "bf16": ("bf16", PEAK_TFLOPS["bf16"], 1),
-         "bf16x3": ("bf16x3", PEAK_TFLOPS["bf16"], 3), "bf16x6": ("bf16x6", PEAK_TFLOPS["bf16"], 6)}
+         "bf16x3": ("bf16x3", PEAK_TFLOPS["bf16"], 3), "bf16x6": ("bf16x6 (24-bit operands = the fp32 values, fp32-exact products, fp32 accumulate)", PEAK_TFLOPS["bf16"], 6)}
 
 
 # uniformly random row gathers, chip-wide (MI355X_MICROARCH.md "Indexed rows: gather into LDS"): rows served by the XCD's own L2,
@@ -566,6 +566,48 @@ X3_ARITHMETIC = ("bf16x3 - a stated-tolerance fast path, NARROWER than the refer
                  "(tests/test_hip_x3.py); row blocks over the Cauchy-Schwarz logit bound run the exact f32 kernel")
 
 
+def arithmetic_error_vs_fp64(model, cfg, r, u, device, rows=320):
+    """Error of the catalog kernels against fp64 on rows the MODEL itself produces (rx of `recommend` for the first slates of the
+    batch) over the whole table: max |lse - lse64| and max |dx - dx64| / max |dx64| per arithmetic.  fp64 softmax by torch on the
+    device, chunked over the catalog (an independent path; measurement only, outside every timed region)."""
+    from pivotcvae_amd import ops
+    from pivotcvae_amd._hip import PREC_NAMES
+    N, S, D = cfg["N"], cfg["S"], cfg["D"]
+    nb = max(1, rows // S)
+    with torch.no_grad():
+        rx = model.recommend(r[:nb], u[:nb])[0].reshape(-1, D).contiguous()
+    R = rx.shape[0]
+    E = model.docEmbed.weight.detach()
+    tgt = torch.randint(0, N, (R,), device=device, generator=torch.Generator(device=device).manual_seed(7))
+    m = torch.full((R,), -float("inf"), device=device, dtype=torch.float64)
+    ssum = torch.zeros(R, device=device, dtype=torch.float64)
+    num = torch.zeros(R, D, device=device, dtype=torch.float64)
+    step = max(1, min(N, int(2.5e8 // max(R, 1))))
+    for c0 in range(0, N, step):
+        Ec = E[c0:c0 + step].double()
+        lg = rx.double() @ Ec.t()
+        mn = torch.maximum(m, lg.max(1)[0])
+        sc = torch.exp(m - mn)
+        pe = torch.exp(lg - mn[:, None])
+        ssum = ssum * sc + pe.sum(1)
+        num = num * sc[:, None] + pe @ Ec
+        m = mn
+    lse64 = m + torch.log(ssum)
+    dx64 = num / ssum[:, None] - E[tgt].double()
+    out = {"rows": R, "row_source": "rx of model.recommend on the batch's first slates (real model outputs)", "items": N,
+           "max_abs_lse64": float(lse64.abs().max()), "max_row_norm": float(rx.norm(dim=1).max())}
+    table = model.catalog_table()
+    for name in ("f32", "bf16x6", "bf16x3", "bf16"):
+        if ops.effective_precision(PREC_NAMES[name], D) != PREC_NAMES[name]:
+            continue
+        _, lse, dx = ops.catalog_ce_raw(rx, table, tgt, prec=PREC_NAMES[name])
+        el = lse.double() - lse64
+        out[name] = {"lse_max_abs_err": float(el.abs().max()), "lse_rms_err": float(el.pow(2).mean().sqrt()),
+                     "lse_mean_err": float(el.mean()),
+                     "dx_max_err_over_scale": float((dx.double() - dx64).abs().max() / dx64.abs().max())}
+    return out
+
+
 X6_ARITHMETIC = ("bf16x6 - the reference's fp32 arithmetic on the bf16 matrix cores: every fp32 operand (table rows, rx rows, softmax "
                  "numerators) as THREE bf16 components whose sum is the fp32 value exactly (3 x 8 = 24 significand bits), 6 bf16 MFMAs per "
                  "product (c0c0, c0c1, c1c0, c1c1, c0c2, c2c0; the dropped c1c2, c2c1, c2c2 are <= 2^-25 relative: below the rounding of "
@@ -583,13 +625,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="4", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default=None, choices=["f32", "bf16x6", "bf16x3", "bf16"],
-                    help="arithmetic of the catalog contraction of the HEADLINE line.  Default: the reference's own arithmetic - "
-                         "exact f32 MFMA (configs 1, 2, 4); configs 3 and 5 are stated in bf16 (BASELINE.json).  The other "
-                         "arithmetics - bf16x3 is a stated-tolerance fast path with 16-bit-mantissa operands, NOT fp32 - are "
-                         "measured as named blocks under `variants`")
+                    help="arithmetic of the catalog contraction of the HEADLINE line.  Default: the reference's own arithmetic (fp32 "
+                         "operands, fp32 accumulate) - config 4 (D = 128): bf16x6, every fp32 operand as three bf16 components = "
+                         "exactly the fp32 value, six bf16 MFMAs per product; configs 1, 2: f32 (v_mfma_f32_32x32x2_f32; they are "
+                         "launch-bound); configs 3 and 5 are stated in bf16 (BASELINE.json).  The other arithmetics - f32 always, "
+                         "bf16x3 (a stated-tolerance fast path with 16-bit-mantissa operands, NOT fp32), bf16 - are measured as "
+                         "named blocks under `variants`")
     ap.add_argument("--mlp", default=None, choices=["f32", "bf16x3"],
                     help="arithmetic of the MLP GEMMs of the train step.  Default: bf16x3 where the catalog contraction runs in bf16x3 "
-                         "or bf16 (the whole step then computes on the bf16 matrix cores), exact f32 MFMA with --dtype f32")
+                         "or bf16 (the whole step then computes on the bf16 matrix cores), exact f32 MFMA with --dtype f32 / bf16x6")
     ap.add_argument("--n_neg", type=int, default=None, help="default: N (full-catalog softmax)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the mlp_roofline / gather_roofline / generate / eval blocks")
@@ -648,13 +692,16 @@ def main():
     if B % world:
         raise SystemExit("global batch not divisible by the number of GPUs")
     if args.dtype is None:
-        args.dtype = {"3": "bf16", "5": "bf16"}.get(args.config, "f32")
+        # the reference's own arithmetic: fp32 operands, fp32 accumulation - on v_mfma_f32_32x32x2_f32 ("f32"), and where the
+        # bf16x6 kernel exists and the catalog is large enough to be MFMA-bound (D = 128: config 4) on the bf16 matrix cores with
+        # every fp32 operand carried exactly as three bf16 components; `variants.f32` is in the same line
+        args.dtype = {"3": "bf16", "5": "bf16"}.get(args.config, "bf16x6" if D == 128 else "f32")
     if args.dtype == "bf16x3" and ops.x3_width(D) is None:
         raise SystemExit(f"bf16x3 exists for D <= {ops.X3_MAX_PADDED}")
     if args.dtype == "bf16x6" and ops.x6_width(D) is None:
         raise SystemExit("bf16x6 exists for D <= 128")
     if args.mlp is None:
-        args.mlp = "f32" if args.dtype == "f32" else "bf16x3"
+        args.mlp = "bf16x3" if args.dtype in ("bf16x3", "bf16") else "f32"
     model, st = build_model(cfg, device, args.dtype)
     model.set_mlp_precision(args.mlp)
     # hipGraph replay pays off when the step is launch-bound (per-rank batch <= 4096 slates: ~50 launches of 5-30 us);
@@ -736,6 +783,9 @@ def main():
                                                                  traffic=committed_traffic(f"config{args.config}_nneg1000_gpus{world}"))}
         trainer.capture_graph = was_graph
         out["variants"] = variants
+    if single and not args.no_variants and cfg.get("model") != "listcvae" and N * D <= 2.6e8:
+        # what "the reference's arithmetic" means in numbers: every arithmetic of this line against fp64, measured live
+        out["arithmetic_error_vs_fp64"] = arithmetic_error_vs_fp64(model, cfg, r, u, device)
     if single and not args.no_cpu_baseline:
         base, parity = cpu_baseline_and_parity(model, st, cfg, args.dtype)
         out["cpu_baseline"] = base

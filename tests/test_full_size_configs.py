@@ -64,8 +64,9 @@ def model_rx(model, s, r, u, eps):
 
 
 # per arithmetic: (lse/nll rtol, atol, gradient tolerance relative to its scale)
-TOL = {"f32": (2e-6, 4e-6, 2e-5), "bf16x3": (2e-6, 4e-6, 2e-5), "bf16": (2e-3, 3e-2, 2e-2)}
-CASES = [("2", ["f32", "bf16x3"]), ("3", ["bf16", "bf16x3", "f32"]), ("4", ["bf16x3", "bf16", "f32"]), ("5", ["bf16", "bf16x3"])]
+TOL = {"f32": (2e-6, 4e-6, 2e-5), "bf16x6": (2e-6, 4e-6, 2e-5), "bf16x3": (2e-6, 4e-6, 2e-5), "bf16": (2e-3, 3e-2, 2e-2)}
+CASES = [("2", ["f32", "bf16x3", "bf16x6"]), ("3", ["bf16", "bf16x3", "bf16x6", "f32"]), ("4", ["bf16x6", "bf16x3", "bf16", "f32"]),
+         ("5", ["bf16", "bf16x3"])]
 
 
 @pytest.mark.parametrize("config,dtypes", CASES)
@@ -100,7 +101,8 @@ def test_config_at_stated_size(config, dtypes):
         nll, lse, dx = ops.catalog_ce_raw(rx, table, tgt, prec=PREC_NAMES[name])
         assert torch.isfinite(nll).all() and torch.isfinite(dx).all()
         eff = name   # widths without a bf16 / bf16x3 kernel compute in exact f32 (ops.effective_precision)
-        if (name == "bf16x3" and ops.x3_width(D) is None) or (name == "bf16" and D not in ops.BF16_DIMS):
+        if (name == "bf16x3" and ops.x3_width(D) is None) or (name == "bf16" and D not in ops.BF16_DIMS) or \
+                (name == "bf16x6" and ops.x6_width(D) is None):
             eff = "f32"
         rt, at, gt = TOL[eff]
         torch.testing.assert_close(lse[pick].double(), want_lse, rtol=rt, atol=at)

@@ -65,6 +65,8 @@ def arithmetics(D):
     out = ["f32"]
     if ops.x3_width(D) is not None:
         out.append("bf16x3")
+    if ops.x6_width(D) is not None:
+        out.append("bf16x6")
     return out
 
 

@@ -14,8 +14,9 @@ from tests.gpu_util import DEV, build_from_golden, close, dev
 from tests.helpers import load, stated_cases
 
 pytestmark = pytest.mark.gpu
-# bf16x3: natively at D = 128, on zero-padded columns at D = 16 / 32 (ops.x3_width) - the reference-precision fast path of every case
-CASES = [(n, p) for n in stated_cases() for p in ("f32", "bf16x3")]
+# bf16x3 (16-bit-mantissa operands) and bf16x6 (round 4: the fp32 operands themselves as three bf16 components): natively at D = 128,
+# on zero-padded columns at narrower widths (ops.x3_width / ops.x6_width); D = 256 has no bf16x6 kernel - it computes in exact f32 there
+CASES = [(n, p) for n in stated_cases() for p in ("f32", "bf16x6", "bf16x3")]
 
 
 def adam_close(got, want, lr, steps, rtol=1e-4, atol=3e-6):
