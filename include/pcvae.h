@@ -339,7 +339,9 @@ int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, 
 /* Measurement only (bench.py, tools/): per-kernel durations from HIP events attached to the dispatch itself.  While enabled, the
  * instrumented launches (tags below) go out through hipExtLaunchKernelGGL with a start / stop event pair; read returns the number
  * of timed launches and fills their durations (ms) and tags in launch order.  No reference counterpart (the reference times with
- * time.time(), train_generative.py:113).                                                                                       */
+ * time.time(), train_generative.py:113).
+ * This is the library's ONE piece of process-global state: the switch applies to the instrumented launches of every thread and
+ * the durations are kept in a process-wide list - off by default, never toggle it while another thread is launching.           */
 #define PCVAE_TIMER_GATHER 1        /* gather_rows_vec4_kernel      (pcvae_gather_rows)      */
 #define PCVAE_TIMER_ASSEMBLE 2      /* assemble_inputs_vec_kernel   (pcvae_assemble_inputs)  */
 int pcvae_kernel_timer(int enable);

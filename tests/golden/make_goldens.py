@@ -567,7 +567,39 @@ def make_analysis(name="response_analysis"):
     print(f"{name}: coverage {cov}")
 
 
+def make_pickles():
+    """round 4, SURVEY 8(f)4: two WHOLE-MODULE pickles written the way the reference writes its checkpoints
+    (train_generative.py:198-213: ``torch.save(model, open(path, 'wb'))``; the click model is loaded the same way, :259): the gt_pi
+    model of case ``pivotcvae_gt_pi_user`` in its initial state and the click model of case ``response_mlp`` - rebuilt from those
+    cases' seeds and checked against their committed ``sd/`` arrays before anything is written.  A pickle is data: tensors, the
+    hyper-parameter attributes and the CLASS PATHS models.pivotcvae.UserPivotCVAE / env.response_model.UserResponseModel_MLP."""
+    keys = list(ref_pivot.PIVOTCVAE_MODELS)
+    seed = 100 + keys.index("pivotcvae_gt_pi")
+    S, D, Z, N, NU, H, HP = 5, 16, 4, 203, 11, 24, 12
+    torch.manual_seed(seed)
+    a = (2.0 / D) ** 0.5
+    raw_doc = torch.nn.Embedding(N, D)
+    raw_doc.weight.data.uniform_(-a, a)
+    raw_user = torch.nn.Embedding(NU, D)
+    raw_user.weight.data.uniform_(-a, a)
+    m = build("pivotcvae_gt_pi", structs("pivotcvae_gt_pi", S, D, Z, H, HP, False), raw_doc, raw_user, S, D, Z, False)
+    gold = np.load(os.path.join(OUT, "pivotcvae_gt_pi_user.npz"))
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.numpy(), gold["sd/" + k]), k
+    torch.save(m, open(os.path.join(OUT, "ref_pickle_pivotcvae_gt_pi_user.pt"), "wb"))
+    torch.manual_seed(401)
+    rm = quiet(ref_env.UserResponseModel_MLP, 203 - 1, 11 - 1, 16, 5, [(5 + 1) * 16, 24, 24, 5], "cpu", False)
+    gold = np.load(os.path.join(OUT, "response_mlp.npz"))
+    for k, v in rm.state_dict().items():
+        assert np.array_equal(v.numpy(), gold["sd/" + k]), k
+    torch.save(rm, open(os.path.join(OUT, "ref_pickle_response_mlp.pt"), "wb"))
+    print("ref_pickle_pivotcvae_gt_pi_user.pt, ref_pickle_response_mlp.pt written (states equal the committed goldens')")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "pickles":   # round 4 (every earlier case stays byte-identical)
+        make_pickles()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "response_analysis":
         make_analysis()
         return
@@ -600,6 +632,7 @@ def main():
     make_urm("response_urm", N=203, NU=11, D=16, S=5, B=9, seed=601)
     make_candidates("candidate_sets", N=40, S=5, Cn=12, L=16, seed=701)
     make_stated()
+    make_pickles()
 
 
 if __name__ == "__main__":
