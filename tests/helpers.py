@@ -92,3 +92,78 @@ def stated_cases():
 
 def load(name):
     return Golden(os.path.join(GOLDEN, name + ".npz"))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# LeakyReLU kinks: the one place where two arithmetics can differ by MORE than their rounding.  A hidden unit whose pre-activation
+# lies within the arithmetic's perturbation of zero for some slate takes the other slope there; its derivative jumps 1 <-> 0.01 for
+# that ONE slate, and that slate's share of (a) the unit's own row of its layer's weight gradient and bias gradient and (b) every
+# gradient BELOW that layer changes discretely.  The tests that allow such entries name their cause with this.
+LEAKY_STACKS = {"pivot": ("enc", "scm", "prior"), "list": ("enc", "dec", "prior")}
+
+
+def leaky_kinks(sd, meta, s, r, u, eps, rel):
+    """fp64 forward of the trained stacks from a state_dict (reference models/pivotcvae.py:159-227, 229-240, ground-truth pivot):
+    -> {"enc_1": {unit: [slates]}, ...}: units j of LeakyReLU layer `name` with |pre[b, j]| < rel * sum_k |x[b, k]| |W[j, k]| for some
+    slate b (`rel`: the relative error of one product in the arithmetic under test; the sum of absolute products bounds what a
+    change of arithmetic can move the pre-activation by)."""
+    tables = {k: torch.as_tensor(sd[k]) for k in ("docEmbed.weight", "userEmbed.weight") if k in sd}   # (up to 0.5 GB: rows only)
+    sd = {k: torch.as_tensor(v).double() for k, v in sd.items() if k not in tables}
+    S, D, no_user = meta["S"], meta["D"], meta["no_user"]
+    B = s.shape[0]
+    E = tables["docEmbed.weight"]
+    emb = E[s.reshape(-1)].double().reshape(B, S * D)
+    cond = torch.zeros(B, S + 1, dtype=torch.float64)
+    cond[torch.arange(B), r.sum(1).long()] = 1.0
+    parts_u = [] if no_user else [tables["userEmbed.weight"][u.reshape(-1)].double()]
+    kinks = {}
+
+    def stack(prefix, x, last_linear):
+        n = 0
+        while f"{prefix}_{n + 1}.weight" in sd:
+            n += 1
+        for i in range(1, n + 1):
+            W, b = sd[f"{prefix}_{i}.weight"], sd[f"{prefix}_{i}.bias"]
+            pre = x @ W.t() + b
+            if not (last_linear and i == n):
+                bound = rel * (x.abs() @ W.abs().t() + b.abs())
+                hit = (pre.abs() < bound).nonzero()
+                if hit.numel():
+                    d = kinks.setdefault(f"{prefix}_{i}", {})
+                    for bb, j in hit.tolist():
+                        d.setdefault(j, []).append(bb)
+                x = torch.where(pre > 0, pre, 0.01 * pre)
+            else:
+                x = pre
+        return x
+
+    h = stack("enc", torch.cat([emb, cond] + parts_u, 1), False)
+    mu = h @ sd["encmu.weight"].t() + sd["encmu.bias"]
+    lv = h @ sd["enclogvar.weight"].t() + sd["enclogvar.bias"]
+    z = torch.as_tensor(eps).double() * torch.exp(0.5 * lv) + mu
+    stack("prior", torch.cat([cond] + parts_u, 1), False)
+    if meta["model"] == "listcvae":
+        stack("dec", torch.cat([z, cond] + parts_u, 1), True)
+    else:
+        stack("scm", torch.cat([z, cond, E[s[:, 0]].double()] + parts_u, 1), True)
+    return kinks
+
+
+def explain_by_kinks(name, off_rows, kinks, model):
+    """`off_rows`: rows (output units) of parameter `name` (e.g. "enc_2.weight") that hold out-of-tolerance gradient entries.  Assert
+    that LeakyReLU kinks explain them: with L* the highest kinked layer of the chain that feeds back into this parameter (its own
+    stack from its layer up; for the encoder also the whole decoder stack, which z feeds), the parameter must sit AT L* - then the
+    offending rows are kinked units of that layer - or below it.  -> a description for the log."""
+    stem = name.rsplit(".", 1)[0]
+    heads = {"encmu": ("enc", 99), "enclogvar": ("enc", 99), "priorMu": ("prior", 99), "priorLogvar": ("prior", 99)}
+    stk, layer = heads[stem] if stem in heads else (stem.rsplit("_", 1)[0], int(stem.rsplit("_", 1)[1]))
+    dec = "dec" if model == "listcvae" else "scm"
+    chain = [(k.rsplit("_", 1)[0], int(k.rsplit("_", 1)[1])) for k in kinks]
+    above = [(a, i) for a, i in chain if (a == stk and i >= layer) or (stk == "enc" and a == dec)]
+    assert above, f"{name}: {len(off_rows)} rows out of tolerance and no LeakyReLU kink at or above it (kinks: {sorted(kinks)})"
+    own_top = max([i for a, i in above if a == stk], default=None)
+    if own_top == layer and not any(a == dec for a, i in above if stk == "enc"):
+        units = set(kinks[f"{stk}_{layer}"])
+        assert set(off_rows) <= units, f"{name}: rows {sorted(set(off_rows) - units)} out of tolerance are not kinked units {sorted(units)}"
+        return f"{name}: rows {sorted(set(off_rows))} = kinked units of {stk}_{layer}"
+    return f"{name}: {len(set(off_rows))} rows, below the kink(s) at {sorted(above)}"

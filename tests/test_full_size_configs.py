@@ -173,6 +173,51 @@ def test_config4_default_masked_mode_at_stated_size():
     assert abs(r0.item() - np.log(cfg["N"])) < 0.2 and r1.item() < r0.item() + 1e-3
 
 
+def test_graph_replay_next_to_an_rccl_all_reduce_follows_the_eager_trajectory():
+    """the data-parallel step as the 8-GPU run executes it on every rank - hipGraph replay of zero-grad + forward + backward, then
+    the all-reduce of the flat gradient buffer + statistics tail on RCCL, then Adam - with a 1-rank RCCL group (the collective is
+    issued for real: NCCL kernels on the stream between the replayed graph and Adam).  One rank's shard of config 4 (N = 1M, K = 10,
+    D = 128, B = 1024 slates), the headline arithmetic, the benchmark's call pattern (a host sync after two steps, nothing read
+    back afterwards: the pattern in which a memset node of the captured graph once raced with the eager launch in front of it).
+    The trajectory must equal the eager, collective-free one to rounding; and a replayed step must equal an eager step of the same
+    trainer (both inside the group)."""
+    import socket
+    import torch.distributed as dist
+    import bench
+    from pivotcvae_amd.train_generative import Trainer
+    cfg = dict(bench.CONFIGS["4"])
+    B = 1024
+    data = [bench.synthetic_batch(cfg, B, torch.device(DEV), seed=70 + i) for i in range(3)]
+
+    def run(graph):
+        model, _ = bench.build_model(cfg, torch.device(DEV), "bf16x6")
+        tr = Trainer(model, lr=bench.LR, beta=bench.BETA, capture_graph=graph)
+        for i in range(2):
+            tr.step(*data[i % 3], global_batch=B)
+        torch.cuda.synchronize()
+        for i in range(2, 6):
+            loss, rec, kld = tr.step(*data[i % 3], global_batch=B)
+        torch.cuda.synchronize()
+        assert not graph or (tr.capture_failed is None and tr._graph is not None)
+        return tr, (rec.item(), kld.item(), tr.opt.flat.clone())
+
+    _, plain = run(False)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        tr_e, eager = run(False)
+        tr_g, graph = run(True)
+        assert tr_g.dist is not None and tr_g.world == 1 and tr_g._in_tail   # gradients and statistics went through ONE all_reduce
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    for got in (eager, graph):
+        np.testing.assert_allclose(got[:2], plain[:2], rtol=2e-6)
+        assert float((got[2] - plain[2]).abs().max()) <= 1e-6
+
+
 def test_graph_replay_after_a_host_sync_follows_the_eager_trajectory():
     """config 4 at its stated size, six optimisation steps: hipGraph replay against eager launches, with the host synchronised after
     the second step and nothing read back afterwards - the call pattern of a benchmark loop, and the one in which a memset NODE in

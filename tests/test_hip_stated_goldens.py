@@ -11,7 +11,11 @@ import pytest
 import torch
 
 from tests.gpu_util import DEV, build_from_golden, close, dev
-from tests.helpers import load, stated_cases
+from tests.helpers import explain_by_kinks, leaky_kinks, load, stated_cases
+
+# a pre-activation counts as "at a LeakyReLU kink" for the bf16x3 MLP arithmetic when it lies within this many x (sum of absolute
+# products) of zero: an operand carries 16 mantissa bits, the dropped lo*lo term is 2^-18 per product
+KINK_REL_X3 = 2.0 ** -18
 
 pytestmark = pytest.mark.gpu
 # bf16x3 (16-bit-mantissa operands) and bf16x6 (round 4: the fp32 operands themselves as three bf16 components): natively at D = 128,
@@ -179,17 +183,27 @@ def _whole_step_x3(name):
     tr.local_phase(s, r, u, dev(g.t("full/eps")))
     np.testing.assert_allclose([float(x) for x in tr._stats], g.a["full/loss"], rtol=1e-4)
     # Typical agreement (tools/dbg_mlp_x3.py): 4e-6 .. 1.3e-5 of a tensor's scale.  The exception is inherent to ANY change of
-    # arithmetic in front of a LeakyReLU: a pre-activation within the perturbation (~1e-6 here, ~1e-8 between two fp32 summation
-    # orders) of zero changes sign, its derivative jumps 1 -> 0.01 for that ONE slate, and that slate's contribution to the
-    # layer's weight-gradient row changes discretely - about 2 such units among the 1.3 M activations of a config-2 step; seen
-    # as 1.3e-3 of scale on a few entries of enc_2.  So: (nearly) every entry within rtol 2e-4 + 1e-4 of scale, none beyond 5e-3.
+    # arithmetic in front of a LeakyReLU: a pre-activation within the perturbation of zero changes sign, its derivative jumps
+    # 1 -> 0.01 for that ONE slate, and that slate's contribution to the unit's row of its layer's weight gradient - and to every
+    # gradient below that layer - changes discretely.  Round 4: the entries beyond rtol 2e-4 + 1e-4 of scale are no longer merely
+    # counted, their CAUSE is asserted: the golden's own pre-activations are recomputed in fp64 (tests/helpers.py::leaky_kinks: units
+    # within `rel` x the sum of absolute products of zero for some slate), and every offending tensor must sit at or below a kinked
+    # layer of its chain; at the kinked layer itself the offending rows must BE kinked units.  None beyond 5e-3 of scale.
+    kinks = leaky_kinks(g.sd, g.meta, g.t("s"), g.t("r"), g.t("u"), g.t("full/eps"), rel=KINK_REL_X3)
+    n_off = 0
     for k, prm in m.named_parameters():
         want = g.sub("grad").get(k)
         if want is not None:
             scale = float(want.abs().max())
             diff = (prm.grad.cpu() - want).abs()
             off = diff > 2e-4 * want.abs() + max(2e-6, 1e-4 * scale)
-            assert float(off.float().mean()) < 5e-3 and float(diff.max()) < 5e-3 * scale, (k, float(off.float().mean()), float(diff.max()) / scale)
+            assert float(diff.max()) < 5e-3 * scale, (k, float(diff.max()) / scale)
+            if off.any():
+                n_off += int(off.sum())
+                print("[kink] " + explain_by_kinks(k, off.nonzero()[:, 0].tolist(), kinks, g.meta["model"]) +
+                      f" ({int(off.sum())} of {off.numel()} entries, max {float(diff.max()) / scale:.1e} of scale)")
+    print(f"[kink] {name}: {n_off} gradient entries beyond tolerance; kinked units within {KINK_REL_X3:g}: "
+          + str({a: len(b) for a, b in sorted(kinks.items())}))
     m2 = _model(g, "bf16x3").set_mlp_precision("bf16x3")
     tr2 = Trainer(m2, lr=g.meta["lr"], beta=g.meta["beta"])
     for step in range(3):
