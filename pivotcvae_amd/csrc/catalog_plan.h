@@ -13,6 +13,10 @@
 #endif
 static inline constexpr int x3_ct(int D) { return D == 256 ? X3_CT256 : X3_CT; }
 
+#ifndef PCVAE_RANGE_MB_DEFAULT
+#define PCVAE_RANGE_MB_DEFAULT 0   // longest catalog range in MB of table stream (0: no limit); see catalog_plan
+#endif
+
 namespace pcvae {
 
 struct CatalogPlan {
@@ -45,7 +49,19 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // fp32-grade results (exact f32, bf16x3): a range's row sums and U are ONE fp32 accumulation chain, and past ~1M items the
     // running sum's ulp swallows the small terms of a peaked row (N = 10M, |logit| up to 6: lse 6e-5 low, round 3).  Ranges of at
     // most 16 384 tiles (512K items); the merge adds the <= 64 partials.  (bf16: its own 2^-9 per term dwarfs that - plan unchanged.)
-    const int64_t ns_min = (f32 || x3) ? std::min<int64_t>(cap, cdiv(p.ntiles, 16384)) : 1;
+    int64_t ns_min = (f32 || x3) ? std::min<int64_t>(cap, cdiv(p.ntiles, 16384)) : 1;
+    // The 32 workgroups an XCD runs side by side stream the SAME catalog range and share it in the XCD's 4 MB L2 - as long as they
+    // stay within a few MB of each other in that stream.  Nothing holds them together (the ring's prefetch makes every workgroup
+    // latency-tolerant), so they drift apart at ~1 % of a pass: over a pass of 16 - 64 MB (config 4: 2 - 5 ms) that is nothing and
+    // the memory-side traffic is exactly one table read per 32 row blocks; over a pass of 2.5 - 5 GB (config 5 with one or two
+    // ranges: 100+ ms) the sharing is lost - PMC, round 4: 573 GB per launch for the bf16 kernel (2.8x the shared ideal) and
+    // 17.3 TB = 4.3 TB/s for bf16x3, every workgroup reading the 10 GB image on its own.  So a range is at most ~128 MB of table
+    // stream: workgroups re-align with every new pass.  (The price is partials: 169 MB per range at config 5, written and read once.)
+    const int64_t row_bytes = (int64_t)D * (f32 ? 4 : prec == PCVAE_PREC_BF16X6 ? 6 : x3 ? 4 : 2);
+    const char* env_mb = getenv("PCVAE_RANGE_MB");   // (experiments: tools/range_sweep.sh; read per call like PCVAE_PIPE_MIN_TILES)
+    const int64_t range_mb = env_mb ? atoll(env_mb) : PCVAE_RANGE_MB_DEFAULT;
+    if (range_mb > 0)
+        ns_min = std::max<int64_t>(ns_min, std::min<int64_t>(cap, cdiv((int64_t)p.ntiles * 32 * row_bytes, range_mb << 20)));
     int64_t best_cost = -1;
     for (int64_t ns = ns_min; ns <= cap; ++ns) {
         const int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;

@@ -16,6 +16,9 @@ from tests.helpers import explain_by_kinks, leaky_kinks, load, stated_cases
 # a pre-activation counts as "at a LeakyReLU kink" for the bf16x3 MLP arithmetic when it lies within this many x (sum of absolute
 # products) of zero: an operand carries 16 mantissa bits, the dropped lo*lo term is 2^-18 per product
 KINK_REL_X3 = 2.0 ** -18
+# ... and between the reference's and our fp32 trajectory (two summation orders of every layer, parameters that differ in their
+# last bits after a step; with a bf16x3 catalog the incoming gradient - hence the parameters after a step - by ~2e-5 of scale)
+KINK_REL_ADAM = {"f32": 2.0 ** -19, "bf16x6": 2.0 ** -19, "bf16x3": 2.0 ** -15}
 
 pytestmark = pytest.mark.gpu
 # bf16x3 (16-bit-mantissa operands) and bf16x6 (round 4: the fp32 operands themselves as three bf16 components): natively at D = 128,
@@ -23,20 +26,46 @@ pytestmark = pytest.mark.gpu
 CASES = [(n, p) for n in stated_cases() for p in ("f32", "bf16x6", "bf16x3")]
 
 
-def adam_close(got, want, lr, steps, rtol=1e-4, atol=3e-6):
-    """parameters after Adam steps: rtol / atol as in tests/test_hip_model_golden.py for (nearly) every element.  Adam's first steps
-    move a weight by ~lr * g / (|g| + 1e-8): where |g| is of the order of its own rounding error (a handful of the 1e5 .. 1e6
-    weights at these sizes) the normalised step follows the noise - those may differ by up to the whole move, 2 lr per step.
-    After the FIRST step that is all (<= 1e-4 of the elements).  Later steps can also meet a LeakyReLU kink: a hidden unit whose
-    pre-activation lies within rounding of zero for one slate takes the other slope in the other summation order, and that
-    slate's share of the unit's weight-gradient row (and of everything below it) changes discretely - the D = 64 case: 195 of
-    45 760 elements of enc_1.weight after three steps, by at most 9.6e-5 (tools/dbg_adam_noise.py).  Counted (<= 1 %), bounded."""
+def adam_off_rows(got, want, rtol=1e-4, atol=3e-6):
+    """rows (output units) of a parameter that hold entries beyond rtol / atol after Adam steps, the count of such entries, max |diff|"""
     a, b = got.detach().cpu(), want.detach().cpu() if torch.is_tensor(want) else torch.as_tensor(want)
     diff = (a - b).abs()
     off = diff > atol + rtol * b.abs()
-    allowed = int(1e-4 * off.numel()) if steps == 1 else max(1, int(1e-2 * off.numel()))   # (the flipped unit's own bias: 1 of 64)
-    assert int(off.sum()) <= allowed, (int(off.sum()), off.numel(), float(diff.max()))
-    assert float(diff.max()) <= 2.001 * lr * steps
+    return off.nonzero()[:, 0].tolist(), int(off.sum()), off.numel(), float(diff.max())
+
+
+def adam_close(got, want, lr, steps, rtol=1e-4, atol=3e-6):
+    """parameters after Adam steps: rtol / atol as in tests/test_hip_model_golden.py for (nearly) every element.  Adam's first steps
+    move a weight by ~lr * g / (|g| + 1e-8): where |g| is of the order of its own rounding error (a handful of the 1e5 .. 1e6
+    weights at these sizes) the normalised step follows the noise - those may differ by up to the whole move, 2 lr per step: at
+    most 1e-4 of a tensor's elements, after ANY number of steps.  -> True if the tensor is within that budget.  More than that
+    has exactly one legitimate cause, which the caller must then demonstrate (explain_adam_by_kinks): a LeakyReLU kink."""
+    rows, n_off, numel, dmax = adam_off_rows(got, want, rtol, atol)
+    assert dmax <= 2.001 * lr * steps, dmax
+    return n_off <= max(1, int(1e-4 * numel))
+
+
+def explain_adam_by_kinks(g, offenders, prec):
+    """`offenders`: {parameter name: rows beyond tolerance} after three Adam steps, beyond the rounding-noise budget.  The one
+    legitimate cause: a hidden unit whose pre-activation lies within rounding of zero for some slate at one of the three states
+    the gradients were taken at takes the other LeakyReLU slope in the other summation order; that slate's share of the unit's
+    weight-gradient row (and of everything below it) changes discretely and Adam's normalisation turns it into up to 2 lr per
+    step.  Demonstrated here: the three states are rebuilt (the golden's initial state, then the ORACLE's Adam steps on the golden's
+    recorded eps - the checker, fp32 CPU), their pre-activations recomputed in fp64, and every offending tensor must sit at or
+    below a kinked layer, at the kinked layer in kinked rows (tests/helpers.py)."""
+    from oracle import pivotcvae_oracle as orc
+    from tests.helpers import explain_by_kinks, leaky_kinks
+    cfg, sd, state, kinks = g.cfg(), dict(g.sd), {}, {}
+    s, r, u = g.t("s"), g.t("r"), g.t("u")
+    for step in range(3):
+        eps = g.t(f"adam/eps{step}")
+        for layer, units in leaky_kinks(sd, g.meta, s, r, u, eps, rel=KINK_REL_ADAM[prec]).items():
+            kinks.setdefault(layer, {}).update(units)
+        if step < 2:
+            _, grads = orc.loss_and_grads(sd, cfg, s, r, u, eps, g.meta["beta"])
+            sd = orc.adam_step(sd, grads, state, g.meta["lr"])
+    for k, rows in offenders.items():
+        print("[kink] " + explain_by_kinks(k, rows, kinks, g.meta["model"]) + f" ({len(rows)} entries)")
 
 
 def _model(g, prec, fused=True):
@@ -112,8 +141,12 @@ def test_three_adam_steps(name, prec):
         np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], g.a[f"adam/loss{step}"], rtol=1e-4)
         if step in (0, 2):
             sd = m.state_dict()
-            for k, v in g.sub(f"adam/step{step + 1}").items():
-                adam_close(sd[k], v, g.meta["lr"], step + 1)
+            offenders = {k: adam_off_rows(sd[k], v)[0] for k, v in g.sub(f"adam/step{step + 1}").items()
+                         if not adam_close(sd[k], v, g.meta["lr"], step + 1)}
+            if offenders:   # beyond the rounding-noise budget: only a demonstrated LeakyReLU kink excuses it (never after ONE step:
+                assert step == 2, offenders.keys()   # the first gradient is taken at the golden's own state)
+                assert g.meta["N"] <= 20000, "no oracle replay at this catalog size: the strict budget holds there"
+                explain_adam_by_kinks(g, offenders, prec)
     for k in g.meta["none_grads"] + ["docEmbed.weight", "userEmbed.weight"]:
         assert torch.equal(m.state_dict()[k].cpu(), g.sd[k]), k
 
@@ -130,6 +163,11 @@ def test_greedy_ids(name, prec):
     safe = g.a["rec/item_margin"] > 1e-5     # rows whose top-2 margin is above fp32 rounding of a D-term dot product
     assert safe.mean() > 0.99
     np.testing.assert_array_equal(items.cpu().numpy()[safe], g.a["rec/items"][safe])
+    # the rows left out of the bit-exact claim are COUNTED, and reported with what happened on them (pytest -s / the round's log)
+    n_unsafe = int((~safe).sum())
+    agree = int((items.cpu().numpy()[~safe] == g.a["rec/items"][~safe]).sum())
+    print(f"[margin] {name} {prec}: {n_unsafe} of {safe.size} rows have a top-2 margin <= 1e-5 (ids equal the reference's on {agree} "
+          f"of them); smallest margin {float(g.a['rec/item_margin'].min()):.2e}")
     if g.has("rec/pivot"):
         np.testing.assert_array_equal(m.last_pivot.cpu().numpy(), g.a["rec/pivot"])
 
