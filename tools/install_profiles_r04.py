@@ -12,11 +12,11 @@ for f in sorted(glob.glob(os.path.join(src, "*.csv")) + glob.glob(os.path.join(s
 R4, R3, R5 = 81920, 40960, 163840
 JOBS = [
     ("x6_config4", "catalog_ce_x3_pipe_kernel<128, 2, 3>", "config4_bf16x6_gpus1", 4.0 * R4 * 1e6 * 128,
-     768e6 + R4 * 128 * 4 + 32 * R4 * 130 * 4, "table image [N, 384] bf16 once + rx + the 32 ranges' partials"),
+     768e6 + R4 * 128 * 4 + 2 * 2 * R4 * 130 * 4, "table image [N, 384] bf16 once + rx + the 2 ranges' partials written and read"),
     ("bf16_config3", "catalog_ce_bf16_pipe_kernel<64, 4>", "config3_bf16_gpus1", 4.0 * R3 * 1e5 * 64,
      12.8e6 + R3 * 64 * 4 + 8 * R3 * 66 * 4, "bf16 table once + rx + the ranges' partials"),
     ("bf16_config5", "catalog_ce_bf16_pipe_kernel<256, 2>", "config5_bf16_gpus1", 4.0 * R5 * 1e7 * 256,
-     5.12e9 + R5 * 256 * 4 + 2 * R5 * 258 * 4, "bf16 table (5.12 GB) once + rx + the ranges' partials"),
+     5.12e9 + R5 * 256 * 4 + 2 * R5 * 258 * 4, "bf16 table (5.12 GB) once + rx + the one range's partials written and read"),
     ("x3_config5", "catalog_ce_x3_pipe_kernel<256, 1, 2>", "config5_bf16x3_gpus1", 4.0 * R5 * 1e7 * 256,
      10.24e9 + R5 * 256 * 4 + 20 * R5 * 258 * 4, "two [N, 256] bf16 images (10.24 GB) once + rx + the 20 ranges' partials"),
 ]
