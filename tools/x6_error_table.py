@@ -14,11 +14,14 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import pivotcvae_oracle as orc   # noqa: E402  (a measurement tool, not the product)
 from pivotcvae_amd import ops                # noqa: E402
 from pivotcvae_amd._hip import PREC_NAMES    # noqa: E402
 
 DEV, D = "cuda:0", 128
+
+
+def normalize_rows(w):
+    return w / w.pow(2).sum(dim=1, keepdim=True).sqrt().clamp_min(1e-12)
 
 
 def truth64(rx, E, tgt):
@@ -31,11 +34,11 @@ def families(seed=31):
     g = torch.Generator().manual_seed(seed)
     out = {}
     N, R = 20000, 256
-    E = orc.normalize_rows(torch.rand(N, D, generator=g) * 2 - 1)
+    E = normalize_rows(torch.rand(N, D, generator=g) * 2 - 1)
     out["model_scale_|x|=8"] = ((torch.rand(R, D, generator=g) * 2 - 1) * 1.2, E)
     out["large_norm_|x|=23"] = ((torch.rand(R, D, generator=g) * 2 - 1) * 3.5, E)
     out["dominant_logit_30"] = (torch.stack([E[(17 * i) % N] * 30.0 for i in range(R)]), E)
-    Ec = orc.normalize_rows(torch.ones(N, D) * 0.7 + (torch.rand(N, D, generator=g) * 2 - 1) * 0.3)
+    Ec = normalize_rows(torch.ones(N, D) * 0.7 + (torch.rand(N, D, generator=g) * 2 - 1) * 0.3)
     alt = torch.tensor([1.0, -1.0]).repeat(D // 2)
     out["cancelling_rows_const_table"] = (torch.stack([alt * (3.0 + 0.007 * i) + (torch.rand(D, generator=g) * 2 - 1) * 0.05
                                                         for i in range(R)]), Ec)
