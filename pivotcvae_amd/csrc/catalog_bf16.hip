@@ -820,6 +820,9 @@ __device__ __forceinline__ void lgkm_wait() {
 // copies (tests/test_host_logic.py checks the generated ISA) and is fenced once per trip, at its latch.
 __device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
+#ifndef PIPE_CT256
+#define PIPE_CT256 2         // column tiles of 16 rows per wave of the D = 256 cross-entropy kernel
+#endif
 #ifndef PIPE_TD
 #define PIPE_TD 2            // transposed reads: d tiles requested ahead (2 reads each)
 #endif
@@ -1435,7 +1438,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
             // small catalogs) stay on the two-waves-per-SIMD kernel.  PCVAE_PIPE_MIN_TILES (read per launch) moves the
             // threshold: the tests force the pipelined kernels onto small shapes with it.
             constexpr bool ALWAYS_PIPE = D == 256;
-            constexpr int CT = D == 256 ? 2 : 4;
+            constexpr int CT = D == 256 ? PIPE_CT256 : 4;
             if (catalog_bf16_pipelined(D, p.tiles_per_split)) {
                 constexpr int lds_pipe = PipeGeo<D, CT>::NB * 16384;
                 static bool attr_set3 = false;
