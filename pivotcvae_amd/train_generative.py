@@ -207,7 +207,9 @@ class Trainer:
             if key[2] not in st["ws"] or st["ws"][key[2]].numel() < buf.numel():
                 st["ws"][key[2]] = buf
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph), ops.workspace_holder(_FixedWorkspace(st["ws"])):
+        # thread_local: CUDA / HIP calls other threads make while this one captures (RCCL's watchdog polling its events) must not
+        # invalidate the capture
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"), ops.workspace_holder(_FixedWorkspace(st["ws"])):
             st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
         self._graph, self._static = graph, st
 
