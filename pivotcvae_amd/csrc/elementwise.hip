@@ -20,6 +20,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: what
 #ifndef GATHER_NT_STORE
 #define GATHER_NT_STORE 1
 #endif
+#ifndef GATHER_COAL
+#define GATHER_COAL 1   // one coalesced index load per wave and batch (gather_rows_coal_kernel); 0: sixteen broadcast loads per lane
+#endif
 #ifndef GATHER_MAXBLOCKS
 #define GATHER_MAXBLOCKS (256 * 8)
 #endif
@@ -62,6 +65,45 @@ __global__ void __launch_bounds__(256) gather_rows_vec4_kernel(const f32x4* __re
     }
 }
 
+// Round 4: the same batch with the wave's row indices fetched by ONE coalesced load - lane l < RPB loads idx[first + l] (RPB = the
+// 16 * 64 / LPR rows of a batch: 16 / 32 / 64 for rows of 64 / 32 / 16 chunks), and every lane then reads the index of each of its
+// 16 rows from the lane that holds it (ds_bpermute: no LDS memory) - instead of 16 loads per lane of which only 64 / LPR addresses
+// per instruction are distinct.  One index round trip in front of the row loads instead of sixteen queued ones, and a sixteenth
+// of the address-unit work: in tools/gather_probe.hip (bare HIP, same shape, same box) 21.7 us against 34.6 us event to event.
+template <int LPR, bool CONTIG>
+__global__ void __launch_bounds__(256) gather_rows_coal_kernel(const f32x4* __restrict__ table, const int64_t* __restrict__ idx,
+                                                               int64_t n_idx, int group, float* __restrict__ out, int64_t out_ld,
+                                                               int D) {
+    constexpr int U = 16, RPW = 64 / LPR, RPB = U * RPW, CH = LPR;   // LPR lanes per row = 16-byte chunks per row (D = 4 LPR)
+    static_assert(RPB <= 64, "a batch's indices fit one wave-wide load");
+    const int lane = threadIdx.x & 63, sub = lane / LPR, c = lane % LPR;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t first = wave * RPB; first < n_idx; first += n_waves * RPB) {
+        const int64_t mine = (lane < RPB && first + lane < n_idx) ? idx[first + lane] : -1;
+        const int lo = (int)(mine & 0xffffffff), hi = (int)(mine >> 32);
+        int64_t src[U];
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int from = RPW * u + sub;
+            src[u] = ((int64_t)__shfl(hi, from, 64) << 32) | (uint32_t)__shfl(lo, from, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (src[u] >= 0) v[u] = GATHER_NT_LOAD ? __builtin_nontemporal_load(&table[src[u] * CH + c]) : table[src[u] * CH + c];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (src[u] >= 0) {
+                const int64_t i = first + RPW * u + sub;
+                // CONTIG: out_ld == group * D, i.e. output row i starts at i * D (no 64-bit division on the hot path)
+                float* o = out + (CONTIG ? i * (int64_t)D : (i / group) * out_ld + (i % group) * (int64_t)D) + c * 4;
+                if (GATHER_NT_STORE) __builtin_nontemporal_store(v[u], reinterpret_cast<f32x4*>(o));
+                else *reinterpret_cast<f32x4*>(o) = v[u];
+            }
+    }
+}
+
 // (Round 3, measured and dropped: the wave's row indices through the SCALAR cache - 4 s_load_dwordx16 instead of 16 broadcast vector
 // loads.  23.3 us against 21.5 us for this kernel on the same box: every row load then waits for ALL indices (one lgkmcnt), while
 // here a lane's row load follows its own index load.)
@@ -96,6 +138,18 @@ extern "C" int pcvae_gather_rows(const float* table, int64_t n_rows, int D, cons
         const int rows_per_wave = 64 / lpr;
         const int64_t n_groups = cdiv(n_idx, rows_per_wave);
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(cdiv(cdiv(n_groups, GATHER_UNROLL), 4), GATHER_MAXBLOCKS));
+        const bool contig = out_ld == (int64_t)group * D;
+        const f32x4* tab4 = reinterpret_cast<const f32x4*>(table);
+#define PCVAE_GATHER_COAL(L, C)                                                                                          \
+        PCVAE_LAUNCH_TIMED(PCVAE_TIMER_GATHER, (gather_rows_coal_kernel<L, C>), dim3((unsigned)blocks), dim3(256), 0,   \
+                           as_stream(stream), tab4, idx, n_idx, group, out, out_ld, D)
+        if (GATHER_COAL && GATHER_UNROLL == 16 && chunks == lpr && (lpr == 16 || lpr == 32 || lpr == 64)) {   // D = 64 / 128 / 256
+            if (lpr == 16) { if (contig) PCVAE_GATHER_COAL(16, true); else PCVAE_GATHER_COAL(16, false); }
+            else if (lpr == 32) { if (contig) PCVAE_GATHER_COAL(32, true); else PCVAE_GATHER_COAL(32, false); }
+            else { if (contig) PCVAE_GATHER_COAL(64, true); else PCVAE_GATHER_COAL(64, false); }
+            return check_launch("gather_rows");
+        }
+#undef PCVAE_GATHER_COAL
         if (out_ld == (int64_t)group * D)
             PCVAE_LAUNCH_TIMED(PCVAE_TIMER_GATHER, (gather_rows_vec4_kernel<GATHER_UNROLL, true>), dim3((unsigned)blocks), dim3(256), 0,
                                as_stream(stream), reinterpret_cast<const f32x4*>(table), chunks, lpr, idx, n_idx, group, out, out_ld, D);
@@ -688,6 +742,9 @@ __global__ void __launch_bounds__(256) assemble_inputs_vec_kernel(const float* _
     }
 }
 
+// (Round 4, measured and dropped: the batch shape of gather_rows_coal_kernel here - 16 rows in flight per lane behind ONE coalesced
+// index load per wave: 28.1 us against 27.4 us for this kernel on the same box.  The launch is bound by its stores - 7.8 KB written per
+// slate against 5.6 KB read, into rows that start on 4-byte boundaries (row widths like 1419 floats) - not by its index round trips.)
 extern "C" int pcvae_assemble_inputs(const float* E, int64_t n_items, const float* U, int64_t n_users, const int64_t* s, const float* r,
                                      const int64_t* u, int64_t B, int S, int D, int ncols, int Z, float* enc_in, int64_t ld_enc,
                                      float* prior_in, int64_t ld_prior, float* scm_in, int64_t ld_scm, float* rx, int64_t ld_rx,
@@ -701,11 +758,11 @@ extern "C" int pcvae_assemble_inputs(const float* E, int64_t n_items, const floa
     if (B == 0) return PCVAE_OK;
     const int cpr = D / 4;
     if (D % 4 == 0 && cpr <= 64 && 64 % cpr == 0 && B * (S + 1) < (1LL << 31) && ((uintptr_t)E % 16 == 0) &&
-        (!U || (uintptr_t)U % 16 == 0))   // a row = an aligned group of <= 64 lanes, 16-byte aligned in its table
+        (!U || (uintptr_t)U % 16 == 0)) {   // a row = an aligned group of <= 64 lanes, 16-byte aligned in its table
         PCVAE_LAUNCH_TIMED(PCVAE_TIMER_ASSEMBLE, assemble_inputs_vec_kernel<4>, dim3((unsigned)cdiv(B * (S + (U ? 1 : 0)), (256 / cpr) * 4)),
                            dim3(256), 0, as_stream(stream), E, U, s, r, u, B, S, D, ncols, Z, enc_in, ld_enc, prior_in, ld_prior, scm_in,
                            ld_scm, rx, ld_rx);
-    else
+    } else
         hipLaunchKernelGGL(assemble_inputs_kernel, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, as_stream(stream), E, U, s, r, u, B, S, D,
                            ncols, Z, enc_in, ld_enc, prior_in, ld_prior, scm_in, ld_scm, rx, ld_rx);
     return check_launch("assemble_inputs");

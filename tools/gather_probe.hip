@@ -122,6 +122,61 @@ __global__ void __launch_bounds__(256) k_pipe2(const f32x4* __restrict__ table, 
     }
 }
 
+// ---- V3 (round 4): the wave's 32 row indices by ONE coalesced 256-byte load (lane l < 32 loads idx[first + l]), distributed by
+// cross-lane reads; then the product kernel's 16 row loads + 16 stores.  D = 128 only (32 lanes per row, 2 rows per instruction).
+template <bool NT_LD, bool NT_ST>
+__global__ void __launch_bounds__(256) k_coal(const f32x4* __restrict__ table, const int64_t* __restrict__ idx, int64_t n_idx,
+                                              f32x4* __restrict__ out) {
+    const int lane = threadIdx.x & 63, sub = lane >> 5, c = lane & 31;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t first = wave * 32;
+    if (first >= n_idx) return;
+    const int64_t mine = first + (lane & 31) < n_idx ? idx[first + (lane & 31)] : -1;
+    int lo = (int)(mine & 0xffffffff), hi = (int)(mine >> 32);
+    f32x4 v[16];
+    int64_t src[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int from = 2 * u + sub;
+        const int l2 = __shfl(lo, from, 64), h2 = __shfl(hi, from, 64);
+        src[u] = ((int64_t)h2 << 32) | (uint32_t)l2;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (src[u] >= 0) v[u] = NT_LD ? __builtin_nontemporal_load(&table[src[u] * 32 + c]) : table[src[u] * 32 + c];
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (src[u] >= 0) {
+            f32x4* o = &out[(first + 2 * u + sub) * 32 + c];
+            if (NT_ST) __builtin_nontemporal_store(v[u], o); else *o = v[u];
+        }
+}
+
+// ---- V4 (round 4): as V3 with the row loads and stores of the two halves of the batch interleaved (8 loads, 8 loads, 8 stores, 8 stores)
+template <int U2>
+__global__ void __launch_bounds__(256) k_coal2(const f32x4* __restrict__ table, const int64_t* __restrict__ idx, int64_t n_idx,
+                                               f32x4* __restrict__ out) {
+    const int lane = threadIdx.x & 63, sub = lane >> 5, c = lane & 31;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t first = wave * (2 * U2);
+    if (first >= n_idx) return;
+    const int64_t mine = (lane & 31) < 2 * U2 && first + (lane & 31) < n_idx ? idx[first + (lane & 31)] : -1;
+    int lo = (int)(mine & 0xffffffff), hi = (int)(mine >> 32);
+    f32x4 v[U2];
+    int64_t src[U2];
+#pragma unroll
+    for (int u = 0; u < U2; ++u) {
+        const int from = 2 * u + sub;
+        src[u] = ((int64_t)__shfl(hi, from, 64) << 32) | (uint32_t)__shfl(lo, from, 64);
+    }
+#pragma unroll
+    for (int u = 0; u < U2; ++u)
+        if (src[u] >= 0) v[u] = __builtin_nontemporal_load(&table[src[u] * 32 + c]);
+#pragma unroll
+    for (int u = 0; u < U2; ++u)
+        if (src[u] >= 0) __builtin_nontemporal_store(v[u], &out[(first + 2 * u + sub) * 32 + c]);
+}
+
 __global__ void k_empty() {}
 
 int main(int argc, char** argv) {
@@ -218,6 +273,11 @@ int main(int argc, char** argv) {
     PIPE2(2, 16);
     PIPE2(2, 32);
     // reference points: plain device copy of the same byte count, and a read-only / write-only split
+    run("coal (one idx load per wave) nt nt", [&] { hipLaunchKernelGGL((k_coal<true, true>), dim3((unsigned)((n_idx / 32 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    run("coal (one idx load per wave) plain ld, nt st", [&] { hipLaunchKernelGGL((k_coal<false, true>), dim3((unsigned)((n_idx / 32 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    run("coal2 U2=8 (16 rows per wave)", [&] { hipLaunchKernelGGL((k_coal2<8>), dim3((unsigned)((n_idx / 16 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    run("coal2 U2=4 (8 rows per wave)", [&] { hipLaunchKernelGGL((k_coal2<4>), dim3((unsigned)((n_idx / 8 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    BATCH(16, true, true, 0);
     run("hipMemcpyDtoD 50 MB (same bytes r+w)", [&] { CK(hipMemcpyAsync(out, table, (size_t)n_idx * D * 4, hipMemcpyDeviceToDevice, 0)); });
     return 0;
 }
