@@ -177,6 +177,48 @@ __global__ void __launch_bounds__(256) k_coal2(const f32x4* __restrict__ table, 
         if (src[u] >= 0) __builtin_nontemporal_store(v[u], &out[(first + 2 * u + sub) * 32 + c]);
 }
 
+// ---- V5 (round 4): V3 with the index load non-temporal too, any block size; V6: 64 rows per wave (one 64-lane index load), the
+// second half's row loads issued before the first half's stores
+template <bool NT_IDX>
+__global__ void k_coal_b(const f32x4* __restrict__ table, const int64_t* __restrict__ idx, int64_t n_idx, f32x4* __restrict__ out) {
+    const int lane = threadIdx.x & 63, sub = lane >> 5, c = lane & 31;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t first = wave * 32;
+    if (first >= n_idx) return;
+    int64_t mine = -1;
+    if (first + (lane & 31) < n_idx) mine = NT_IDX ? __builtin_nontemporal_load(&idx[first + (lane & 31)]) : idx[first + (lane & 31)];
+    int lo = (int)(mine & 0xffffffff), hi = (int)(mine >> 32);
+    f32x4 v[16];
+    int64_t src[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) src[u] = ((int64_t)__shfl(hi, 2 * u + sub, 64) << 32) | (uint32_t)__shfl(lo, 2 * u + sub, 64);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (src[u] >= 0) v[u] = __builtin_nontemporal_load(&table[src[u] * 32 + c]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (src[u] >= 0) __builtin_nontemporal_store(v[u], &out[(first + 2 * u + sub) * 32 + c]);
+}
+__global__ void __launch_bounds__(256) k_coal64(const f32x4* __restrict__ table, const int64_t* __restrict__ idx, int64_t n_idx,
+                                                f32x4* __restrict__ out) {
+    const int lane = threadIdx.x & 63, sub = lane >> 5, c = lane & 31;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t first = wave * 64;
+    if (first >= n_idx) return;
+    const int64_t mine = first + lane < n_idx ? idx[first + lane] : -1;
+    int lo = (int)(mine & 0xffffffff), hi = (int)(mine >> 32);
+    f32x4 v[32];
+    int64_t src[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) src[u] = ((int64_t)__shfl(hi, 2 * u + sub, 64) << 32) | (uint32_t)__shfl(lo, 2 * u + sub, 64);
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+        if (src[u] >= 0) v[u] = __builtin_nontemporal_load(&table[src[u] * 32 + c]);
+#pragma unroll
+    for (int u = 0; u < 32; ++u)
+        if (src[u] >= 0) __builtin_nontemporal_store(v[u], &out[(first + 2 * u + sub) * 32 + c]);
+}
+
 __global__ void k_empty() {}
 
 int main(int argc, char** argv) {
@@ -277,6 +319,16 @@ int main(int argc, char** argv) {
     run("coal (one idx load per wave) plain ld, nt st", [&] { hipLaunchKernelGGL((k_coal<false, true>), dim3((unsigned)((n_idx / 32 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
     run("coal2 U2=8 (16 rows per wave)", [&] { hipLaunchKernelGGL((k_coal2<8>), dim3((unsigned)((n_idx / 16 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
     run("coal2 U2=4 (8 rows per wave)", [&] { hipLaunchKernelGGL((k_coal2<4>), dim3((unsigned)((n_idx / 8 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    for (int rep = 0; rep < 2; ++rep) {
+    run("coal (one idx load per wave) nt nt, 256 thr", [&] { hipLaunchKernelGGL((k_coal<true, true>), dim3((unsigned)((n_idx / 32 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    run("coal_b plain idx, 128 thr", [&] { hipLaunchKernelGGL((k_coal_b<false>), dim3((unsigned)((n_idx / 32 + 1) / 2)), dim3(128), 0, 0, T, idx, n_idx, O); });
+    run("coal_b plain idx, 64 thr", [&] { hipLaunchKernelGGL((k_coal_b<false>), dim3((unsigned)(n_idx / 32)), dim3(64), 0, 0, T, idx, n_idx, O); });
+    run("coal_b plain idx, 512 thr", [&] { hipLaunchKernelGGL((k_coal_b<false>), dim3((unsigned)((n_idx / 32 + 7) / 8)), dim3(512), 0, 0, T, idx, n_idx, O); });
+    run("coal_b plain idx, 1024 thr", [&] { hipLaunchKernelGGL((k_coal_b<false>), dim3((unsigned)((n_idx / 32 + 15) / 16)), dim3(1024), 0, 0, T, idx, n_idx, O); });
+    run("coal_b nt idx, 256 thr", [&] { hipLaunchKernelGGL((k_coal_b<true>), dim3((unsigned)((n_idx / 32 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    run("coal64 (64 rows per wave), 256 thr", [&] { hipLaunchKernelGGL(k_coal64, dim3((unsigned)((n_idx / 64 + 3) / 4)), dim3(256), 0, 0, T, idx, n_idx, O); });
+    run("coal64 (64 rows per wave), 128 thr", [&] { hipLaunchKernelGGL(k_coal64, dim3((unsigned)((n_idx / 64 + 1) / 2)), dim3(128), 0, 0, T, idx, n_idx, O); });
+    }
     BATCH(16, true, true, 0);
     run("hipMemcpyDtoD 50 MB (same bytes r+w)", [&] { CK(hipMemcpyAsync(out, table, (size_t)n_idx * D * 4, hipMemcpyDeviceToDevice, 0)); });
     return 0;
