@@ -48,6 +48,26 @@ def test_gather_rows(ops, D, group, pad):
         assert torch.all(buf[:, group * D:] == -7.0)  # neighbours of the window untouched
 
 
+@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("n_idx,group,pad", [(1, 1, 0), (15, 1, 0), (17, 1, 3), (33, 3, 0), (64, 1, 0), (65, 5, 5), (1000, 10, 0), (4099, 1, 0),
+                                             (300_007, 1, 0)])
+def test_gather_rows_coalesced_index_kernel(ops, D, n_idx, group, pad):
+    """round 4: gather_rows_coal_kernel (D = 64 / 128 / 256: one coalesced index load per wave and batch of 64 / 32 / 16 rows, indices
+    handed between lanes): batches that end inside a wave, one row, strided output windows with untouched neighbours, more rows
+    than one sweep of the capped grid covers (2048 blocks x 4 waves x 16 rows at D = 256), first and last table row"""
+    n_idx = n_idx // group * group or group
+    N = 5000
+    table = rnd(N, D, seed=1)
+    idx = torch.randint(0, N, (n_idx,), generator=torch.Generator().manual_seed(n_idx))
+    idx[0], idx[-1] = N - 1, 0
+    B = n_idx // group
+    buf = torch.full((B, group * D + pad), -7.0, device=DEV)
+    out = ops.gather_rows(table.to(DEV), idx.to(DEV), out=buf[:, : group * D] if pad else None, group=group)
+    assert torch.equal(out.cpu(), table[idx].reshape(B, group * D))
+    if pad:
+        assert torch.all(buf[:, group * D:] == -7.0)
+
+
 def test_gather_empty_and_errors(ops):
     table = rnd(10, 16).to(DEV)
     out = ops.gather_rows(table, torch.zeros(0, dtype=torch.long, device=DEV))

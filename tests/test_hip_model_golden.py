@@ -193,6 +193,25 @@ def test_graph_captured_step_equals_eager_step():
             close(outs[1][1][k], outs[0][1][k], rtol=1e-4, atol=2e-6)
 
 
+def test_trainer_reports_the_loss_an_injected_loss_fn_returned():
+    """Trainer(loss_fn=...) on the device: the loss that is back-propagated is the one that is reported - also when it carries a term
+    beyond rec + beta * KLD (a regulariser).  (Round 3 logged rec + beta * KLD whatever the function had returned.)"""
+    from pivotcvae_amd.train_generative import Trainer
+    g = load("pivotcvae_gt_pi_s10")
+    s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
+    beta = g.meta["beta"]
+
+    def with_regulariser(m, s, r, u, **kw):
+        loss, rec, kld = m.loss(s, r, u, **{k: v for k, v in kw.items() if k != "mask_seed"})
+        return loss + 0.25 * rec, rec, kld
+
+    m = build_from_golden(g)
+    tr = Trainer(m, lr=1e-3, beta=beta, loss_fn=with_regulariser)
+    loss, rec, kld = (float(x) for x in tr.step(s, r, u, eps=dev(g.t("full/eps"))))
+    np.testing.assert_allclose(loss, 1.25 * rec + beta * kld, rtol=1e-6)
+    np.testing.assert_allclose([rec, kld], g.a["full/loss"][1:], rtol=1e-4)
+
+
 def test_trainer_with_a_one_rank_rccl_group_equals_the_plain_trainer():
     """The data-parallel path of Trainer.step on the GPU (one all-reduce over the flat gradient buffer, whose tail carries the
     logged ELBO terms) with a 1-rank RCCL group: bitwise the same parameters and statistics as the trainer without a group."""
