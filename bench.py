@@ -154,13 +154,17 @@ def gather_roofline(model, cfg, device, tables=4):
         d = kernel_timer_run(lambda: ops.gather_rows(tabs[it % tables], idxs[it % tables], out=outs[it % tables]), TIMER_GATHER)
         if it >= 3:
             kt += d
-    tk = sum(kt) / len(kt)
+    tk_mean = sum(kt) / len(kt)
+    tk = sorted(kt)[len(kt) // 2]   # the MEDIAN of the ten cold launches (one launch each): robust against the odd 23 us outlier
     t1, tb = ms["single"], ms["back_to_back"]
     bw = lambda t_ms: nbytes / (t_ms * 1e-3) / 1e9
     return {"kernel": "gather_rows_vec4_kernel", "bound": "hbm", "achieved": bw(tk), "peak": 8000.0,
             "unit": "GB/s", "frac": bw(tk) / 8000.0, "bytes_per_launch": nbytes, "us_per_launch": tk * 1e3,
             "rows": n_idx, "timed_over": "ONE launch at a time, cold caches, HIP events attached to the dispatch (hipExtLaunchKernelGGL start / "
-                                         "stop events: the kernel's own begin / end timestamps, as in rocprofv3's kernel trace)",
+                                         "stop events: the kernel's own begin / end timestamps, as in rocprofv3's kernel trace); "
+                                         "median of 10 such launches",
+            "us_per_launch_mean": tk_mean * 1e3, "us_per_launch_min": min(kt) * 1e3, "us_per_launch_max": max(kt) * 1e3,
+            "frac_of_mean": bw(tk_mean) / 8000.0,
             "event_pair_around_one_launch": {"us_per_launch": t1 * 1e3, "achieved": bw(t1), "frac": bw(t1) / 8000.0,
                                              "note": "hipEventRecord pair around one launch: also times its own two marker packets (~2.4 us)"},
             "back_to_back": {"us_per_launch": tb * 1e3, "achieved": bw(tb), "frac": bw(tb) / 8000.0,
