@@ -204,9 +204,11 @@ int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t
  *        dx_r  = sum_n keep_n * (softmax(z)_n - [n == target_r]) * E_n        (optional, [R,D])
  *     i.e. loss AND its gradient direction in one streaming pass (online softmax over catalog
  *     tiles, flash-style), so the backward pass is dx * (upstream / R).
- *     E is the fp32 table for F32, its bf16 copy for BF16, the hi | lo image of pcvae_split_bf16x2 for BF16X3; E_lo (BF16X3
- *     only) is the fp32 table again: exact target logit / target row, and the exact f32 kernel for masked calls and for
- *     256-row blocks whose norms rule out the max-free kernel.  `ws` is scratch of at least pcvae_catalog_ws_bytes().
+ *     E is the fp32 table for F32, its bf16 copy for BF16, the c0 | c1 image of pcvae_split_bf16x2 for BF16X3, the c0 | c1 | c2
+ *     image of pcvae_split_bf16x3 for BF16X6; E_lo (BF16X3 / BF16X6 only) is the fp32 table again: exact target logit / target
+ *     row, and the exact f32 kernel for masked calls and for 256-row blocks whose norms rule out the max-free kernel.
+ *     BF16X6 is the reference's arithmetic (fp32 operands, exact products, fp32 accumulate) on the bf16 pipe; BF16X3 and BF16 are
+ *     narrower.  `ws` is scratch of at least pcvae_catalog_ws_bytes().
  *     e_max_norm: max_n ||E_n||_2 of the table (the model's table is row-normalised: 1.0).  The bf16
  *     path uses it to prove, per 256-row block, that exp2(logit) cannot leave the fp32 range and then
  *     skips the running-max machinery; pass <= 0 when unknown (always take the running-max kernel).
@@ -214,7 +216,7 @@ int pcvae_sum(const float* x, int64_t n, float scale, float* out, pcvae_stream_t
 size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_dx);
 /* which kernel an unmasked training call (dx wanted) of this shape runs - for reports, never needed for correctness:
  * 0 = exact f32 MFMA kernel, 1 = bf16 kernel with two waves per SIMD, 2 = software-pipelined bf16 kernel (one wave per
- * SIMD), -1 = unsupported shape.  Mirrors the launch logic, including the PCVAE_PIPE_MIN_TILES override. */
+ * SIMD), 3 = bf16x3 kernel, 4 = bf16x6 kernel, -1 = unsupported shape.  Mirrors the launch logic, including the PCVAE_PIPE_MIN_TILES override. */
 int pcvae_catalog_ce_variant(int64_t R, int64_t N, int D, int prec);
 int pcvae_catalog_ce(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
                      float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
