@@ -6,7 +6,7 @@
 #include <cstdlib>
 
 #ifndef X3_CT
-#define X3_CT 2   // column tiles of 16 rows per wave of the bf16x3 kernel: 32 rows per wave, 128 per workgroup (3 and 4 spill: DESIGN 3.1b)
+#define X3_CT 2   // column tiles of 16 rows per wave of the bf16x3 kernel: 32 rows per wave, 128 per workgroup (3 and 4 spill: HISTORY.md 3.1b)
 #endif
 #ifndef X3_CT256
 #define X3_CT256 1   // D = 256: 16 rows per wave, 64 per workgroup (U alone is 128 accumulator registers at 32 rows: hipcc then spills)

@@ -133,7 +133,7 @@ struct X3Geo {
         // nothing behind the first 2 CT MFMAs: the first split op overwrites the c0 numerators (r.w[0]) that the LAST MFMAs of the
         // gradient chain in front of this L read as their B operand.  hipcc sees those operands dead and the in-order issue would
         // seem to protect them, but a VALU write two MFMAs behind such a read corrupted it (column tile 0 - the first pair
-        // written - NaN, depending on where an unrelated ds_read sat: tools/dbg_x3.py): MFMAs queue in front of the
+        // written - NaN, depending on where an unrelated ds_read sat: tools/dbg_x3.py, HISTORY.md 3.1b): MFMAs queue in front of the
         // matrix pipe and read their operands when they start, not when they issue.  2 CT MFMAs of distance.
         if (m < 2 * CT || m >= ML - 2) return 0;
         const Pos p = pos_of(m % MLI, 2 * KSH);

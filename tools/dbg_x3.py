@@ -1,5 +1,5 @@
 """dbg_x3.py: the bf16x3 catalog kernel against the C oracle on one shape, per output (lse / nll / dx) and per 16-row column tile -
-the script the queued-operand hazard was bisected with."""
+the script the queued-operand hazard was bisected with (HISTORY.md 3.1b)."""
 import sys, torch, numpy as np
 sys.path.insert(0, '/root/repo')
 from pivotcvae_amd import ops

@@ -1,5 +1,5 @@
 """dbg_x3_big.py [D] [R] [N]: bf16x3 lse at N = 10M against a chunked fp64 softmax on the device (long fp32 accumulation chains,
-DESIGN 3.1b: the range cap of catalog_plan)."""
+HISTORY.md 3.1b: the range cap of catalog_plan)."""
 import sys; sys.path.insert(0,'/root/repo')
 import torch
 from pivotcvae_amd import ops, _hip

@@ -1,6 +1,6 @@
 """diag_dw.py M K N: the weight gradient of one layer against fp64, three launches; for wrong elements: which 32-row chunk or 64-row
 batch split is missing or doubled, which tiles and which wave quadrants / accumulator rows (used to track down the lost fp32
-atomic updates between XCDs: DESIGN 3.1d)."""
+atomic updates between XCDs: HISTORY.md 3.1d)."""
 import sys, torch
 sys.path.insert(0, '.')
 from pivotcvae_amd import ops
