@@ -54,6 +54,13 @@
 #ifndef X3_PROBE
 #define X3_PROBE 0
 #endif
+// bf16x6: the logits of a subtile in TWO accumulators - the c0 c0 products (16-bit, never truncated against the sum) in one, the
+// five small component products (2^-8 .. 2^-17 of it) in the other - added once per slot in fp32.  The matrix core aligns the 33
+// addends of an MFMA to the largest and keeps 27 bits of each (tools/mfma_round_probe.hip): small products added to a big
+// accumulator lose their low bits toward zero, in their own accumulator they do not.  (rx component 0 then lives in AGPRs too.)
+#ifndef X6_SPLIT_ACC
+#define X6_SPLIT_ACC 1
+#endif
 
 // D = 256 (round 3, NC = 2 only): the table is TWO images - dims 0..127 and dims 128..255, each [N, 256] bf16 c0 | c1 with the
 // 512-byte rows of the D = 128 kernel - and a slot walks both: the logits chain is 16 k-steps per image into the SAME accumulators,
@@ -85,7 +92,8 @@ struct X3Geo {
     static constexpr int NRS = NC * CT;                    // row-sum MFMAs (first in G)
     static constexpr int MG = NRS + NIMG * MGI;
     static constexpr int P = 4 * CT;                       // numerator pairs per slot: (row tile, column tile, half)
-    static constexpr int GOPS = 2 * P;                     // during G: the 2 exponentials of every pair
+    static constexpr bool SPLIT = NC == 3 && X6_SPLIT_ACC; // logits in two accumulators (see X6_SPLIT_ACC)
+    static constexpr int GOPS = (SPLIT ? 4 : 2) * P;       // during G: (the 2 additions acc += acc_lo and) the 2 exponentials of every pair
     static constexpr int OPP = NC == 2 ? 6 : 11;           // split ops per pair: conversion, shift, mask, 2 subtractions, per component after the first
     static constexpr int LOPS = OPP * P;                   // during the next L
     static constexpr int ROWS = 4 * 16 * CT;               // rows per workgroup (4 waves)
@@ -119,7 +127,7 @@ struct X3Geo {
         // first tile: the logits accumulators are fresh there)
         if (CT == 1) return (p.j == 0 && m > NRS) ? 1 : 0;
         if (p.j == 0 || p.j == p.len - 1) return 0;
-        return NC == 2 ? 1 : (p.j & 1);
+        return (NC == 2 || SPLIT) ? 1 : (p.j & 1);
     }
     static constexpr int gfirst(int m) {
         int n = 0;
@@ -159,6 +167,7 @@ struct X3Geo {
 template <int CT, int NT, int NC>
 struct X3Regs {
     f32x4 acc[2][CT];          // logits of the current subtile [row tile][column tile] (log2 domain)
+    f32x4 accl[2][CT];         // (bf16x6, X6_SPLIT_ACC) the small component products of the same logits
     unsigned w[NC][CT][4];     // [component][ct][2 rt + h]: bf16 pairs; written during L, read by the G right behind it
     float e[4 * CT][2];        // the fp32 numerators: written during G (exponentials), split during the next L
     float tmp[2][2];           // running residuals of the two pairs in flight
@@ -169,12 +178,20 @@ struct X3Regs {
     s16x4 tl[NT], th[NT];      // (X3Geo::NDTL transposed tiles)
 };
 
-// G-phase op V: exponential `V & 1` of pair V / 2 (pair k <-> row tile k / (2 CT), column tile (k / 2) % CT, half k & 1)
-template <int CT, int V, class RG>
+// G-phase op V: exponential `V & 1` of pair V / 2 (pair k <-> row tile k / (2 CT), column tile (k / 2) % CT, half k & 1).
+// SPLIT: blocks of 8 ops for two pairs (a, b): add0 a, add1 a, add0 b, add1 b (acc += acc_lo), exp0 a, exp1 a, exp0 b, exp1 b
+template <int CT, bool SPLIT, int V, class RG>
 __device__ __forceinline__ void x3_gop(RG& r) {
-    constexpr int k = V / 2, which = V % 2;
-    constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
-    asm volatile("v_exp_f32 %0, %1" : "=v"(r.e[k][which]) : "v"(r.acc[rt][ct][2 * h + which]));
+    if constexpr (!SPLIT) {
+        constexpr int k = V / 2, which = V % 2;
+        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+        asm volatile("v_exp_f32 %0, %1" : "=v"(r.e[k][which]) : "v"(r.acc[rt][ct][2 * h + which]));
+    } else {
+        constexpr int blk = V / 8, o = V % 8, k = 2 * blk + ((o >> 1) & 1), which = o & 1;
+        constexpr int rt = k / (2 * CT), ct = (k / 2) % CT, h = k & 1;
+        if constexpr (o < 4) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r.acc[rt][ct][2 * h + which]) : "v"(r.accl[rt][ct][2 * h + which]));
+        else asm volatile("v_exp_f32 %0, %1" : "=v"(r.e[k][which]) : "v"(r.acc[rt][ct][2 * h + which]));
+    }
 }
 // L-phase op V: the split of the numerators into bf16 components, two pairs (a, b) interleaved so that no op reads the result
 // of the op right in front of it:  c0 = RNE bf16(e);  c1 = RNE bf16(e - float(c0));  c2 = RNE bf16(e - float(c0) - float(c1))
@@ -202,7 +219,7 @@ template <int D, int CT, int NC, int M, int V = X3Geo<D, CT, NC>::gfirst(M), cla
 __device__ __forceinline__ void x3_gops(RG& r) {
     using XG = X3Geo<D, CT, NC>;
     if constexpr (M < XG::MG && V < XG::gfirst(M + 1)) {
-        x3_gop<CT, V>(r);
+        x3_gop<CT, XG::SPLIT, V>(r);
         x3_gops<D, CT, NC, M, V + 1>(r);
     }
 }
@@ -218,7 +235,7 @@ __device__ __forceinline__ void x3_lops(RG& r) {
 template <int D, int CT, int NC, int V = 0, class RG>
 __device__ __forceinline__ void x3_all_gops(RG& r) {
     if constexpr (V < X3Geo<D, CT, NC>::GOPS) {
-        x3_gop<CT, V>(r);
+        x3_gop<CT, X3Geo<D, CT, NC>::SPLIT, V>(r);
         x3_all_gops<D, CT, NC, V + 1>(r);
     }
 }
@@ -236,6 +253,12 @@ template <bool COLD>
 __device__ __forceinline__ void mfma_v_ab(f32x4& acc, const bf16x8& a, const bf16x8& b) {
     if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+v"(acc) : "v"(a), "a"(b));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b));
+}
+
+template <bool COLD>
+__device__ __forceinline__ void mfma_v0_ab(f32x4& acc, const bf16x8& a, const bf16x8& b) {   // acc (VGPR) = A . B, B in AGPRs
+    if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15" : "=&v"(acc) : "v"(a), "a"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
 }
 
 template <int CT, int NC>
@@ -314,7 +337,11 @@ __device__ __forceinline__ void x3_lstep(const unsigned lbase, const int a0, bf1
         // operand reservations (x3_keep): an operand stays allocated until >= 4 MFMAs behind its last MFMA - two steps at CT >= 2
         // (every step has >= 2 MFMAs; the statement sits behind the step's second MFMA), four at CT = 1 (a last-part step is ONE MFMA)
         constexpr int KD = CT == 1 ? 4 : 2, KPOS = CT == 1 ? 0 : 1;
-        if constexpr (j == 0) {
+        if constexpr (XG::SPLIT) {   // every rx component in AGPRs; component pairs (i, 0) -> acc, the small ones -> accl
+            f32x4& dst = (part == 0 && j == 0) ? r.acc[rt][cti] : r.accl[rt][cti];
+            if constexpr (s == 0 && img == 0 && j <= 1) mfma_v0_ab<COLD>(dst, af[I], x[j][cti][xs]);
+            else mfma_v_ab<COLD>(dst, af[I], x[j][cti][xs]);
+        } else if constexpr (j == 0) {
             if constexpr (s == 0 && img == 0) mfma_v0<COLD>(r.acc[rt][cti], af[I], x[0][cti][xs]);
             else mfma_v<COLD>(r.acc[rt][cti], af[I], x[0][cti][xs]);
         } else {
@@ -572,7 +599,8 @@ __device__ __forceinline__ void x3_cold_gradient(const unsigned lbase_g, const u
 // one subtile on its own (ragged tail): logits, bound check, numerators, gradient - nothing overlapped, every MFMA fenced
 template <int D, int CT, int NC, int I = 0>
 __device__ __forceinline__ void x3_cold_logits(const unsigned lbase, const unsigned istride, const int a0,
-                                               bf16x8 (&af)[X3Geo<D, CT, NC>::NI], PCVAE_X3_XARGS(D, CT, NC), f32x4 (&acc)[2][CT]) {
+                                               bf16x8 (&af)[X3Geo<D, CT, NC>::NI], PCVAE_X3_XARGS(D, CT, NC), f32x4 (&acc)[2][CT],
+                                               f32x4 (&accl)[2][CT]) {
     using XG = X3Geo<D, CT, NC>;
     if constexpr (I < XG::NI) {
         constexpr int img = I / XG::NIL, i = I % XG::NIL;
@@ -581,12 +609,23 @@ __device__ __forceinline__ void x3_cold_logits(const unsigned lbase, const unsig
         constexpr int s = i >> 1, rt = i & 1, xs = img * XG::KSH + s % XG::KSH, part = s / XG::KSH;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
-            if constexpr (s == 0 && img == 0) mfma_v0<true>(acc[rt][ct], af[I], x[0][ct][xs]);
-            else mfma_v<true>(acc[rt][ct], af[I], x[0][ct][xs]);
+            if constexpr (XG::SPLIT) {   // c0 c0 -> acc, every other component pair -> accl
+                if constexpr (s == 0 && img == 0) mfma_v0_ab<true>(acc[rt][ct], af[I], x[0][ct][xs]);
+                else if constexpr (part == 0) mfma_v_ab<true>(acc[rt][ct], af[I], x[0][ct][xs]);
+                else mfma_v_ab<true>(accl[rt][ct], af[I], x[0][ct][xs]);
 #pragma unroll
-            for (int j = 1; j < NC - part; ++j) mfma_v_ab<true>(acc[rt][ct], af[I], x[j][ct][xs]);
+                for (int j = 1; j < NC - part; ++j) {
+                    if (s == 0 && img == 0 && j == 1) mfma_v0_ab<true>(accl[rt][ct], af[I], x[j][ct][xs]);
+                    else mfma_v_ab<true>(accl[rt][ct], af[I], x[j][ct][xs]);
+                }
+            } else {
+                if constexpr (s == 0 && img == 0) mfma_v0<true>(acc[rt][ct], af[I], x[0][ct][xs]);
+                else mfma_v<true>(acc[rt][ct], af[I], x[0][ct][xs]);
+#pragma unroll
+                for (int j = 1; j < NC - part; ++j) mfma_v_ab<true>(acc[rt][ct], af[I], x[j][ct][xs]);
+            }
         }
-        x3_cold_logits<D, CT, NC, I + 1>(lbase, istride, a0, af, x, acc);
+        x3_cold_logits<D, CT, NC, I + 1>(lbase, istride, a0, af, x, acc, accl);
     }
 }
 __device__ __forceinline__ unsigned x3_pack_rne(float a, float b) {   // two fp32 -> packed bf16 pair (RNE), a in the low half
@@ -600,11 +639,17 @@ __device__ __forceinline__ void x3_solo(const unsigned lbase, const unsigned ist
                                         f32x4 (&U)[X3Geo<D, CT, NC>::NDT][CT], f32x4 (&lsum)[CT]) {
     using XG = X3Geo<D, CT, NC>;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    f32x4 acc[2][CT];
+    f32x4 acc[2][CT], accl[2][CT];
     bf16x8 af[XG::NI];
     pipe_fence();
-    x3_cold_logits<D, CT, NC>(lbase, istride, L.a0, af, x, acc);
+    x3_cold_logits<D, CT, NC>(lbase, istride, L.a0, af, x, acc, accl);
     pipe_fence();
+    if constexpr (XG::SPLIT) {
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc[rt][ct] += accl[rt][ct];
+    }
     bf16x8 pb[NC][CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
@@ -704,7 +749,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
 #pragma unroll
             for (int s = 0; s < NX; ++s) {
                 x[j][ct][s] = xr[j][s];
-                if (j > 0) asm volatile("" : "+a"(x[j][ct][s]));   // components 1.. live in AGPRs (mfma_v_ab)
+                if (j > 0 || XG::SPLIT) asm volatile("" : "+a"(x[j][ct][s]));   // components 1.. (SPLIT: all) live in AGPRs (mfma_v_ab)
             }
     }
     f32x4 U[XG::NDT][CT];
