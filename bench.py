@@ -584,6 +584,9 @@ def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None, traffi
                        f"ALGORITHMIC flops against the bf16 peak, `mfma_issue_frac` the MFMAs actually issued; in fp32 terms the "
                        f"algorithmic rate is {ach / PEAK_TFLOPS['f32']:.2f}x the dense f32-MFMA peak of {PEAK_TFLOPS['f32']} TFLOP/s")
         out["algorithmic_vs_f32_mfma_peak"] = ach / PEAK_TFLOPS["f32"]
+        # the roof of THIS algorithm on the pipe it runs on: the dense bf16 peak divided by the MFMAs one multiply-add costs
+        out["algorithm_peak_TFLOPs"] = peak / mult
+        out["frac_of_algorithm_peak"] = ach * mult / peak
     return out
 
 
