@@ -61,6 +61,14 @@
 #ifndef X6_SPLIT_ACC
 #define X6_SPLIT_ACC 1
 #endif
+// bf16x6: the row sums of a catalog range in CHUNKS of one steady-state trip (6 slots = 192 items): the accumulator restarts with
+// every trip (its first row-sum MFMA takes C = 0) and the finished chunk is added to a running fp32 total by one v_add per column
+// tile and trip.  A single accumulator over 10^5 .. 10^6 items grows far above the numerators it is fed; the matrix core then
+// truncates their low bits toward zero (27-bit alignment) and the sum of POSITIVE terms comes out low: -6.6e-6 relative on rows
+// with logits of +-10 over 20 000 items in an emulation of that arithmetic, +2e-8 with chunks (a plain fp32 chain: +2e-7).
+#ifndef X6_CHUNK_LSUM
+#define X6_CHUNK_LSUM 1
+#endif
 
 // D = 256 (round 3, NC = 2 only): the table is TWO images - dims 0..127 and dims 128..255, each [N, 256] bf16 c0 | c1 with the
 // 512-byte rows of the D = 128 kernel - and a slot walks both: the logits chain is 16 k-steps per image into the SAME accumulators,
@@ -93,6 +101,7 @@ struct X3Geo {
     static constexpr int MG = NRS + NIMG * MGI;
     static constexpr int P = 4 * CT;                       // numerator pairs per slot: (row tile, column tile, half)
     static constexpr bool SPLIT = NC == 3 && X6_SPLIT_ACC; // logits in two accumulators (see X6_SPLIT_ACC)
+    static constexpr bool CHUNK = NC == 3 && X6_CHUNK_LSUM; // row sums restart every steady-state trip (see X6_CHUNK_LSUM)
     static constexpr int GOPS = (SPLIT ? 4 : 2) * P;       // during G: (the 2 additions acc += acc_lo and) the 2 exponentials of every pair
     static constexpr int OPP = NC == 2 ? 6 : 11;           // split ops per pair: conversion, shift, mask, 2 subtractions, per component after the first
     static constexpr int LOPS = OPP * P;                   // during the next L
@@ -259,6 +268,12 @@ template <bool COLD>
 __device__ __forceinline__ void mfma_v0_ab(f32x4& acc, const bf16x8& a, const bf16x8& b) {   // acc (VGPR) = A . B, B in AGPRs
     if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15" : "=&v"(acc) : "v"(a), "a"(b));
     else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(b));
+}
+
+template <bool COLD>
+__device__ __forceinline__ void mfma_a0(f32x4& acc, const bf16x8& a, const bf16x8& b) {   // acc (AGPR) = A . B
+    if constexpr (COLD) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\ts_nop 15" : "=&a"(acc) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&a"(acc) : "v"(a), "v"(b));
 }
 
 template <int CT, int NC>
@@ -523,17 +538,18 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
     }
 }
 
-// row-sum MFMAs POS .. NC CT - 1
-template <int CT, int NC, int POS, bool COLD>
+// row-sum MFMAs POS .. NC CT - 1.  RESTART: the accumulator begins a new chunk (the first MFMA of every column tile takes C = 0)
+template <int CT, int NC, int POS, bool COLD, bool RESTART = false>
 __device__ __forceinline__ void x3_ones(f32x4 (&lsum)[CT], const bf16x8& ones, const bf16x8 (&pb)[NC][CT]) {
     if constexpr (POS < NC * CT) {
-        mfma_a<COLD>(lsum[POS % CT], ones, pb[POS / CT][POS % CT]);
-        x3_ones<CT, NC, POS + 1, COLD>(lsum, ones, pb);
+        if constexpr (RESTART && POS < CT) mfma_a0<COLD>(lsum[POS % CT], ones, pb[POS / CT][POS % CT]);
+        else mfma_a<COLD>(lsum[POS % CT], ones, pb[POS / CT][POS % CT]);
+        x3_ones<CT, NC, POS + 1, COLD, RESTART>(lsum, ones, pb);
     }
 }
 
 // one slot: L(t) || split of subtile t-1's numerators, then G(t-1) || exponentials of subtile t
-template <int D, int CT, int NC, int OFFL, int OFFG, int OFFL_NEXT, bool HAS_G, int VM, bool COLD, class RG>
+template <int D, int CT, int NC, int OFFL, int OFFG, int OFFL_NEXT, bool HAS_G, int VM, bool COLD, bool RESTART = false, class RG>
 __device__ __forceinline__ void x3_slot(const unsigned lbase_l, const unsigned lbase_g, const FastLane& L,
                                         PCVAE_X3_XARGS(D, CT, NC),
                                         bf16x8 (&af)[X3Geo<D, CT, NC>::NI], RG& r, f32x4 (&U)[X3Geo<D, CT, NC>::NDT][CT],
@@ -548,7 +564,7 @@ __device__ __forceinline__ void x3_slot(const unsigned lbase_l, const unsigned l
     x3_pack<CT, NC>(r.w, r.pb);
     if constexpr (HAS_G) {
         if constexpr (COLD || !(X3_PROBE & 4)) x3_tr_prologue<D, CT, NC, OFFG, X3_TD>(lbase_g, L.t0, r.tl, r.th);
-        x3_ones<CT, NC, 0, COLD>(lsum, L.ones, r.pb);
+        x3_ones<CT, NC, 0, COLD, RESTART>(lsum, L.ones, r.pb);
     }
     if constexpr (COLD) {               // exponentials of this subtile, nothing overlapped
         pipe_fence();
@@ -770,6 +786,9 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
     }
     const FastLane L = fast_lane<DL>(lane);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    float ltot[CT];   // (CHUNK) the row sums of the finished chunks
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) ltot[ct] = 0.f;
 
     X3Regs<CT, XG::NDTL, NC> r;
     bf16x8 af[XG::NI];
@@ -807,6 +826,10 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
             // Round 3 met it: with the copies in another order (a rebuild with one more instantiation in the translation unit)
             // the first MFMA of the first trip read a stale fragment - column tile 0 of every wave wrong.  Fenced here, per trip.
             pipe_fence();
+            if constexpr (XG::CHUNK) {   // the chunk the last trip summed joins the total; this trip's first row-sum MFMA restarts lsum
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) ltot[ct] += lsum[ct][0];
+            }
 #define PCVAE_X3S(UU)                                                                                                     \
             {                                                                                                             \
                 constexpr int TL = 1 + UU, TG = UU, TN = 2 + UU;                                                          \
@@ -814,7 +837,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
                 X3Seam s2 = seam_of(t + UU);                                                                              \
                 s2.stage_lds[0] = lds0 + ((NIMG * TL + NIMG + PF) % NB) * CB;   /* t = 1 (mod TR): constants */           \
                 if constexpr (NIMG > 1) s2.stage_lds[NIMG - 1] = lds0 + ((NIMG * TL + NIMG - 1 + NIMG + PF) % NB) * CB;   \
-                x3_slot<D, CT, NC, OL, OG, ON, true, (PF - 1) * PPW, false>(lds0, lds0, L, x, af, r, U, lsum, s2, wave_u, lane_off); \
+                x3_slot<D, CT, NC, OL, OG, ON, true, (PF - 1) * PPW, false, XG::CHUNK && UU == 0>(lds0, lds0, L, x, af, r, U, lsum, s2, wave_u, lane_off); \
             }
             PCVAE_X3S(0) PCVAE_X3S(1) PCVAE_X3S(2) PCVAE_X3S(3)
             if constexpr (TR > 4) { PCVAE_X3S(4) }
@@ -854,7 +877,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
     pipe_fence();
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-        const float l = lsum[ct][0];
+        const float l = XG::CHUNK ? ltot[ct] + lsum[ct][0] : lsum[ct][0];
         const int64_t row = rw + 16 * ct + c;
         if (row < p.R) {
             const int64_t o = (int64_t)split * p.R + row;
@@ -917,7 +940,13 @@ __global__ void __launch_bounds__(256) catalog_ce_merge_x3_kernel(CatParamsB p, 
             zt = fmaf(e[3], x[3], zt);
         }
     }
-    const float lse_r = log2f(L) * kLn2;
+    // ln L = e ln2 + ln m with L = m 2^e, m in [0.5, 1): log2f(L) * ln2 rounds log2 L at ITS magnitude (1 ulp of ~17 is 1.9e-6, and
+    // v_log_f32 is a 1-ulp instruction), which was the largest single term of this arithmetic's lse error.  e * kLn2Hi is exact
+    // (kLn2Hi has 9 trailing zero bits, |e| < 256); the rest is two fmaf, so the result carries one rounding of lse + ~1e-7.
+    int le;
+    const float lm = frexpf(L, &le);
+    constexpr float kLn2Hi = 0.693145751953125f, kLn2Lo = 1.42860682e-06f;
+    const float lse_r = fmaf((float)le, kLn2Hi, fmaf((float)le, kLn2Lo, logf(lm)));
     if (lane == 0) {
         nll[r] = t_ok ? lse_r - zt : NAN;
         if (lse) lse[r] = lse_r;

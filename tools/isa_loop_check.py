@@ -40,7 +40,18 @@ def forbidden_in(loop, no_mov=False):
             if k:
                 mfma_dst[k] |= r
     bad = []
-    for l in loop:
+    n = len(loop)
+    for i, l in enumerate(loop):
+        if l.startswith("v_accvgpr_read_b32"):
+            # a READ of an accumulator that no MFMA of the loop wrote in the last 16 instructions (the back edge included) moves a
+            # finished result, wherever hipcc puts it: the bf16x6 kernel hands its chunk of row sums to the running total that
+            # way once per trip (catalog_x3.h, X6_CHUNK_LSUM).  Anything closer to its writer stays forbidden.
+            k, src = _regs(l.split(",")[-1])
+            recent = [loop[(i - d) % n] for d in range(1, 17)]
+            close = any(x.startswith("v_mfma") and (_regs(x.split(None, 1)[1].split(",")[0])[1] & src) for x in recent)
+            if k != "a" or close:
+                bad.append(l)
+            continue
         if l.startswith(("v_accvgpr_", "scratch_", "buffer_store", "v_readlane", "v_writelane")):
             bad.append(l)
         elif l.startswith("v_mov_b"):

@@ -64,7 +64,7 @@ def main():
         res[name] = row
         print(name, json.dumps(row), flush=True)
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "r04_x6_error_table.json")
-    os.makedirs(os.path.dirname(path), exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     json.dump(res, open(path, "w"), indent=1)
 
 
