@@ -601,6 +601,25 @@ __device__ __forceinline__ void pipe_stage(const uint16_t* __restrict__ E, int64
                  : "memory", "m0");
 }
 
+// pieces [I0, I0 + K) of a wave's four, alone (PIPE_DMA_SPREAD: the seam's refill goes out over the gradient steps behind the
+// seam instead of as a burst of four at it: the burst stalled the wave's MFMA issue behind the vector-memory queue)
+template <int D, int I0, int K>
+__device__ __forceinline__ void pipe_stage_pieces(const uint16_t* __restrict__ E, int64_t n0, unsigned lds_dst, const int wave_u,
+                                                  const int (&lane_off)[4]) {
+    using G = FastGeo<D>;
+    static_assert(K == 1 || K == 2, "one or two pieces per step");
+    const char* base = reinterpret_cast<const char*>(E) + (n0 + (int64_t)wave_u * 4 * G::RPP) * G::RB;
+    const unsigned m0v = lds_dst + (unsigned)wave_u * 4096u;
+    if constexpr (K == 1)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                     ::"v"(lane_off[I0]), "s"(base), "s"(m0v), "n"(I0 * 1024) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 offset:%4\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:%5"
+                     ::"v"(lane_off[I0]), "v"(lane_off[I0 + 1]), "s"(base), "s"(m0v), "n"(I0 * 1024), "n"(I0 * 1024 + 1024)
+                     : "memory", "m0");
+}
+
 // ragged tail: up to 128 items staged synchronously with clamped addresses (same image: row * RB, fswz)
 template <int D, int NW>
 __device__ __forceinline__ void fast_stage_tail(const uint16_t* __restrict__ E, int64_t N, int64_t n0, char* buf) {
@@ -832,6 +851,12 @@ __device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 1
 // Timing probes (tools/build_variant.sh ... -DPIPE_PROBE=<mask>; results are garbage, only the time means something): drop from the
 // steady-state slots 1: the numerator VALU ops, 2: the A-fragment reads, 4: the transposed reads, 8: the seam (wait + barrier +
 // refill), 16: the LDS waits, 32: the row-sum MFMAs, 64: only the refill of the seam
+#ifndef PIPE_DMA_SPREAD
+#define PIPE_DMA_SPREAD 0    // 1: the seam's four LDS-DMA pieces over the gradient steps behind it instead of a burst at the seam.
+                             // Measured (round 4, same box): D = 128 config 4 25.30 -> 25.65 ms, D = 256 26.80 -> 27.48 ms, D = 64
+                             // +0.5 % - these slots are vector-issue bound and every piece then pays its own M0 write; the
+                             // bf16x3 / bf16x6 kernels (catalog_x3.h: X3_DMA_SPREAD, MFMA-bound slots) gain 1.0 / 1.4 % from it
+#endif
 #ifndef PIPE_PROBE
 #define PIPE_PROBE 0
 #endif
@@ -1018,6 +1043,8 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
                                            bf16x8 (&af)[2 * FastGeo<D>::KS]) {
     using G = FastGeo<D>;
     constexpr int NDT = G::NDT, SEAM_AT = NDT / 2;
+    constexpr int DMA_PS = (NDT - SEAM_AT) >= 4 ? 1 : 2;   // pieces per step of the spread refill (D = 64: two steps only)
+    static_assert(DMA_PS * (NDT - SEAM_AT) >= 4, "the spread refill is out before the gradient chain ends");
     if constexpr (DT < NDT) {
         if constexpr (DT == SEAM_AT) {
             if constexpr (SEAM) {
@@ -1031,13 +1058,22 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
                 } else if constexpr (!(PIPE_PROBE & 8)) {
                     if constexpr (PIPE_PROBE & 64) asm volatile("s_barrier" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
-                    if constexpr (!(PIPE_PROBE & 64))
-                        if (sm.n_stage >= 0) pipe_stage<D>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
+                    if constexpr (!(PIPE_PROBE & 64)) {
+                        if constexpr (PIPE_DMA_SPREAD) {
+                            if (sm.n_stage >= 0) pipe_stage_pieces<D, 0, DMA_PS>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
+                        } else {
+                            if (sm.n_stage >= 0) pipe_stage<D>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
+                        }
+                    }
                 }
             }
             if constexpr (COLD || !(PIPE_PROBE & 2))
                 pipe_a_prologue<D, OFFL_NEXT, PIPE_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
         }
+        // the rest of the seam's refill, DMA_PS pieces in front of each following step (all out before the next seam: the counted
+        // vmcnt there sees the same queue as with the burst)
+        if constexpr (SEAM && !COLD && PIPE_DMA_SPREAD && DT > SEAM_AT && (DT - SEAM_AT) * DMA_PS < 4 && !(PIPE_PROBE & (8 | 64)))
+            if (sm.n_stage >= 0) pipe_stage_pieces<D, (DT - SEAM_AT) * DMA_PS, DMA_PS>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
         if constexpr (HAS_G) {
             constexpr int extra = (DT >= SEAM_AT && DT < SEAM_AT + PIPE_TD) ? PIPE_AD : 0;
             if constexpr (DT + PIPE_TD < NDT && !(!COLD && (PIPE_PROBE & 4)))

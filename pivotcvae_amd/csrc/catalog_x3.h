@@ -51,6 +51,9 @@
 // Timing probes (tools/build_variant.sh ... -DX3_PROBE=<mask>; results are garbage, only the time means something): drop from the
 // steady-state slots 1: the numerator VALU ops, 2: the A-fragment reads, 4: the transposed reads, 8: the seam (wait + barrier +
 // refill), 16: the LDS waits, 32: only the seam's barrier, 64: only the seam's refill
+#ifndef X3_DMA_SPREAD
+#define X3_DMA_SPREAD 1      // the seam's LDS-DMA pieces one per X3_DMA_SPREAD gradient steps (0: a burst of 2 NC at the seam)
+#endif
 #ifndef X3_PROBE
 #define X3_PROBE 0
 #endif
@@ -451,6 +454,16 @@ __device__ __forceinline__ void x3_pipe_stage(const uint16_t* __restrict__ E, co
                        "s"(base), "s"(base + 4096), "s"(m0v), "s"(m0v + 4096u)
                      : "memory", "m0");
 }
+// piece I of a wave's 2 NC, alone (X3_DMA_SPREAD: one piece per gradient step behind the seam instead of a burst of 2 NC at it)
+template <int NC, int I>
+__device__ __forceinline__ void x3_pipe_stage_piece(const uint16_t* __restrict__ E, const int64_t n0, const unsigned lds_dst,
+                                                    const int wave_u, const int (&lane_off)[2 * NC]) {
+    constexpr int HI = I / 4, LO = I % 4;   // the immediate is 13 bits signed: pieces 4, 5 from a base 4 KiB further
+    const char* base = reinterpret_cast<const char*>(E) + n0 * (256 * NC) + (int64_t)wave_u * (2 * NC * 1024) + HI * 4096;
+    const unsigned m0v = lds_dst + (unsigned)wave_u * (unsigned)(2 * NC * 1024) + (unsigned)(HI * 4096);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 ::"v"(lane_off[I]), "s"(base), "s"(m0v), "n"(LO * 1024) : "memory", "m0");
+}
 // ragged tail: up to 128 items staged synchronously with clamped rows (same image: row * RB + part * 256, swizzled chunks)
 template <int NC>
 __device__ __forceinline__ void x3_stage_tail(const uint16_t* __restrict__ E, const int64_t N, const int64_t n0, char* buf) {
@@ -517,11 +530,19 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
             } else if constexpr (!(X3_PROBE & 8)) {
                 if constexpr (X3_PROBE & 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");   // probe: no barrier
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
-                if constexpr (!(X3_PROBE & 64)) x3_pipe_stage<NC>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);   // probe: no refill
+                if constexpr (!(X3_PROBE & 64)) {   // probe: no refill
+                    if constexpr (X3_DMA_SPREAD) x3_pipe_stage_piece<NC, 0>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
+                    else x3_pipe_stage<NC>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
+                }
             }
             if constexpr (DT == SEAM_LAST && (COLD || !(X3_PROBE & 2)))
                 x3_a_prologue<D, CT, NC, OFFL_NEXT, X3_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
         }
+        // the other pieces of the seam's refill, one in front of each following step (all of them are out before the next seam, so
+        // the counted vmcnt there sees the same queue as with the burst)
+        if constexpr (!COLD && X3_DMA_SPREAD && d > NDTI / 2 && (d - NDTI / 2) % X3_DMA_SPREAD == 0 &&
+                      (d - NDTI / 2) / X3_DMA_SPREAD < 2 * NC && !(X3_PROBE & (8 | 64)))
+            x3_pipe_stage_piece<NC, (d - NDTI / 2) / X3_DMA_SPREAD>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
         if constexpr (HAS_G) {
             // younger than tile DT's reads: tiles DT + 1 .. DT + X3_TD - 1, and the next slot's first A fragments once they are out
             constexpr int young = (DT + X3_TD - 1 < NDTL ? X3_TD - 1 : NDTL - 1 - DT);
@@ -723,6 +744,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
     constexpr int CB = XG::CB, ROWS = XG::ROWS, TR = XG::TR, NB = XG::NB, PF = XG::PF, DL = XG::DL, NIMG = XG::NIMG, PPW = XG::PPW;
     constexpr int NX = NIMG * XG::KSH;                                   // rx fragments per column tile and component
     static_assert(PPW == 2 * NC, "a wave stages 2 NC pieces of a chunk");
+    static_assert(XG::NDTI / 2 + (2 * NC - 1) * X3_DMA_SPREAD < XG::NDTI, "the spread refill is out before the gradient chain ends");
     static_assert(XG::gfirst(XG::MG) == XG::GOPS && XG::gfirst(XG::MG - 1) == XG::GOPS, "every exponential has a gap");
     static_assert(XG::lfirst(XG::ML - 2) == XG::LOPS, "every split op has a gap, the last two gaps of L stay free");
     static_assert(XG::gfirst(XG::NRS + 1) == 0, "no exponential before the row-sum MFMAs are out: the accumulators are fresh");
