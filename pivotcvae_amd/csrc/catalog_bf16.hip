@@ -852,10 +852,11 @@ __device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 1
 // steady-state slots 1: the numerator VALU ops, 2: the A-fragment reads, 4: the transposed reads, 8: the seam (wait + barrier +
 // refill), 16: the LDS waits, 32: the row-sum MFMAs, 64: only the refill of the seam
 #ifndef PIPE_DMA_SPREAD
-#define PIPE_DMA_SPREAD 0    // 1: the seam's four LDS-DMA pieces over the gradient steps behind it instead of a burst at the seam.
-                             // Measured (round 4, same box): D = 128 config 4 25.30 -> 25.65 ms, D = 256 26.80 -> 27.48 ms, D = 64
-                             // +0.5 % - these slots are vector-issue bound and every piece then pays its own M0 write; the
-                             // bf16x3 / bf16x6 kernels (catalog_x3.h: X3_DMA_SPREAD, MFMA-bound slots) gain 1.0 / 1.4 % from it
+#define PIPE_DMA_SPREAD 0    // n > 0: the seam's four LDS-DMA pieces as two pairs, the second n gradient steps behind the seam, instead of a
+                             // burst of four at it.  Measured (round 4, same box, n = 1 / 2 / 3): D = 128 config 4 +0.2 / +0.5 / +0.5 %,
+                             // D = 256 -0.5 / -0.3 / 0 %, config 3 +0.5 / +0.3 / 0 % - nothing, so the burst stays.  (One piece per
+                             // step: +1.4 ... +2.5 % AND three times the L2 misses.)  The bf16x6 kernel gains 1.1 % from pairs:
+                             // catalog_x3.h, X3_DMA_SPREAD; profiles/r04_dma_spread.txt
 #endif
 #ifndef PIPE_PROBE
 #define PIPE_PROBE 0
@@ -1043,8 +1044,9 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
                                            bf16x8 (&af)[2 * FastGeo<D>::KS]) {
     using G = FastGeo<D>;
     constexpr int NDT = G::NDT, SEAM_AT = NDT / 2;
-    constexpr int DMA_PS = (NDT - SEAM_AT) >= 4 ? 1 : 2;   // pieces per step of the spread refill (D = 64: two steps only)
-    static_assert(DMA_PS * (NDT - SEAM_AT) >= 4, "the spread refill is out before the gradient chain ends");
+    constexpr int DMA_PS = 2;   // pieces per group of the spread refill: pairs (single pieces cost L2 hits: catalog_x3.h, X3_DMA_SPREAD)
+    constexpr int DMA_STEP = PIPE_DMA_SPREAD < NDT - SEAM_AT ? PIPE_DMA_SPREAD : NDT - SEAM_AT - 1;   // steps between the two groups
+    static_assert(!PIPE_DMA_SPREAD || (DMA_STEP >= 1 && SEAM_AT + DMA_STEP < NDT), "the spread refill is out before the gradient chain ends");
     if constexpr (DT < NDT) {
         if constexpr (DT == SEAM_AT) {
             if constexpr (SEAM) {
@@ -1070,10 +1072,10 @@ __device__ __forceinline__ void pipe2_grad(const unsigned lbase_g, const int t0,
             if constexpr (COLD || !(PIPE_PROBE & 2))
                 pipe_a_prologue<D, OFFL_NEXT, PIPE_AD>(sm.next_lbase, a0, af);   // first A fragments of the next slot
         }
-        // the rest of the seam's refill, DMA_PS pieces in front of each following step (all out before the next seam: the counted
-        // vmcnt there sees the same queue as with the burst)
-        if constexpr (SEAM && !COLD && PIPE_DMA_SPREAD && DT > SEAM_AT && (DT - SEAM_AT) * DMA_PS < 4 && !(PIPE_PROBE & (8 | 64)))
-            if (sm.n_stage >= 0) pipe_stage_pieces<D, (DT - SEAM_AT) * DMA_PS, DMA_PS>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
+        // the second pair of the seam's refill, DMA_STEP steps later (out before the next seam: the counted vmcnt there sees the
+        // same queue as with the burst)
+        if constexpr (SEAM && !COLD && PIPE_DMA_SPREAD && DT == SEAM_AT + DMA_STEP && !(PIPE_PROBE & (8 | 64)))
+            if (sm.n_stage >= 0) pipe_stage_pieces<D, 2, DMA_PS>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
         if constexpr (HAS_G) {
             constexpr int extra = (DT >= SEAM_AT && DT < SEAM_AT + PIPE_TD) ? PIPE_AD : 0;
             if constexpr (DT + PIPE_TD < NDT && !(!COLD && (PIPE_PROBE & 4)))

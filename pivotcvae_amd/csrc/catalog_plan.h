@@ -50,13 +50,12 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // running sum's ulp swallows the small terms of a peaked row (N = 10M, |logit| up to 6: lse 6e-5 low, round 3).  Ranges of at
     // most 16 384 tiles (512K items); the merge adds the <= 64 partials.  (bf16: its own 2^-9 per term dwarfs that - plan unchanged.)
     int64_t ns_min = (f32 || x3) ? std::min<int64_t>(cap, cdiv(p.ntiles, 16384)) : 1;
-    // The 32 workgroups an XCD runs side by side stream the SAME catalog range and share it in the XCD's 4 MB L2 - as long as they
-    // stay within a few MB of each other in that stream.  Nothing holds them together (the ring's prefetch makes every workgroup
-    // latency-tolerant), so they drift apart at ~1 % of a pass: over a pass of 16 - 64 MB (config 4: 2 - 5 ms) that is nothing and
-    // the memory-side traffic is exactly one table read per 32 row blocks; over a pass of 2.5 - 5 GB (config 5 with one or two
-    // ranges: 100+ ms) the sharing is lost - PMC, round 4: 573 GB per launch for the bf16 kernel (2.8x the shared ideal) and
-    // 17.3 TB = 4.3 TB/s for bf16x3, every workgroup reading the 10 GB image on its own.  So a range is at most ~128 MB of table
-    // stream: workgroups re-align with every new pass.  (The price is partials: 169 MB per range at config 5, written and read once.)
+    // Range-length limit (experiments only; default off).  The 32 workgroups an XCD runs side by side stream the SAME catalog range
+    // and share it in the XCD's 4 MB L2 while they stay within ~2 MB of each other in that stream; at config 5 (5 - 10 GB images)
+    // they do not (PMC, round 4: 573 GB per launch for the bf16 kernel = 2.8x the shared ideal, 17.3 TB for bf16x3).  Hypothesis:
+    // they drift apart over a long pass, so shorter ranges would re-align them.  Refuted (tools/range_sweep.sh,
+    // profiles/r04_config5_range_sweep.txt): ranges of <= 1024 / 256 / 96 MB move the reads by 17 % and the time by +0.2 .. +0.4 %;
+    // the memory-side bytes do not set these kernels' time.  The knob stays for measurements.
     const int64_t row_bytes = (int64_t)D * (f32 ? 4 : prec == PCVAE_PREC_BF16X6 ? 6 : x3 ? 4 : 2);
     const char* env_mb = getenv("PCVAE_RANGE_MB");   // (experiments: tools/range_sweep.sh; read per call like PCVAE_PIPE_MIN_TILES)
     const int64_t range_mb = env_mb ? atoll(env_mb) : PCVAE_RANGE_MB_DEFAULT;

@@ -52,7 +52,14 @@
 // steady-state slots 1: the numerator VALU ops, 2: the A-fragment reads, 4: the transposed reads, 8: the seam (wait + barrier +
 // refill), 16: the LDS waits, 32: only the seam's barrier, 64: only the seam's refill
 #ifndef X3_DMA_SPREAD
-#define X3_DMA_SPREAD 1      // the seam's LDS-DMA pieces one per X3_DMA_SPREAD gradient steps (0: a burst of 2 NC at the seam)
+#define X3_DMA_SPREAD 3      // the seam's LDS-DMA refill in groups of X3_DMA_PPS pieces, one group per X3_DMA_SPREAD gradient steps
+                             // (0: a burst of 2 NC pieces at the seam).  Round 4, bf16x6 at config 4, same box: burst 148.0 ms; pairs
+                             // every 1 / 3 steps 146.8 / 146.5 ms with the L2 misses unchanged (121 M per launch = one per 32
+                             // workgroups); SINGLE pieces per step 146.5 ms but 380 M misses (L2 hit rate 96.8 -> 90.1 %: 44 GB
+                             // instead of 15.5 GB of memory-side reads per launch) - profiles/r04_dma_spread.txt
+#endif
+#ifndef X3_DMA_PPS
+#define X3_DMA_PPS 2         // pieces per group of the spread refill (adjacent 1 KiB pieces: 2 KiB of one table row range)
 #endif
 #ifndef X3_PROBE
 #define X3_PROBE 0
@@ -464,6 +471,15 @@ __device__ __forceinline__ void x3_pipe_stage_piece(const uint16_t* __restrict__
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
                  ::"v"(lane_off[I]), "s"(base), "s"(m0v), "n"(LO * 1024) : "memory", "m0");
 }
+// pieces I0 .. I0 + X3_DMA_PPS - 1
+template <int NC, int I0, int K = 0>
+__device__ __forceinline__ void x3_pipe_stage_group(const uint16_t* __restrict__ E, const int64_t n0, const unsigned lds_dst,
+                                                    const int wave_u, const int (&lane_off)[2 * NC]) {
+    if constexpr (K < X3_DMA_PPS && I0 + K < 2 * NC) {
+        x3_pipe_stage_piece<NC, I0 + K>(E, n0, lds_dst, wave_u, lane_off);
+        x3_pipe_stage_group<NC, I0, K + 1>(E, n0, lds_dst, wave_u, lane_off);
+    }
+}
 // ragged tail: up to 128 items staged synchronously with clamped rows (same image: row * RB + part * 256, swizzled chunks)
 template <int NC>
 __device__ __forceinline__ void x3_stage_tail(const uint16_t* __restrict__ E, const int64_t N, const int64_t n0, char* buf) {
@@ -531,7 +547,7 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
                 if constexpr (X3_PROBE & 32) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");   // probe: no barrier
                 else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
                 if constexpr (!(X3_PROBE & 64)) {   // probe: no refill
-                    if constexpr (X3_DMA_SPREAD) x3_pipe_stage_piece<NC, 0>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
+                    if constexpr (X3_DMA_SPREAD) x3_pipe_stage_group<NC, 0>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
                     else x3_pipe_stage<NC>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
                 }
             }
@@ -541,8 +557,8 @@ __device__ __forceinline__ void x3_grad(const unsigned lbase_g, const int t0, s1
         // the other pieces of the seam's refill, one in front of each following step (all of them are out before the next seam, so
         // the counted vmcnt there sees the same queue as with the burst)
         if constexpr (!COLD && X3_DMA_SPREAD && d > NDTI / 2 && (d - NDTI / 2) % X3_DMA_SPREAD == 0 &&
-                      (d - NDTI / 2) / X3_DMA_SPREAD < 2 * NC && !(X3_PROBE & (8 | 64)))
-            x3_pipe_stage_piece<NC, (d - NDTI / 2) / X3_DMA_SPREAD>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
+                      (d - NDTI / 2) / X3_DMA_SPREAD * X3_DMA_PPS < 2 * NC && !(X3_PROBE & (8 | 64)))
+            x3_pipe_stage_group<NC, (d - NDTI / 2) / X3_DMA_SPREAD * X3_DMA_PPS>(sm.E[img], sm.n_stage[img], sm.stage_lds[img], wave_u, lane_off);
         if constexpr (HAS_G) {
             // younger than tile DT's reads: tiles DT + 1 .. DT + X3_TD - 1, and the next slot's first A fragments once they are out
             constexpr int young = (DT + X3_TD - 1 < NDTL ? X3_TD - 1 : NDTL - 1 - DT);
@@ -744,7 +760,7 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_x3_pipe_kernel(CatParamsB p
     constexpr int CB = XG::CB, ROWS = XG::ROWS, TR = XG::TR, NB = XG::NB, PF = XG::PF, DL = XG::DL, NIMG = XG::NIMG, PPW = XG::PPW;
     constexpr int NX = NIMG * XG::KSH;                                   // rx fragments per column tile and component
     static_assert(PPW == 2 * NC, "a wave stages 2 NC pieces of a chunk");
-    static_assert(XG::NDTI / 2 + (2 * NC - 1) * X3_DMA_SPREAD < XG::NDTI, "the spread refill is out before the gradient chain ends");
+    static_assert(XG::NDTI / 2 + (2 * NC - 1) / X3_DMA_PPS * X3_DMA_SPREAD < XG::NDTI, "the spread refill is out before the gradient chain ends");
     static_assert(XG::gfirst(XG::MG) == XG::GOPS && XG::gfirst(XG::MG - 1) == XG::GOPS, "every exponential has a gap");
     static_assert(XG::lfirst(XG::ML - 2) == XG::LOPS, "every split op has a gap, the last two gaps of L stay free");
     static_assert(XG::gfirst(XG::NRS + 1) == 0, "no exponential before the row-sum MFMAs are out: the accumulators are fresh");
