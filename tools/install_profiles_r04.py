@@ -33,6 +33,8 @@ for name, kern, key, flops, alg_bytes, what in JOBS:
             if short.split("<")[0] in r["kernel"] and ("pipe_kernel<" + kern.split("<")[1][:6]) in r["kernel"]:
                 c[r["counter"]] = float(r["mean_per_dispatch"])
     avg_ns = None
+    if not os.path.exists(os.path.join(src, f"{name}_kernel_stats.csv")):   # this part of tools/profile_r04.sh was not re-run: entry kept
+        continue
     for r in csv.DictReader(open(os.path.join(src, f"{name}_kernel_stats.csv"))):
         if kern in r["Name"]:
             avg_ns = float(r["AverageNs"])
