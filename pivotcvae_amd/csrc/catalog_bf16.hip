@@ -839,9 +839,6 @@ __device__ __forceinline__ void lgkm_wait() {
 // copies (tests/test_host_logic.py checks the generated ISA) and is fenced once per trip, at its latch.
 __device__ __forceinline__ void pipe_fence() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 
-#ifndef PIPE_CT256
-#define PIPE_CT256 2         // column tiles of 16 rows per wave of the D = 256 cross-entropy kernel
-#endif
 #ifndef PIPE_TD
 #define PIPE_TD 2            // transposed reads: d tiles requested ahead (2 reads each)
 #endif
@@ -1225,7 +1222,12 @@ __global__ void __launch_bounds__(256, 1) catalog_ce_bf16_pipe_kernel(CatParamsB
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int nrb = (int)((p.R + ROWS - 1) / ROWS);
     const int split = logical / nrb, rb = logical % nrb;
-    if (p.safe_flags[(int)(((int64_t)rb * ROWS) / ROWS_WG)] != 0) return;  // large |rx|: the lazy-max kernel handles this block
+    {   // large |rx|: the lazy-max kernel handles those 256-row blocks (flags are per ROWS_WG rows; a workgroup whose rows straddle
+        // two of them - ROWS does not divide ROWS_WG at CT = 3 - leaves only when BOTH are flagged: the merge ignores what it
+        // computes for rows of a flagged block)
+        const int64_t r_first = (int64_t)rb * ROWS, r_last = min(r_first + ROWS, p.R) - 1;
+        if (p.safe_flags[(int)(r_first / ROWS_WG)] != 0 && p.safe_flags[(int)(r_last / ROWS_WG)] != 0) return;
+    }
     const int t_beg = split * p.tiles_per_split;
     const int t_end = min(t_beg + p.tiles_per_split, p.ntiles);
     const int64_t nbase = (int64_t)t_beg * 32;

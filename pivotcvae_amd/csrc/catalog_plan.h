@@ -12,6 +12,12 @@
 #define X3_CT256 1   // D = 256: 16 rows per wave, 64 per workgroup (U alone is 128 accumulator registers at 32 rows: hipcc then spills)
 #endif
 static inline constexpr int x3_ct(int D) { return D == 256 ? X3_CT256 : X3_CT; }
+#ifndef PIPE_CT256
+#define PIPE_CT256 2   // column tiles of 16 rows per wave of the D = 256 bf16 cross-entropy kernel (64 PIPE_CT256 rows per workgroup).
+                       // 3 (48 rows per wave, a third less LDS traffic per MFMA) builds with a copy-free steady-state loop but 592 bytes
+                       // of scratch per lane in the fenced paths; measured round 4: N = 1M 27.5 ms (no gain), config 5 five times
+                       // SLOWER, one parity failure at R = 300 - not pursued
+#endif
 
 #ifndef PCVAE_RANGE_MB_DEFAULT
 #define PCVAE_RANGE_MB_DEFAULT 0   // longest catalog range in MB of table stream (0: no limit); see catalog_plan
@@ -44,7 +50,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // Ranges stay long enough that the per-range prologue (rx fragments) and epilogue (partials) are amortised.
     const int64_t slots = 256 * (f32 ? 2 : 1);
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
-    const int64_t nblk = x3 ? cdiv(R, 64 * x3_ct(D)) : ((!f32 && D == 256) ? cdiv(R, 128) : p.nrb);
+    const int64_t nblk = x3 ? cdiv(R, 64 * x3_ct(D)) : ((!f32 && D == 256) ? cdiv(R, 64 * PIPE_CT256) : p.nrb);
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));
     // fp32-grade results (exact f32, bf16x3): a range's row sums and U are ONE fp32 accumulation chain, and past ~1M items the
     // running sum's ulp swallows the small terms of a peaked row (N = 10M, |logit| up to 6: lse 6e-5 low, round 3).  Ranges of at
