@@ -325,6 +325,20 @@ int pcvae_candidate_scores_bwd(const float* dp, int64_t R, const float* E, int64
 int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, const int64_t* target, float* nll, float* dp,
                    int64_t lddp, pcvae_stream_t stream);
 
+/* K9 fused: candidate-set softmax cross-entropy, loss AND gradient in one launch, nothing of size [R, Cn] in memory
+ *                                                       data_loader.py:46-58 ; models/pivotcvae.py:265-271 ;
+ *                                                       train_generative.py:52-57 (the DEFAULT mode: no --mask_train)
+ *     ids of row r: given (cand [R, Cn] + cand_target [R]: what a batch of the reference's dataset carries, or a recorded draw)
+ *                   or, with cand == NULL, drawn in-kernel exactly as pcvae_candidate_draw(feature, .., seed, row_offset) draws them
+ *                   (first-hit / overwrite rule; the stream is keyed by the GLOBAL row row_offset + r);
+ *     s_c = <rx_r, E[id_c]> (fp32 fmaf chains) ;  nll[r] = logsumexp_c s_c - s_t ;  lse[r] optional ;
+ *     dx[r, :] = dx_scale * (sum_c softmax_c E[id_c] - E[id_t])  (optional) ;  tgt_out[r] = the target column used (optional).
+ *     A candidate id or target outside its range makes that row's outputs NaN (the reference raises an index error).
+ *     D in {16, 32, 64, 128, 256} (other widths: zero-padded by the caller), N < 2^31 - 1.                                  */
+int pcvae_candidate_ce(const float* rx, int64_t R, const float* E, int64_t N, int D, int Cn, const int64_t* feature,
+                       uint64_t seed, uint64_t row_offset, const int64_t* cand, const int64_t* cand_target, float* nll,
+                       float* lse, float* dx, float dx_scale, int64_t* tgt_out, pcvae_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K8  Adam over one flat fp32 buffer                    train_generative.py:103,134
  *     torch.optim.Adam defaults (betas 0.9/0.999, eps 1e-8, no weight decay, bias-corrected):
@@ -344,8 +358,9 @@ int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, 
  * time.time(), train_generative.py:113).
  * This is the library's ONE piece of process-global state: the switch applies to the instrumented launches of every thread and
  * the durations are kept in a process-wide list - off by default, never toggle it while another thread is launching.           */
-#define PCVAE_TIMER_GATHER 1        /* gather_rows_vec4_kernel      (pcvae_gather_rows)      */
+#define PCVAE_TIMER_GATHER 1        /* gather_rows_coal_kernel (D = 64 / 128 / 256) or gather_rows_vec4_kernel (pcvae_gather_rows) */
 #define PCVAE_TIMER_ASSEMBLE 2      /* assemble_inputs_vec_kernel   (pcvae_assemble_inputs)  */
+#define PCVAE_TIMER_CANDIDATE_CE 3  /* candidate_ce_kernel          (pcvae_candidate_ce)     */
 int pcvae_kernel_timer(int enable);
 int pcvae_kernel_timer_read(float* ms, int* tags, int cap);
 

@@ -25,6 +25,8 @@ Reference citations (relative to /root/reference):
   response_mlp          env/response_model.py:76-87
   urm_forward           env/response_model.py:129-154, 286-295, 315-323   (URM / URM_P / URM_P_MR as evaluators; golden G10)
   candidate_targets     data_loader.py:46-58          (first-hit / overwrite rule on a recorded draw; golden G11)
+  candidate_ce          models/pivotcvae.py:265-271 + train_generative.py:56   (per-row nll and d rx of the candidate branch; the
+                        same ops as forward(candidates=..) + gen_loss, which golden G6 pins, applied to a bare rx)
 """
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -295,6 +297,19 @@ def candidate_targets(features, raw):
         else:
             flat_c[i, 0] = flat_f[i]
     return cand, tgt.view(features.shape)
+
+
+def candidate_ce(rx, E, cand, tgt, dtype=torch.float64):
+    """The candidate branch's tail on a bare rx [R, D]: candidateEmb = E[cand] [R, Cn, D]; p = bmm(candidateEmb, rx)
+    (models/pivotcvae.py:268-270); per-row CrossEntropyLoss(p, tgt) (train_generative.py:56, reduction left to the caller) and its
+    gradient with respect to rx by autograd.  -> (nll [R], lse [R], d(sum nll)/d rx [R, D]) in ``dtype``."""
+    x = rx.to(dtype).clone().requires_grad_(True)
+    Cn = cand.shape[-1]
+    emb = E.to(dtype)[cand.reshape(-1, Cn)]
+    p = torch.bmm(emb, x.view(-1, x.shape[1], 1)).view(-1, Cn)
+    nll = F.cross_entropy(p, tgt.reshape(-1), reduction="none")
+    nll.sum().backward()
+    return nll.detach(), torch.logsumexp(p.detach(), dim=1), x.grad
 
 
 def response_loss_and_grads(sd, slates, users, targets, no_user=False):

@@ -77,6 +77,7 @@ SIGNATURES = {
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_candidate_scores_bwd": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],
+    "pcvae_candidate_ce": [_P, _L, _P, _L, _I, _I, _P, _U64, _U64, _P, _P, _P, _P, _P, _F, _P, _P],
     "pcvae_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "pcvae_adam_step_l2": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _F, _P],
     "pcvae_kernel_timer": [_I],

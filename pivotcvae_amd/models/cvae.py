@@ -140,6 +140,28 @@ class BaseCVAE(nn.Module):
         return ops.catalog_argmax(embeddings.reshape(-1, self.feature_size), self.catalog_table(),
                                   prec=self.catalog_precision)
 
+    def _rec_term(self, rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates=None):
+        """the reconstruction term of get_gen_loss from rx [B, S, D], fused loss + gradient, no logits in memory.
+
+        ``candidates`` None: the mask-train branch (train_generative.py:58-59): full-catalog softmax CE with the downsample rule.
+        ``candidates`` = an int Cn: the candidate-set branch (:52-56) with the sets of data_loader.py:46-58 drawn in-kernel (Philox
+        stream keyed by (mask_seed, global slot)); a pair (sample_candidates [B, S, Cn], sample_targets [B, S]): sets as given."""
+        S, D = s.shape[1], self.feature_size
+        rows = rx.reshape(-1, D)
+        if candidates is not None:
+            if isinstance(candidates, (tuple, list)):
+                cand, tgt = candidates
+                return ops.candidate_ce(rows, self.catalog_table(), cand=cand, cand_target=tgt, inv_count=inv_count,
+                                        unit_upstream=terms_only)
+            return ops.candidate_ce(rows, self.catalog_table(), int(candidates), s.reshape(-1), mask_seed, row_offset * S,
+                                    inv_count=inv_count, unit_upstream=terms_only)
+        N = self.docEmbed.weight.shape[0]
+        keep_prob = 1.0 if n_neg is None else float(n_neg) / N
+        if keep_prob > 1.0:
+            raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
+        return ops.catalog_ce(rows, self.catalog_table(), s.reshape(-1), keep_prob, mask_seed, row_offset * S, keep_mask,
+                              self.catalog_precision, inv_count, unit_upstream=terms_only)
+
     def _user_rows(self, u, B):
         return None if self.noUser else ops.gather_rows(self.userEmbed.weight, u.reshape(-1)).reshape(B, -1)
 

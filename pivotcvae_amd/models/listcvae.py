@@ -68,11 +68,11 @@ class UserListCVAEWithPrior(BaseCVAE):
         return p, rx, z, emb, z_mu, z_logvar
 
     def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
-             eps_offset=None, terms_only=False):
-        """Fused counterpart of train_generative.get_gen_loss for the mask-train path: the [R, N] logits are
-        never materialised.  -> (loss, recLoss, KLD)."""
+             eps_offset=None, terms_only=False, candidates=None):
+        """Fused counterpart of train_generative.get_gen_loss: neither the [R, N] logits of the mask-train branch nor the
+        [R, Cn] ids / rows / logits of the candidate branch (``candidates``: BaseCVAE._rec_term) are ever materialised.
+        -> (loss, recLoss, KLD)."""
         B = s.shape[0]
-        N = self.docEmbed.weight.shape[0]
         cond = self.get_condition(r)
         emb = ops.gather_rows(self.docEmbed.weight, s.reshape(-1), group=s.shape[1])
         u_emb = self._user_rows(u, B)
@@ -84,12 +84,7 @@ class UserListCVAEWithPrior(BaseCVAE):
         else:
             z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, eps)
         rx = self.decode(z, cond, u_emb)
-        keep_prob = 1.0 if n_neg is None else float(n_neg) / N
-        if keep_prob > 1.0:
-            raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
-        rec = ops.catalog_ce(rx.reshape(-1, self.feature_size), self.catalog_table(), s.reshape(-1), keep_prob,
-                             mask_seed, row_offset * s.shape[1], keep_mask, self.catalog_precision, inv_count,
-                             unit_upstream=terms_only)
+        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates)
         if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
             return None, rec, k
         return rec + beta * k, rec, k

@@ -131,8 +131,10 @@ class UserPivotCVAE(BaseCVAE):
         return p, rx, z, emb, z_mu, z_logvar
 
     def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
-             eps_offset=None, terms_only=False, sample_offset=None):
-        """Fused counterpart of train_generative.get_gen_loss (mask-train path) -> (loss, recLoss, KLD).
+             eps_offset=None, terms_only=False, sample_offset=None, candidates=None):
+        """Fused counterpart of train_generative.get_gen_loss -> (loss, recLoss, KLD).  ``candidates`` None: the mask-train
+        branch; an int Cn / a pair (sample_candidates, sample_targets): the candidate-set branch - the reference's default mode
+        (train_generative.py:52-57, 270-274) - from ONE fused launch (BaseCVAE._rec_term, ops.candidate_ce).
 
         The [B*S, N] logits never exist: the full-catalog softmax CE (with the reference's downsample
         semantics when n_neg < N) and its gradient come from one streaming pass over the catalog.
@@ -144,10 +146,10 @@ class UserPivotCVAE(BaseCVAE):
         the reference either.
         """
         B, S = s.shape
-        N = self.docEmbed.weight.shape[0]
         if self.TRAIN_RULE == "gt" and self.FUSED_TRAIN_PATH and r.shape[1] == S and \
                 ops.heads_adjacent(self.encmu, self.enclogvar) and ops.heads_adjacent(self.priorMu, self.priorLogvar):
-            return self._loss_fused(s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only)
+            return self._loss_fused(s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only,
+                                    candidates)
         cond = self.get_condition(r)
         emb = ops.gather_rows(self.docEmbed.weight, s.reshape(-1), group=S)
         u_emb = self._user_rows(u, B)
@@ -166,25 +168,21 @@ class UserPivotCVAE(BaseCVAE):
             rx = self._complete(z, cond, u_emb, pivot_emb)
         else:
             rx = self.decode(z, cond, u_emb=u_emb, true_pivot=s[:, 0].contiguous(), sample_offset=sample_offset)
-        keep_prob = 1.0 if n_neg is None else float(n_neg) / N
-        if keep_prob > 1.0:
-            raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
-        rec = ops.catalog_ce(rx.reshape(-1, self.feature_size), self.catalog_table(), s.reshape(-1), keep_prob,
-                             mask_seed, row_offset * S, keep_mask, self.catalog_precision, inv_count, unit_upstream=terms_only)
+        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates)
         if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
             return None, rec, k
         return rec + beta * k, rec, k
 
     FUSED_TRAIN_PATH = True   # tests switch it off to compare the two routes
 
-    def _loss_fused(self, s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only):
+    def _loss_fused(self, s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only,
+                    candidates=None):
         """loss() for the ground-truth pivot rule with a trainer's flat parameter buffer attached: the same arithmetic in fewer,
         larger launches - one kernel assembles the three stack inputs (condition, gathers, concatenations), each stack's two heads
         are one N = 2 Z GEMM, reparametrize + KL are one kernel that writes z straight into the slate-completion input, and that
         stack's last GEMM writes slots 1.. of rx next to the pivot row."""
         B, S = s.shape
         D, Z = self.feature_size, self.latent_size
-        N = self.docEmbed.weight.shape[0]
         enc_in, prior_in, scm_in, rx = ops.assemble_inputs(self.docEmbed.weight, None if self.noUser else self.userEmbed.weight,
                                                            s, r, u, Z)
         # the encoder and the prior share only their inputs: layer i of both is one grouped launch, forward and backward
@@ -198,11 +196,7 @@ class UserPivotCVAE(BaseCVAE):
             scm_x, self._last_eps, k = ops.latent_packed(y_enc, y_prior, scm_in, eps, Z=Z)
         self.last_pivot = s[:, 0]
         rx = ops.mlp_into(scm_x, self._mlp_layers("scm", self._n_scm), rx, D, grad_cols=Z)   # only z carries a gradient
-        keep_prob = 1.0 if n_neg is None else float(n_neg) / N
-        if keep_prob > 1.0:
-            raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
-        rec = ops.catalog_ce(rx.reshape(-1, D), self.catalog_table(), s.reshape(-1), keep_prob, mask_seed, row_offset * S, keep_mask,
-                             self.catalog_precision, inv_count, unit_upstream=terms_only)
+        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates)
         if terms_only:
             return None, rec, k
         return rec + beta * k, rec, k

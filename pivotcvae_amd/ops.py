@@ -1299,6 +1299,90 @@ def candidate_draw(slates, n_items, n_candidate, seed=0, row_offset=0, raw=None)
     return cand.view(B, S, Cn), tgt.view(B, S)
 
 
+def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offset=0, cand=None, cand_target=None, want_dx=True,
+                     dx_scale=1.0, want_target=False):
+    """The candidate-set softmax CE in ONE launch (pcvae_candidate_ce): -> (nll [R], lse [R], dx [R, D] * dx_scale or None,
+    target column [R] or None).  Either ``cand`` [R, Cn] + ``cand_target`` [R] (sets as given: a batch of the reference's dataset,
+    a recorded draw) or ``feature`` [R] + ``n_candidate`` (sets drawn in-kernel from the stream of ``candidate_draw``)."""
+    table = _as_table(table)
+    require_device(rx, table.weight, feature, cand, cand_target)
+    rx = _c2d(rx).contiguous()
+    R, D0 = rx.shape
+    E, D = table.padded()
+    rx = _pad_cols(rx, D)
+    N = E.shape[0]
+    if cand is not None:
+        cand = cand.reshape(R, -1).to(torch.int64).contiguous()
+        Cn = cand.shape[1]
+        if cand_target is None:
+            raise ValueError("candidate_ce: given candidate sets need their target columns (sample_targets)")
+        cand_target = cand_target.reshape(-1).to(torch.int64).contiguous()
+        if cand_target.numel() != R:
+            raise ValueError("candidate_ce: one target column per row expected")
+        feature = None
+    else:
+        if feature is None or n_candidate is None:
+            raise ValueError("candidate_ce: pass the slots' true items and n_candidate, or candidate sets")
+        Cn = int(n_candidate)
+        feature = feature.reshape(-1).to(torch.int64).contiguous()
+        if feature.numel() != R:
+            raise ValueError("candidate_ce: one true item per row expected")
+    nll = torch.empty(R, dtype=F32, device=rx.device)
+    lse = torch.empty(R, dtype=F32, device=rx.device)
+    dx = torch.empty(R, D, dtype=F32, device=rx.device) if want_dx else None
+    tcol = torch.empty(R, dtype=torch.int64, device=rx.device) if want_target else None
+    timing = CATALOG_CE_TIMING   # the step's reconstruction kernel, whichever it is (bench.py times it on the launch stream)
+    tok = timing[0]() if timing else None
+    check(lib().pcvae_candidate_ce(ptr(rx, F32), R, ptr(E, F32), N, D, Cn, ptr(feature), int(seed), int(row_offset), ptr(cand),
+                                   ptr(cand_target), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), ptr(tcol), stream()),
+          "candidate_ce")
+    if timing:
+        timing[1](tok)
+    if dx is not None and D != D0:
+        dx = dx[:, :D0]
+    return nll, lse, dx, tcol
+
+
+class _CandidateCE(torch.autograd.Function):
+    """mean-reduced (times ``inv_count``) candidate-set softmax CE; backward = saved direction * upstream (``unit_upstream`` as in
+    _CatalogCE: the kernel writes the direction times inv_count and a registered constant-1 seed hands it on without a launch)."""
+
+    @staticmethod
+    def forward(ctx, rx, table, n_candidate, feature, seed, row_offset, cand, cand_target, inv_count, unit_upstream):
+        want_dx = rx.requires_grad
+        nll, _lse, dx, _t = candidate_ce_raw(rx.detach(), table, n_candidate, feature, seed, row_offset, cand, cand_target, want_dx,
+                                             dx_scale=float(inv_count) if unit_upstream else 1.0)
+        out = torch.empty((), dtype=F32, device=rx.device)
+        check(lib().pcvae_sum(ptr(nll, F32), nll.numel(), float(inv_count), ptr(out, F32), stream()), "sum")
+        ctx.inv_count = float(inv_count)
+        ctx.unit = bool(unit_upstream)
+        if want_dx:
+            ctx.save_for_backward(dx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        if ctx.unit and _is_unit_seed(g):
+            return (dx,) + (None,) * 9
+        g = g.contiguous()
+        out = torch.empty_like(dx)
+        check(lib().pcvae_scale_rows(ptr(dx, F32), _ld(dx), ptr(out, F32), _ld(out), dx.shape[0], dx.shape[1],
+                                     ptr(g, F32), 1.0 if ctx.unit else ctx.inv_count, stream()), "scale_rows")
+        return (out,) + (None,) * 9
+
+
+def candidate_ce(rx, table, n_candidate=None, feature=None, seed=0, row_offset=0, cand=None, cand_target=None, inv_count=None,
+                 unit_upstream=False):
+    """CrossEntropyLoss(bmm(docEmbed(candidates), rx), sample_targets) (models/pivotcvae.py:265-271, train_generative.py:52-57)
+    without the [R, Cn] ids, the [R, Cn, D] rows or the [R, Cn] logits: loss and d rx from one launch.
+
+    ``inv_count`` defaults to 1/R (the 'mean'); data-parallel ranks pass 1/(R_local * world_size)."""
+    R = rx.shape[0]
+    return _CandidateCE.apply(rx, _as_table(table), n_candidate, feature, seed, row_offset, cand, cand_target,
+                              (1.0 / R) if inv_count is None else inv_count, unit_upstream)
+
+
 def urm_forward(E, item_bias, U, user_bias, slates, users, pos_bias=None, pos_dep=None, mr_factor=None):
     """URM / URM_P / URM_P_MR.core_forward (env/response_model.py:129-150, 286-295, 315-323) -> [B, S] scores."""
     require_device(E, item_bias, U, user_bias, slates, users, pos_bias, pos_dep)

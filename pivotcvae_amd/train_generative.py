@@ -43,19 +43,24 @@ def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None, seed=0,
     ``trainset.init_sampling(nneg)`` sets in the reference, default ``n_neg`` - Philox stream (seed, row_offset + slot))."""
     slates, users, targets = _batch_to_device(batch_data, model.device)
     if model.candidateFlag:
-        pMu, pLogvar = model.get_prior(targets, users)
-        if "sample_candidates" in batch_data:
+        given = "sample_candidates" in batch_data
+        if given:
             cand = torch.as_tensor(np.asarray(batch_data["sample_candidates"]), dtype=torch.long).to(model.device)
             tgt = torch.as_tensor(np.asarray(batch_data["sample_targets"]), dtype=torch.long).to(model.device)
-        else:
+        # the reference passes nn.CrossEntropyLoss(): that case is ONE fused launch (ids, rows and logits never exist in memory);
+        # any other lossFun is called as given on the materialised candidate logits of forward()
+        plain_ce = isinstance(lossFun, torch.nn.CrossEntropyLoss) and lossFun.weight is None and \
+            lossFun.reduction == "mean" and lossFun.ignore_index == -100 and getattr(lossFun, "label_smoothing", 0.0) == 0.0
+        if plain_ce and hasattr(model, "loss"):
+            cands = (cand, tgt) if given else int(getattr(model, "nCandidate", n_neg))
+            return model.loss(slates, targets, users, beta, eps=eps, mask_seed=seed, row_offset=row_offset, candidates=cands)
+        pMu, pLogvar = model.get_prior(targets, users)
+        if not given:
             N = model.docEmbed.weight.shape[0]
             cand, tgt = ops.candidate_draw(slates, N, int(getattr(model, "nCandidate", n_neg)), seed=seed,
                                            row_offset=row_offset * slates.shape[1])
         pred, _rx, _z, _emb, mu, logvar = model.forward(slates, targets, candidates=cand, u=users, eps=eps)
-        # the reference passes nn.CrossEntropyLoss(); that case runs our dense-CE kernel, anything else is called as given
-        plain_ce = isinstance(lossFun, torch.nn.CrossEntropyLoss) and lossFun.weight is None and \
-            lossFun.reduction == "mean" and lossFun.ignore_index == -100 and getattr(lossFun, "label_smoothing", 0.0) == 0.0
-        recLoss = ops.dense_ce(pred, tgt.reshape(-1)) if plain_ce else lossFun(pred, tgt.reshape(-1))
+        recLoss = lossFun(pred, tgt.reshape(-1))
         KLD = ops.kld(mu, logvar, pMu, pLogvar)
         return recLoss + beta * KLD, recLoss, KLD
     N = model.docEmbed.weight.shape[0]
@@ -114,9 +119,12 @@ class Trainer:
     """
 
     def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None,
-                 capture_graph=False, world_size=None, rank=0, resident_batch=False):
+                 capture_graph=False, world_size=None, rank=0, resident_batch=False, n_candidate=None):
         import torch.distributed as dist
         self.model, self.beta, self.n_neg = model, float(beta), n_neg
+        # the reference's DEFAULT mode (no --mask_train): candidate sets of n_candidate columns per slot, drawn in the fused
+        # kernel from a stream keyed by (step, GLOBAL slot) - independent of the world size, like the masks and eps
+        self.n_candidate = None if n_candidate is None else int(n_candidate)
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
@@ -138,7 +146,7 @@ class Trainer:
         # has the same problem, so that mode stays eager - and so do the SAMPLED pivot rules (spt / sgt): their Gumbel-max
         # sampler takes (seed, row offset) as kernel arguments too, a replayed graph would redraw the same pivots every step.
         # The all-reduce and Adam stay outside the graph.
-        self.capture_graph = bool(capture_graph) and n_neg is None and loss_fn is None and \
+        self.capture_graph = bool(capture_graph) and n_neg is None and n_candidate is None and loss_fn is None and \
             getattr(model, "TRAIN_RULE", "gt") in ("gt", "pt")
         self._graph = None
         self._static = None
@@ -166,6 +174,8 @@ class Trainer:
         self.opt.zero_grad()
         kw = dict(beta=self.beta, n_neg=self.n_neg, eps=eps, row_offset=row_offset, inv_count=1.0 / (B * S * self.world),
                   eps_offset=eps_offset, mask_seed=self.global_step)
+        if self.n_candidate is not None:
+            kw["candidates"] = self.n_candidate
         if self._own_loss and getattr(self.model, "TRAIN_RULE", "gt") in ("spt", "sgt"):
             # sampled pivots: the sampler's stream position is the slate's GLOBAL index in the run, like eps - independent of how
             # the batch is sharded over ranks
@@ -319,8 +329,17 @@ def _dataset_arrays(ds):
 
 
 def candidate_loss(model, s, r, u, beta, n_candidate, seed=0, row_offset=0, inv_count=None, eps=None, eps_offset=None):
-    """The candidate path of get_gen_loss as a Trainer loss function: candidate sets drawn on the device, streams pinned to global
-    slate indices (independent of sharding), the mean scaled by ``inv_count``.  -> (loss, recLoss, KLD)"""
+    """The candidate path of get_gen_loss as a Trainer loss function: ``model.loss(candidates=n_candidate)`` - candidate sets drawn
+    in the fused kernel, streams pinned to global slate indices (independent of sharding), the mean scaled by ``inv_count``.
+    -> (loss, recLoss, KLD)"""
+    return model.loss(s, r, u, beta, eps=eps, mask_seed=seed, row_offset=row_offset, inv_count=inv_count, eps_offset=eps_offset,
+                      candidates=int(n_candidate))
+
+
+def candidate_loss_materialised(model, s, r, u, beta, n_candidate, seed=0, row_offset=0, inv_count=None, eps=None, eps_offset=None):
+    """The same loss the way the reference computes it - ids [B, S, Cn] (``ops.candidate_draw``), candidate logits through
+    ``forward(candidates=...)`` (K9 scores), dense CE - kept as the cross-check of the fused kernel (tests) and for callers that
+    want ``forward()``'s ``p``.  Same streams, same result up to fp32 summation order."""
     B, S = s.shape
     N = model.docEmbed.weight.shape[0]
     cand, tgt = ops.candidate_draw(s, N, n_candidate, seed=seed, row_offset=row_offset * S)
@@ -390,11 +409,8 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
     L = tr_s.shape[0]
 
     if trainer is None:
-        if model.candidateFlag:
-            fn = lambda m, s, r, u, beta, n_neg, eps, row_offset, inv_count, eps_offset, mask_seed, **_: \
-                candidate_loss(m, s, r, u, beta, n_cand, seed=mask_seed, row_offset=row_offset, inv_count=inv_count, eps=eps,
-                               eps_offset=eps_offset)
-            trainer = Trainer(model, lr=lr, beta=beta, n_neg=None, process_group=process_group, loss_fn=fn)
+        if model.candidateFlag:   # the reference's default mode: the fused candidate kernel inside the trainer's own (seeded) step
+            trainer = Trainer(model, lr=lr, beta=beta, n_neg=None, process_group=process_group, n_candidate=n_cand)
         else:
             trainer = Trainer(model, lr=lr, beta=beta, n_neg=None if n_neg >= N else n_neg, process_group=process_group,
                               capture_graph=capture_graph)

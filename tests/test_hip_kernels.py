@@ -687,6 +687,106 @@ def test_candidate_scores(ops):
     torch.testing.assert_close(rd.grad.cpu(), torch.einsum("rc,rcd->rd", g, E[cand]), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("R,N,D,Cn", [(35, 203, 16, 13), (130, 5000, 128, 1000), (7, 64, 32, 1), (66, 1000, 64, 257),
+                                      (9, 300, 256, 70), (33, 97, 20, 50), (5, 50, 128, 4500), (1, 1, 16, 3)])
+def test_candidate_ce_fused_given_sets(ops, R, N, D, Cn):
+    """pcvae_candidate_ce on GIVEN candidate sets (what a batch of the reference's dataset carries) against the oracle's
+    bmm + CrossEntropyLoss + autograd in fp64: duplicates count in the denominator, the target sits at any column, widths without a
+    kernel are padded (D = 20), Cn beyond one LDS batch (4500), Cn = 1, N = 1."""
+    rx, E = rnd(R, D, seed=1, scale=3.0), unit_rows(N, D, seed=2)
+    g = torch.Generator().manual_seed(3)
+    cand = torch.randint(0, N, (R, Cn), generator=g)
+    tgt = torch.randint(0, Cn, (R,), generator=g)
+    cand[0] = cand[0, 0]                    # a row of one repeated id: nll = ln Cn, zero gradient
+    want_nll, want_lse, want_dx = orc.candidate_ce(rx, E, cand, tgt)
+    table = ops.CatalogTable(E.to(DEV))
+    nll, lse, dx, tcol = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand.to(DEV), cand_target=tgt.to(DEV), want_target=True)
+    assert torch.equal(tcol.cpu(), tgt)
+    np.testing.assert_allclose(nll.cpu().double().numpy(), want_nll.numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(lse.cpu().double().numpy(), want_lse.numpy(), rtol=2e-6, atol=2e-6)
+    assert (dx.cpu().double() - want_dx).abs().max() <= 2e-6 * max(1.0, float(want_dx.abs().max()))
+    np.testing.assert_allclose(nll[0].item(), np.log(Cn), rtol=1e-6, atol=1e-6)
+    # forward only (no dx buffer), and the scaled direction
+    nll2, _, none, _ = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand.to(DEV), cand_target=tgt.to(DEV), want_dx=False)
+    assert none is None and torch.equal(nll2, nll)
+    dx3 = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand.to(DEV), cand_target=tgt.to(DEV), dx_scale=0.25)[2]
+    torch.testing.assert_close(dx3, dx * 0.25, rtol=1e-6, atol=1e-9)
+    # the autograd op: mean reduction, any upstream gradient; equal to the materialised route (K9 scores + dense CE)
+    rd = rx.to(DEV).requires_grad_(True)
+    loss = ops.candidate_ce(rd, table, cand=cand.to(DEV), cand_target=tgt.to(DEV))
+    (loss * 0.7).backward()
+    np.testing.assert_allclose(loss.item(), want_nll.mean().item(), rtol=2e-6)
+    assert (rd.grad.cpu().double() - want_dx * 0.7 / R).abs().max() <= 2e-6 * max(1.0, float(want_dx.abs().max())) / R
+    rm = rx.to(DEV).requires_grad_(True)
+    lm = ops.dense_ce(ops.candidate_scores(rm, E.to(DEV), cand.to(DEV)), tgt.to(DEV))
+    (lm * 0.7).backward()
+    np.testing.assert_allclose(loss.item(), lm.item(), rtol=2e-6)
+    torch.testing.assert_close(rd.grad, rm.grad, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("R,S,N,D,Cn,seed,off", [(40, 5, 60, 16, 50, 77, 10), (64, 10, 30011, 128, 1000, 13, 0),
+                                                 (12, 3, 3000, 64, 5000, 5, 7), (9, 1, 7, 32, 2049, 1, 1 << 33),
+                                                 (9, 2, 100003, 32, 2049, 2, 3)])
+def test_candidate_ce_fused_draws_the_documented_stream(ops, R, S, N, D, Cn, seed, off):
+    """cand == NULL: the kernel draws the sets itself - exactly pcvae_candidate_draw's sets (host restatement: tests/philox_ref.py +
+    the oracle's first-hit / overwrite rule), so the results are BITWISE those of the given-sets mode on the drawn ids; both
+    branches of the rule occur, hits beyond the first LDS batch included (Cn = 5000 / 2049); shards reproduce the whole batch."""
+    gen = torch.Generator().manual_seed(seed)
+    sl = torch.randint(0, N, (R, S), generator=gen)
+    rx, E = rnd(R * S, D, seed=1, scale=3.0), unit_rows(N, D, seed=2)
+    table = ops.CatalogTable(E.to(DEV))
+    want_raw = torch.from_numpy(philox_ref.candidate_raw(R * S, Cn, N, seed, off)).view(R, S, Cn)
+    wc, wt = orc.candidate_targets(sl, want_raw)
+    nll, lse, dx, tcol = ops.candidate_ce_raw(rx.to(DEV), table, Cn, sl.to(DEV).reshape(-1), seed, off, want_target=True)
+    assert torch.equal(tcol.cpu(), wt.reshape(-1))
+    if N < 40 * Cn:
+        assert int((wt > 0).sum()) > 0
+    if N > 50:
+        assert int((wt == 0).sum()) > 0
+    if Cn > 2048 and N == 3000:
+        assert int((wt >= 2048).sum()) > 0        # first hits that only the scan of the later batches finds
+    n2, l2, d2, _ = ops.candidate_ce_raw(rx.to(DEV), table, cand=wc.to(DEV), cand_target=wt.to(DEV))
+    assert torch.equal(nll, n2) and torch.equal(lse, l2) and torch.equal(dx, d2)
+    cd, td = ops.candidate_draw(sl.to(DEV), N, Cn, seed=seed, row_offset=off)
+    assert torch.equal(cd.cpu(), wc) and torch.equal(td.cpu(), wt)
+    want_nll, _, want_dx = orc.candidate_ce(rx, E, wc, wt)
+    np.testing.assert_allclose(nll.cpu().double().numpy(), want_nll.numpy(), rtol=2e-6, atol=2e-6)
+    assert (dx.cpu().double() - want_dx).abs().max() <= 2e-6 * max(1.0, float(want_dx.abs().max()))
+    # a shard of the rows, keyed by its global offset, reproduces its part bit for bit; another seed does not
+    lo = (R // 3) * S
+    a, b, c, _ = ops.candidate_ce_raw(rx[lo:].contiguous().to(DEV), table, Cn, sl.reshape(-1)[lo:].contiguous().to(DEV), seed, off + lo)
+    assert torch.equal(a, nll[lo:]) and torch.equal(b, lse[lo:]) and torch.equal(c, dx[lo:])
+    assert not torch.equal(ops.candidate_ce_raw(rx.to(DEV), table, Cn, sl.to(DEV).reshape(-1), seed + 1, off)[1], lse)
+
+
+def test_candidate_ce_fused_bad_ids_poison_their_row_only(ops):
+    """the reference raises an index error on an id outside the table; the kernel cannot raise: that row's outputs are NaN, every
+    other row is untouched, nothing is read out of bounds"""
+    R, N, D, Cn = 12, 50, 64, 33
+    rx, E = rnd(R, D, seed=1), unit_rows(N, D, seed=2)
+    g = torch.Generator().manual_seed(3)
+    cand = torch.randint(0, N, (R, Cn), generator=g)
+    tgt = torch.randint(0, Cn, (R,), generator=g)
+    table = ops.CatalogTable(E.to(DEV))
+    ref = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand.to(DEV), cand_target=tgt.to(DEV))
+    cand2, tgt2 = cand.clone(), tgt.clone()
+    cand2[2, 5], cand2[7, 0], tgt2[4], tgt2[9] = N, -1, Cn, -3
+    got = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand2.to(DEV), cand_target=tgt2.to(DEV))
+    badrows = torch.tensor([2, 4, 7, 9])
+    good = torch.ones(R, dtype=torch.bool)
+    good[badrows] = False
+    for a, b in zip(got[:3], ref[:3]):
+        assert torch.isnan(a.cpu()[badrows]).all() and torch.equal(a.cpu()[good], b.cpu()[good])
+    feat = torch.randint(0, N, (R,), generator=g)
+    feat[3] = N + 5      # drawn mode: a true item outside the catalog
+    d = ops.candidate_ce_raw(rx.to(DEV), table, Cn, feat.to(DEV), 1, 0)
+    assert torch.isnan(d[0].cpu()[3]) and torch.isnan(d[2].cpu()[3]).all() and torch.isfinite(d[0].cpu()[good & (torch.arange(R) != 3)]).all()
+    from pivotcvae_amd import _hip
+    rc = _hip.lib().pcvae_candidate_ce(_hip.ptr(rx.to(DEV)), R, _hip.ptr(table.weight), N, D, Cn, None, 0, 0, None, None,
+                                       _hip.ptr(torch.empty(R, device=DEV)), None, None, 1.0, None, _hip.stream())
+    assert rc == -1 and b"candidate_ce" in _hip.lib().pcvae_last_error()
+
+
 # ------------------------------------------------------------------------- argument validation
 def test_bad_arguments_are_rejected_before_launch(ops):
     from pivotcvae_amd import _hip
