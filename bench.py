@@ -64,13 +64,13 @@ def build_model(cfg, device, dtype):
     doc.weight.data = (torch.rand(N, D, device=device, generator=gen) * 2 - 1) * a  # env/response_model.py:29-31
     usr = torch.nn.Embedding(N_USER, D, device=device)
     usr.weight.data = (torch.rand(N_USER, D, device=device, generator=gen) * 2 - 1) * a
-    st = structs(S, D, cfg.get("model", "pivotcvae_gt_pi"))
+    st = structs(S, D, "listcvae" if cfg.get("model") == "listcvae" else "pivotcvae")
     if cfg.get("model") == "listcvae":
         from pivotcvae_amd.models.listcvae import UserListCVAEWithPrior
         m = UserListCVAEWithPrior(doc, usr, S, D, Z, S + 1, st["enc"], st["dec"], st["prior"], False, device)
     else:
-        m = pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"](doc, usr, S, D, Z, S + 1, st["enc"], st["psm"], st["scm"], st["prior"],
-                                                  False, device)
+        m = pa.PIVOTCVAE_MODELS[cfg.get("model", "pivotcvae_gt_pi")](doc, usr, S, D, Z, S + 1, st["enc"], st["psm"], st["scm"],
+                                                                    st["prior"], False, device)
     m.set_catalog_precision(dtype)
     return m, st
 
@@ -158,11 +158,15 @@ def gather_roofline(model, cfg, device, tables=4):
     tk = sorted(kt)[len(kt) // 2]   # the MEDIAN of the ten cold launches (one launch each): robust against the odd 23 us outlier
     t1, tb = ms["single"], ms["back_to_back"]
     bw = lambda t_ms: nbytes / (t_ms * 1e-3) / 1e9
-    return {"kernel": "gather_rows_vec4_kernel", "bound": "hbm", "achieved": bw(tk), "peak": 8000.0,
+    from pivotcvae_amd import _hip
+    gname = {0: "gather_rows_scalar_kernel", 1: "gather_rows_vec4_kernel", 2: "gather_rows_coal_kernel"}[
+        _hip.lib().pcvae_gather_rows_variant(D, 1, D)]   # the kernel this width launches, as rocprofv3's trace names it
+    return {"kernel": gname, "bound": "hbm", "achieved": bw(tk), "peak": 8000.0,
             "unit": "GB/s", "frac": bw(tk) / 8000.0, "bytes_per_launch": nbytes, "us_per_launch": tk * 1e3,
             "rows": n_idx, "timed_over": "ONE launch at a time, cold caches, HIP events attached to the dispatch (hipExtLaunchKernelGGL start / "
                                          "stop events: the kernel's own begin / end timestamps, as in rocprofv3's kernel trace); "
-                                         "median of 10 such launches",
+                                         "median of 10 such launches (rounds 1-3 reported the MEAN, kept as frac_of_mean; the median "
+                                         "is robust against the odd 23 us outlier)",
             "us_per_launch_mean": tk_mean * 1e3, "us_per_launch_min": min(kt) * 1e3, "us_per_launch_max": max(kt) * 1e3,
             "frac_of_mean": bw(tk_mean) / 8000.0,
             "event_pair_around_one_launch": {"us_per_launch": t1 * 1e3, "achieved": bw(t1), "frac": bw(t1) / 8000.0,
@@ -471,6 +475,12 @@ class StepTimer:
             pair[1].record()
             events.append(pair)
 
+        pivot_events = []
+
+        def pivot_end(pair):
+            pair[1].record()
+            pivot_events.append(pair)
+
         trace = [] if os.environ.get("PCVAE_BENCH_TRACE_ELBO") == "1" else None   # debugging aid: every step's terms on stderr
         for _ in range(warmup):
             if trace is not None:
@@ -494,6 +504,7 @@ class StepTimer:
             extra = any_graphed
         if not graphed:
             ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
+            ops.PIVOT_TIMING = (hook_begin, pivot_end)
         self.sync_all()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -506,6 +517,7 @@ class StepTimer:
             for i, t in enumerate(trace):
                 print(f"[elbo trace] step {i}: " + " ".join(f"{float(v):.6f}" for v in t), file=sys.stderr, flush=True)
         ops.CATALOG_CE_TIMING = None
+        ops.PIVOT_TIMING = None
         if self.use_dist:
             t = torch.tensor([dt], device=self.device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -523,8 +535,10 @@ class StepTimer:
             ops.CATALOG_CE_TIMING = None
             tr.capture_graph = was
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+        # the pivot-selection kernel of a pt / spt / sgt train step (catalog argmax / Gumbel-max sampler), per step
+        pivot_ms = sum(a.elapsed_time(b) for a, b in pivot_events) / max(steps, 1) if pivot_events else None
         graphed = graphed and tr._graph is not None and tr.capture_failed is None   # what actually happened, for the line's label
-        return dict(dt=dt, steps=steps, kern_ms=kern_ms, graphed=graphed, elbo=(loss, rec, kld))
+        return dict(dt=dt, steps=steps, kern_ms=kern_ms, pivot_ms=pivot_ms, graphed=graphed, elbo=(loss, rec, kld))
 
 
 # what the catalog contraction computes in, per --dtype: (json dtype, MFMA peak it is priced against, MFMAs issued per
@@ -570,6 +584,16 @@ def sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic=None):
                           f"{requested / 1e9:.1f} GB are requested out of a {table / 1e9:.2f} GB table"}
 
 
+def candidate_roofline(R_local, N, D, Cn, kern_ms, traffic=None):
+    """the fused candidate-set kernel is the same uniformly random row gather as the sparse kernel - R (Cn + 1) rows of 4 D bytes
+    requested (Cn candidates + the target row once more for the gradient) - priced on the same cache + HBM gather-time model"""
+    out = sparse_roofline(f"candidate_ce_kernel<{D}, true>", R_local, N, D, kern_ms, Cn + 1, traffic)
+    out["replaces"] = ("candidate_draw -> [R, Cn] int64 ids -> candidate_scores_kernel -> [R, Cn] p -> dense_ce_kernel -> [R, Cn] dp -> "
+                       "candidate_scores_bwd_kernel (the reference: randint on the host + embedding [R, Cn, D] + bmm + CrossEntropyLoss "
+                       "+ autograd); none of those arrays exists here")
+    return out
+
+
 def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None, traffic=None):
     if sparse_kept is not None:
         return sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic)
@@ -587,6 +611,59 @@ def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None, traffi
         # the roof of THIS algorithm on the pipe it runs on: the dense bf16 peak divided by the MFMAs one multiply-add costs
         out["algorithm_peak_TFLOPs"] = peak / mult
         out["frac_of_algorithm_peak"] = ach * mult / peak
+    return out
+
+
+def pivot_block(cfg, B_local, pivot_ms, step_ms):
+    """the pivot-selection kernel of a step (pt: catalog argmax; spt / sgt: Gumbel-max sampler over sigmoid scores): 2 B N D
+    algorithmic flops per step against the dense peak of the pipe it runs on"""
+    N, D = cfg["N"], cfg["D"]
+    flops = 2.0 * B_local * N * D
+    tf = flops / (pivot_ms * 1e-3) / 1e12 if pivot_ms else 0.0
+    return {"ms_per_step": pivot_ms, "share_of_step": pivot_ms / step_ms if step_ms else None, "algorithmic_TFLOPs": tf,
+            "frac_of_bf16_peak": tf / PEAK_TFLOPS["bf16"], "frac_of_f32_mfma_peak": tf / PEAK_TFLOPS["f32"],
+            "algorithmic_flops_per_step": flops}
+
+
+def pivot_rules_block(cfg, device, dtype, mlp, gt_pi_ms):
+    """The paper's variants (models/pivotcvae.py:321-455, settings.py:36-42) at this config, one model each from the registry:
+    train step (3 timed steps after 2 warm-up, eager) with the pivot kernel's own time, and generation (recommend(return_item))
+    for the sampled inference rule."""
+    from pivotcvae_amd.train_generative import Trainer
+    out = {"gt_pi_ms_per_step": gt_pi_ms}
+    B, S = cfg["B"], cfg["S"]
+    for key in ("pivotcvae_sgt_pi", "pivotcvae_spt_pi", "pivotcvae_pt_pi", "pivotcvae_gt_spi"):
+        c2 = dict(cfg, model=key)
+        m, _ = build_model(c2, device, dtype)
+        m.set_mlp_precision(mlp)
+        blk = {"train_rule": m.TRAIN_RULE, "infer_rule": m.INFER_RULE}
+        if m.TRAIN_RULE != "gt":
+            tr = Trainer(m, lr=LR, beta=BETA, capture_graph=False)
+            s, r, u = synthetic_batch(c2, B, device)
+            v = StepTimer(tr, (s, r, u), B, 0, False, device).run(3, 2)
+            ms = v["dt"] / v["steps"] * 1e3
+            blk["train"] = {"value": B / (ms * 1e-3), "unit": "slates/s", "ms_per_step": ms, "vs_gt_pi_step": ms / gt_pi_ms,
+                            "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
+                            "pivot_kernel": pivot_block(c2, B, v["pivot_ms"], ms) if v["pivot_ms"] else None}
+            del tr
+        if m.INFER_RULE == "spi":
+            g = torch.Generator(device=device).manual_seed(7)
+            u = torch.randint(0, N_USER, (B, 1), device=device, generator=g)
+            ctx = (torch.rand(B, S, device=device, generator=g) < 0.5).float()
+            ev = []
+            with torch.no_grad():
+                m.recommend(ctx, u, return_item=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    m.recommend(ctx, u, return_item=True)
+                torch.cuda.synchronize()
+                dtg = (time.perf_counter() - t0) / 3
+            blk["generate"] = {"value": B / dtg, "unit": "slates/s", "ms_per_batch": dtg * 1e3,
+                               "note": "pivot by Categorical(sigmoid(scores)) (Gumbel-max kernel), the S slots by exact greedy argmax"}
+        out[key] = blk
+        del m
+        torch.cuda.empty_cache()
     return out
 
 
@@ -673,6 +750,12 @@ def main():
                     help="arithmetic of the MLP GEMMs of the train step.  Default: bf16x3 where the catalog contraction runs in bf16x3 "
                          "or bf16 (the whole step then computes on the bf16 matrix cores), exact f32 MFMA with --dtype f32 / bf16x6")
     ap.add_argument("--n_neg", type=int, default=None, help="default: N (full-catalog softmax)")
+    ap.add_argument("--n_candidate", type=int, default=None,
+                    help="time the reference's DEFAULT training mode instead (no --mask_train: candidate sets of this many ids per "
+                         "slot, data_loader.py:46-58, train_generative.py:52-57) - the fused candidate kernel")
+    ap.add_argument("--model", default=None,
+                    help="registry key of the model (any of PIVOTCVAE_MODELS: pivotcvae_{gt,pt,spt,sgt}_{pi,spi}); default: the "
+                         "config's (pivotcvae_gt_pi; config 1: listcvae)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the mlp_roofline / gather_roofline / generate / eval blocks")
     ap.add_argument("--no-variants", action="store_true", help="skip the `variants` blocks (other arithmetics, n_neg = 1000)")
@@ -726,6 +809,13 @@ def main():
     cfg = dict(CONFIGS[args.config])
     if args.global_batch:
         cfg["B"] = args.global_batch
+    if args.model:
+        import pivotcvae_amd as pa
+        if args.model != "listcvae" and args.model not in pa.PIVOTCVAE_MODELS:
+            raise SystemExit(f"--model {args.model}: one of listcvae, " + ", ".join(sorted(pa.PIVOTCVAE_MODELS)))
+        cfg["model"] = args.model
+    if args.n_candidate is not None and args.n_neg is not None:
+        raise SystemExit("--n_candidate (candidate sets) and --n_neg (mask-train) are the two branches of get_gen_loss: pick one")
     N, S, D, B = cfg["N"], cfg["S"], cfg["D"], cfg["B"]
     if B % world:
         raise SystemExit("global batch not divisible by the number of GPUs")
@@ -748,7 +838,8 @@ def main():
     use_graph = (not args.no_graph) and (B // world <= 4096 or args.graph)
     # resident_batch: every step of the timed region passes the SAME unmodified tensors (inputs resident in HBM, as the contract
     # says), so a graph replay does not re-copy them into its static buffers
-    trainer = Trainer(model, lr=LR, beta=BETA, n_neg=args.n_neg, capture_graph=use_graph, resident_batch=True)
+    trainer = Trainer(model, lr=LR, beta=BETA, n_neg=args.n_neg, capture_graph=use_graph, resident_batch=True,
+                      n_candidate=args.n_candidate)
     s, r, u = synthetic_batch(cfg, B, device)
     (s, r, u), lo = trainer.shard(s, r, u)
     s, r, u = s.contiguous(), r.contiguous(), u.contiguous()
@@ -759,9 +850,15 @@ def main():
     dt, kern_ms, graphed = res["dt"], res["kern_ms"], res["graphed"]
     loss, rec, kld = res["elbo"]
     sparse = args.n_neg is not None and ops.sparse_ce_applies(args.n_neg / N, N)
-    roof = roofline_block(kernel_name(R_local, N, D, args.dtype) if not sparse else "catalog_ce_sparse_kernel",
-                          R_local, N, D, args.dtype, kern_ms, sparse_kept=(args.n_neg + 1) if sparse else None,
-                          traffic=committed_traffic(f"config{args.config}_nneg{args.n_neg}_gpus{world}") if sparse else None)
+    cand_mode = args.n_candidate is not None
+    if cand_mode:
+        roof = candidate_roofline(R_local, N, D, args.n_candidate, kern_ms,
+                                  committed_traffic(f"config{args.config}_cand{args.n_candidate}_gpus{world}"))
+        sparse = True
+    else:
+        roof = roofline_block(kernel_name(R_local, N, D, args.dtype) if not sparse else "catalog_ce_sparse_kernel",
+                              R_local, N, D, args.dtype, kern_ms, sparse_kept=(args.n_neg + 1) if sparse else None,
+                              traffic=committed_traffic(f"config{args.config}_nneg{args.n_neg}_gpus{world}") if sparse else None)
     if not sparse:
         roof["kernel"] += " (events also span its row-bound prologue and merge kernels, <1% together)"
         roof["traffic"] = committed_traffic(f"config{args.config}_{args.dtype}_gpus{world}")
@@ -775,8 +872,10 @@ def main():
         "value": B * args.steps / dt, "unit": "slates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": ARITH[args.dtype][0], "data": "synthetic",
-        "config": {"workload": f"{'ListCVAE' if cfg.get('model') == 'listcvae' else 'PivotCVAE gt_pi'} train step (fwd+bwd+Adam), catalog N={N} slate K={S} emb D={D} "
-                               f"global batch B={B}, full-catalog softmax" + ("" if args.n_neg is None else f" n_neg={args.n_neg}"),
+        "config": {"workload": f"{'ListCVAE' if cfg.get('model') == 'listcvae' else 'PivotCVAE ' + cfg.get('model', 'pivotcvae_gt_pi')[10:]} train step (fwd+bwd+Adam), catalog N={N} slate K={S} emb D={D} "
+                               f"global batch B={B}, " + (f"candidate sets of {args.n_candidate} ids per slot drawn in-kernel (the reference's default mode: no --mask_train)"
+                                                          if cand_mode else "full-catalog softmax" + ("" if args.n_neg is None else f" n_neg={args.n_neg}")),
+                   "model": cfg.get("model", "pivotcvae_gt_pi"),
                    "global_batch": B, "per_gpu_batch": B // world, "parallelism": f"dp{world}",
                    "rccl_ranks": dist.get_world_size() if use_dist else 1,
                    **({"rehearsal": "all ranks on ONE GPU, gloo collectives: checks the N > 1 path, not its speed"} if rehearsal else {}),
@@ -789,6 +888,8 @@ def main():
         "elbo": {"loss": loss.item(), "recLoss": rec.item(), "KLD": kld.item()},
         "roofline": roof,
     }
+    if res.get("pivot_ms") is not None:
+        out["pivot_kernel"] = pivot_block(cfg, B // world, res["pivot_ms"], dt / args.steps * 1e3)
     single = rank == 0 and world == 1
     if single and not args.no_variants:
         # the same workload in the other arithmetics and in the reference's default masked mode (n_neg = 1000), each with its
@@ -799,7 +900,7 @@ def main():
         for dt_name in ("f32", "bf16x6", "bf16x3", "bf16"):
             if dt_name == args.dtype or (dt_name == "bf16x3" and ops.x3_width(D) is None) or \
                     (dt_name == "bf16x6" and (ops.x6_width(D) is None or D < 64)) or \
-                    (dt_name == "bf16" and D not in ops.BF16_DIMS) or args.n_neg is not None:
+                    (dt_name == "bf16" and D not in ops.BF16_DIMS) or args.n_neg is not None or cand_mode:
                 continue
             if dt_name == "f32" and 4.0 * R_local * N * D > 2e14:   # config 5 in exact f32: minutes per step
                 continue
@@ -819,12 +920,27 @@ def main():
                                       "roofline": roofline_block("catalog_ce_sparse_kernel", R_local, N, D, "f32", v["kern_ms"],
                                                                  sparse_kept=1001,
                                                                  traffic=committed_traffic(f"config{args.config}_nneg1000_gpus{world}"))}
+        if args.n_neg is None and not cand_mode and N >= 100_000:
+            # the reference's DEFAULT mode (train_generative.py:270-274: candidate sets unless --mask_train; my_utils.py:169
+            # --nneg 1000): ONE fused launch per step draws the sets, gathers, scores, takes the CE and the gradient
+            for cn in (1000, 50):
+                trainer.n_candidate = cn
+                v = timer.run(3, 2)
+                trainer.n_candidate = None
+                variants[f"candidates_nneg{cn}"] = {
+                    "value": B * v["steps"] / v["dt"], "unit": "slates/s", "ms_per_step": v["dt"] / v["steps"] * 1e3, "dtype": "f32",
+                    "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
+                    "roofline": candidate_roofline(R_local, N, D, cn, v["kern_ms"],
+                                                   committed_traffic(f"config{args.config}_cand{cn}_gpus{world}"))}
         trainer.capture_graph = was_graph
         out["variants"] = variants
     if single and not args.no_variants and cfg.get("model") != "listcvae" and N * D <= 2.6e8:
         # what "the reference's arithmetic" means in numbers: every arithmetic of this line against fp64, measured live
         out["arithmetic_error_vs_fp64"] = arithmetic_error_vs_fp64(model, cfg, r, u, device)
-    if single and not args.no_cpu_baseline:
+    if single and not args.no_variants and not args.no_extras and cfg.get("model", "pivotcvae_gt_pi") == "pivotcvae_gt_pi" \
+            and args.n_neg is None and not cand_mode and N >= 100_000:
+        out["pivot_rules"] = pivot_rules_block(cfg, device, args.dtype, args.mlp, out["ms_per_step"])
+    if single and not args.no_cpu_baseline and cfg.get("model", "pivotcvae_gt_pi") in ("pivotcvae_gt_pi", "listcvae") and not cand_mode:
         base, parity = cpu_baseline_and_parity(model, st, cfg, args.dtype)
         out["cpu_baseline"] = base
         out["parity"] = parity

@@ -63,6 +63,9 @@ const char* pcvae_last_error(void);
  * ------------------------------------------------------------------------------------------- */
 int pcvae_gather_rows(const float* table, int64_t n_rows, int D, const int64_t* idx, int64_t n_idx,
                       int group, float* out, int64_t out_ld, pcvae_stream_t stream);
+/* the kernel the call above launches for a shape (table / out 16-byte aligned), for labelling measurements with the name a
+ * kernel trace shows: 0 = gather_rows_scalar_kernel, 1 = gather_rows_vec4_kernel, 2 = gather_rows_coal_kernel (D = 64 / 128 / 256) */
+int pcvae_gather_rows_variant(int D, int group, int64_t out_ld);
 
 /* K2  click-count one-hot condition         models/cvae.py:85-92
  *     out[b * out_ld + c] = (c == sum_{j < ncols} r[b, j]),  c in [0, S].  r is [B, ncols]: ncols is the slate size S in

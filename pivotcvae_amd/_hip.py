@@ -36,6 +36,7 @@ SIGNATURES = {
     "pcvae_abi_version": [],
     "pcvae_last_error": [],
     "pcvae_gather_rows": [_P, _L, _I, _P, _L, _I, _P, _L, _P],
+    "pcvae_gather_rows_variant": [_I, _I, _L],
     "pcvae_condition": [_P, _L, _I, _I, _P, _L, _P],
     "pcvae_copy2d": [_P, _L, _P, _L, _L, _I, _P],
     "pcvae_concat": [_P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _I, _P, _L, _L, _P],

@@ -164,6 +164,18 @@ extern "C" int pcvae_gather_rows(const float* table, int64_t n_rows, int D, cons
     return check_launch("gather_rows");
 }
 
+// which kernel pcvae_gather_rows launches for a shape with 16-byte aligned table / out (bench.py and tools/ label their
+// measurements with the name rocprofv3's kernel trace shows): 0 = gather_rows_scalar_kernel, 1 = gather_rows_vec4_kernel,
+// 2 = gather_rows_coal_kernel
+extern "C" int pcvae_gather_rows_variant(int D, int group, int64_t out_ld) {
+    if (D <= 0 || D % 4 != 0 || out_ld % 4 != 0) return 0;
+    const int chunks = D / 4;
+    int lpr = 1;
+    while (lpr < chunks && lpr < 64) lpr <<= 1;
+    (void)group;
+    return (GATHER_COAL && GATHER_UNROLL == 16 && chunks == lpr && (lpr == 16 || lpr == 32 || lpr == 64)) ? 2 : 1;
+}
+
 // =============================================================================================
 // K2: condition one-hot
 // =============================================================================================

@@ -965,6 +965,8 @@ class CatalogTable:
 _ws_cache = {}
 # bench.py installs (begin, end) callables here to bracket the dominant kernel with HIP events
 CATALOG_CE_TIMING = None
+# ... and here around the pivot-selection kernels (catalog_argmax / catalog_sample: the pt / spt / sgt / spi rules)
+PIVOT_TIMING = None
 
 
 _ws_holder = None   # set by workspace_holder(): a dict that owns the scratch buffers instead of the module cache
@@ -1226,8 +1228,12 @@ def catalog_argmax(x, table, prec=PREC_F32, return_best=False, screened=None):
     best = torch.empty(R, dtype=F32, device=x.device) if return_best else None
     nbytes = lib().pcvae_catalog_ws_bytes(R, N, D, 0)
     ws = _workspace(x.device, nbytes)
+    timing = PIVOT_TIMING
+    tok = timing[0]() if timing else None
     check(lib().pcvae_catalog_argmax(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, mode, float(emax), ptr(idx), ptr(best), ptr(ws),
                                      ws.numel(), stream()), "catalog_argmax")
+    if timing:
+        timing[1](tok)
     return (idx, best) if return_best else idx
 
 
@@ -1243,8 +1249,12 @@ def catalog_sample(x, table, seed=0, row_offset=0, prec=PREC_F32):
     E_lo = None
     idx = torch.empty(R, dtype=torch.int64, device=x.device)
     ws = _workspace(x.device, lib().pcvae_catalog_ws_bytes(R, N, D, 0))
+    timing = PIVOT_TIMING
+    tok = timing[0]() if timing else None
     check(lib().pcvae_catalog_sample(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, PREC_F32, int(seed), int(row_offset),
                                      ptr(idx), ptr(ws), ws.numel(), stream()), "catalog_sample")
+    if timing:
+        timing[1](tok)
     return idx
 
 

@@ -198,6 +198,36 @@ def test_masked_mode_and_sampled_pivots_under_sharding(W, tile_mode):
                 grads_close(res["single"][0], gW, g1, tol=tile_mode)
 
 
+@pytest.mark.parametrize("W", [2, 8])
+def test_candidate_mode_and_sampled_pivots_under_sharding(W, tile_mode):
+    """the reference's DEFAULT mode (candidate sets, train_generative.py:52-57) through the fused kernel - sets drawn in-kernel from
+    a stream keyed by (step, GLOBAL slot) - alone and together with a sampled-pivot rule (spt: the PSM output's Gumbel-max sample,
+    keyed by GLOBAL slate index): the sharded job reproduces the single-process one, and two steps draw different sets"""
+    from pivotcvae_amd.train_generative import Trainer
+    N, S, D, B = 50021, 10, 128, 256
+    s, r, u = batch(N, S, B, seed=3)
+    for variant in ("pivotcvae_gt_pi", "pivotcvae_spt_pi"):
+        res = {}
+        for mode in ("single", "sharded"):
+            m = make_model(N, S, D, "f32", variant=variant)
+            m.rng_seed = 99
+            tr = Trainer(m, lr=3e-4, beta=0.001, n_candidate=300, world_size=W if mode == "sharded" else None)
+            assert not tr.capture_graph
+            out = []
+            for _ in range(2):
+                st, g, e = simulated_step(tr, W, s, r, u) if mode == "sharded" else single_step(tr, s, r, u)
+                out.append(([float(x) for x in st], g, e))
+            res[mode] = (tr, out)
+        for k in range(2):
+            st1, g1, e1 = res["single"][1][k]
+            stW, gW, eW = res["sharded"][1][k]
+            assert torch.equal(e1, eW)
+            np.testing.assert_allclose(stW, st1, rtol=2e-6)
+            assert 0.5 * np.log(300) < st1[1] < 1.5 * np.log(300)     # a CE over 300 candidates, not over the catalog
+            if k == 0:
+                grads_close(res["single"][0], gW, g1, tol=tile_mode)
+
+
 def test_in_kernel_streams_are_bitwise_independent_of_the_sharding():
     """each stream on its own, same inputs: a shard's draws == the corresponding rows of the whole batch's draws, bit for bit"""
     from pivotcvae_amd import ops
@@ -227,6 +257,13 @@ def test_in_kernel_streams_are_bitwise_independent_of_the_sharding():
         sl = slice(w * per, (w + 1) * per)
         c2, t2 = ops.candidate_draw(s[sl].contiguous(), N, 50, seed=13, row_offset=w * per * S)
         assert torch.equal(c2, cand[sl]) and torch.equal(t2, ctg[sl])
+    # ... and the fused candidate kernel that draws them itself: per-row nll / lse / dx bitwise a function of (seed, global slot)
+    cn, cl, cx, ct = ops.candidate_ce_raw(rx, table, 50, tgt, 13, 0, want_target=True)
+    assert torch.equal(ct.view(B, S), ctg)
+    for w in range(W):
+        sl = slice(w * per * S, (w + 1) * per * S)
+        a, b, c, _ = ops.candidate_ce_raw(rx[sl].contiguous(), table, 50, tgt[sl].contiguous(), 13, w * per * S)
+        assert torch.equal(a, cn[sl]) and torch.equal(b, cl[sl]) and torch.equal(c, cx[sl])
     # sampled pivots (Gumbel-max over sigmoid scores)
     q = rx[:B].contiguous()
     ids = ops.catalog_sample(q, table, seed=17, row_offset=40)

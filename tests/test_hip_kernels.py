@@ -704,7 +704,8 @@ def test_candidate_ce_fused_given_sets(ops, R, N, D, Cn):
     assert torch.equal(tcol.cpu(), tgt)
     np.testing.assert_allclose(nll.cpu().double().numpy(), want_nll.numpy(), rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(lse.cpu().double().numpy(), want_lse.numpy(), rtol=2e-6, atol=2e-6)
-    assert (dx.cpu().double() - want_dx).abs().max() <= 2e-6 * max(1.0, float(want_dx.abs().max()))
+    tol = max(2e-6, 1e-7 * Cn ** 0.5)       # fp32 accumulation of Cn terms per row (the reference's bmm + softmax are fp32 too)
+    assert (dx.cpu().double() - want_dx).abs().max() <= tol * max(1.0, float(want_dx.abs().max()))
     np.testing.assert_allclose(nll[0].item(), np.log(Cn), rtol=1e-6, atol=1e-6)
     # forward only (no dx buffer), and the scaled direction
     nll2, _, none, _ = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand.to(DEV), cand_target=tgt.to(DEV), want_dx=False)
@@ -716,7 +717,7 @@ def test_candidate_ce_fused_given_sets(ops, R, N, D, Cn):
     loss = ops.candidate_ce(rd, table, cand=cand.to(DEV), cand_target=tgt.to(DEV))
     (loss * 0.7).backward()
     np.testing.assert_allclose(loss.item(), want_nll.mean().item(), rtol=2e-6)
-    assert (rd.grad.cpu().double() - want_dx * 0.7 / R).abs().max() <= 2e-6 * max(1.0, float(want_dx.abs().max())) / R
+    assert (rd.grad.cpu().double() - want_dx * 0.7 / R).abs().max() <= tol * max(1.0, float(want_dx.abs().max())) / R
     rm = rx.to(DEV).requires_grad_(True)
     lm = ops.dense_ce(ops.candidate_scores(rm, E.to(DEV), cand.to(DEV)), tgt.to(DEV))
     (lm * 0.7).backward()
@@ -751,7 +752,7 @@ def test_candidate_ce_fused_draws_the_documented_stream(ops, R, S, N, D, Cn, see
     assert torch.equal(cd.cpu(), wc) and torch.equal(td.cpu(), wt)
     want_nll, _, want_dx = orc.candidate_ce(rx, E, wc, wt)
     np.testing.assert_allclose(nll.cpu().double().numpy(), want_nll.numpy(), rtol=2e-6, atol=2e-6)
-    assert (dx.cpu().double() - want_dx).abs().max() <= 2e-6 * max(1.0, float(want_dx.abs().max()))
+    assert (dx.cpu().double() - want_dx).abs().max() <= max(2e-6, 1e-7 * Cn ** 0.5) * max(1.0, float(want_dx.abs().max()))
     # a shard of the rows, keyed by its global offset, reproduces its part bit for bit; another seed does not
     lo = (R // 3) * S
     a, b, c, _ = ops.candidate_ce_raw(rx[lo:].contiguous().to(DEV), table, Cn, sl.reshape(-1)[lo:].contiguous().to(DEV), seed, off + lo)
