@@ -722,7 +722,7 @@ def test_candidate_ce_fused_given_sets(ops, R, N, D, Cn):
     lm = ops.dense_ce(ops.candidate_scores(rm, E.to(DEV), cand.to(DEV)), tgt.to(DEV))
     (lm * 0.7).backward()
     np.testing.assert_allclose(loss.item(), lm.item(), rtol=2e-6)
-    torch.testing.assert_close(rd.grad, rm.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(rd.grad, rm.grad, rtol=1e-4, atol=2 * tol / R)   # (row 0: both routes hold rounding noise around 0)
 
 
 @pytest.mark.parametrize("R,S,N,D,Cn,seed,off", [(40, 5, 60, 16, 50, 77, 10), (64, 10, 30011, 128, 1000, 13, 0),
