@@ -279,10 +279,14 @@ int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E, const voi
                             size_t ws_bytes, pcvae_stream_t stream);
 
 /* K10 sampled pivot                                     models/pivotcvae.py:349-351, 371-373
- *     idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) over the whole catalog, drawn with the Gumbel-max trick
- *     (argmax_n log sigmoid(s_n) - log(-log u_n), u_n = Philox(seed, row_offset + r, n)); the reference's
- *     torch.multinomial stream cannot be matched, parity is distributional (tests) or by feeding the
- *     recorded draw back in on the host side.                                                       */
+ *     idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) over the whole catalog.  Drawn by rejection sampling - propose n uniform in [0, N),
+ *     accept with probability sigmoid(s_n) <= 1: exactly that categorical, for ~1 / mean sigmoid dot products per row instead of the
+ *     [R, N] score matrix the reference hands to torch.multinomial.  Proposal k of row r = Philox(seed, row_offset + r, k, "RJCT"):
+ *     n_k = (x << 32 | y) mod N, u_k = (z + 0.5) 2^-32; idx[r] = n_k of the lowest k with u_k < sigmoid(s) (s = exact fp32 fmaf dot
+ *     product of the fp32 table row: E = [N, D] fp32, prec = PCVAE_PREC_F32, E_lo unused).  A row that rejects 4096 proposals is
+ *     drawn by Gumbel-max over the whole catalog instead (argmax_n log sigmoid(s_n) - log(-log u_n), u_n = Philox(seed, row, n)).
+ *     The reference's torch.multinomial stream cannot be matched: parity is distributional (tests) or by feeding the recorded
+ *     draw back in on the host side.                                                                                          */
 int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
                          uint64_t seed, uint64_t row_offset, int64_t* idx, void* ws, size_t ws_bytes,
                          pcvae_stream_t stream);

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libpcvae_hip.so")
-SOURCES = ["error.cpp", "elementwise.hip", "gemm_f32.hip", "catalog_f32.hip", "catalog_bf16.hip", "catalog_sparse.hip", "candidate_ce.hip",
+SOURCES = ["error.cpp", "elementwise.hip", "gemm_f32.hip", "catalog_f32.hip", "catalog_bf16.hip", "catalog_sparse.hip", "candidate_ce.hip", "catalog_sample.hip",
            "catalog_api.cpp"]
 HEADERS = ["common.h", "catalog_plan.h", "catalog_x3.h", os.path.join("..", "..", "include", "pcvae.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]

@@ -38,13 +38,6 @@ struct CandParams {
     int64_t* tgt_out;            // [R] or null: the target column the row used
 };
 
-// x % n for n >= 1 (q underestimates floor(x / n) by at most 2)
-__device__ __forceinline__ uint64_t mod_magic(uint64_t x, uint64_t n, uint64_t magic) {
-    uint64_t r = x - __umul64hi(x, magic) * n;
-    while (r >= n) r -= n;
-    return r;
-}
-
 __device__ __forceinline__ void cc_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();

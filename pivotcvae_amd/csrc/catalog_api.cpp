@@ -13,7 +13,7 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
         const CatalogPlan pl = catalog_plan(R, N, D, prec);
         const size_t rows = (size_t)pl.nsplit * (size_t)R;
         const size_t ce = rows * 2 * sizeof(float) + (want_dx ? rows * (size_t)D * sizeof(float) : 0);
-        const size_t am = (rows + 1) * sizeof(float) + rows * sizeof(int64_t) + 16;
+        const size_t am = (rows + 2) * sizeof(float) + rows * sizeof(int64_t) + 32 + (size_t)R;   // (+ the sampler's per-row flags)
         need = std::max(need, std::max(ce, am) + (size_t)pl.nrb + 64);
     }
     need = std::max(need, (size_t)R * (8 + 4 + 4 + 64 * 4) + 64);  // screened argmax: keys, thresholds, <= 64 partial maxima
@@ -23,9 +23,19 @@ extern "C" size_t pcvae_catalog_ws_bytes(int64_t R, int64_t N, int D, int want_d
 
 // bf16x3: its own partials (always with U), the row-block flags, then the f32 kernel's partials for flagged row blocks
 size_t pcvae::catalog_x3_ws_bytes(int64_t R, int64_t N, int D) {
-    const CatalogPlan px = catalog_plan(R, N, D, PCVAE_PREC_BF16X3), pf = catalog_plan(R, N, D, PCVAE_PREC_F32);
-    const size_t rx = (size_t)px.nsplit * (size_t)R, rf = (size_t)pf.nsplit * (size_t)R;
-    return rx * (2 + (size_t)D) * sizeof(float) + (((size_t)px.nrb + 255) / 256) * 256 + rf * (2 + (size_t)D) * sizeof(float) + 64;
+    // bf16x3 and bf16x6 lay their scratch out from their OWN plans; the two agree by default but not under PCVAE_RANGE_MB (a
+    // table row is 4 D against 6 D bytes of stream): one answer that covers both
+    const CatalogPlan pf = catalog_plan(R, N, D, PCVAE_PREC_F32);
+    const size_t rf = (size_t)pf.nsplit * (size_t)R;
+    size_t need = 0;
+    for (int prec : {PCVAE_PREC_BF16X3, PCVAE_PREC_BF16X6}) {
+        if (prec == PCVAE_PREC_BF16X6 && D != 128) continue;
+        const CatalogPlan px = catalog_plan(R, N, D, prec);
+        const size_t rx = (size_t)px.nsplit * (size_t)R;
+        need = std::max(need, rx * (2 + (size_t)D) * sizeof(float) + (((size_t)px.nrb + 255) / 256) * 256 +
+                                  rf * (2 + (size_t)D) * sizeof(float) + 64);
+    }
+    return need;
 }
 
 extern "C" int pcvae_catalog_ce_variant(int64_t R, int64_t N, int D, int prec) {
@@ -125,5 +135,23 @@ extern "C" int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, co
 extern "C" int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
                                     int prec, uint64_t seed, uint64_t row_offset, int64_t* idx, void* ws,
                                     size_t ws_bytes, pcvae_stream_t stream) {
-    return argmax_common(x, R, E, E_lo, N, D, prec, 0.f, true, seed, row_offset, idx, nullptr, ws, ws_bytes, stream);
+    PCVAE_REQUIRE(x && E && idx && ws, "catalog_sample: null pointer");
+    PCVAE_REQUIRE(R > 0 && N > 0, "catalog_sample: empty problem R=%lld N=%lld", (long long)R, (long long)N);
+    PCVAE_REQUIRE(supported_d(D), "catalog_sample: unsupported D=%d (16, 32, 64, 128, 256)", D);
+    PCVAE_REQUIRE(prec == PCVAE_PREC_F32, "catalog_sample: scores are exact fp32 (E = the fp32 table); precision mode %d is not one "
+                  "of its modes", prec);
+    PCVAE_REQUIRE(((uintptr_t)x % 16 == 0) && ((uintptr_t)E % 16 == 0) && ((uintptr_t)ws % 16 == 0),
+                  "catalog_sample: x/E/ws must be 16-byte aligned");
+    if (ws_bytes < pcvae_catalog_ws_bytes(R, N, D, 0)) {
+        set_error("catalog_sample: workspace %zu < %zu bytes", ws_bytes, pcvae_catalog_ws_bytes(R, N, D, 0));
+        return PCVAE_EWORKSPACE;
+    }
+    (void)E_lo;
+    // 1. rejection sampling: a handful of dot products per row; 2. rows that rejected every proposal (flagged, practically never):
+    //    the exact Gumbel-max kernel over the whole catalog - its workgroups leave at once when none of their rows is flagged
+    uint8_t* unres = reinterpret_cast<uint8_t*>(ws) + catalog_sample_unres_offset(R, N, D);
+    const float* Ef = reinterpret_cast<const float*>(E);
+    int rc = catalog_sample_reject(x, R, Ef, N, D, seed, row_offset, idx, unres, as_stream(stream));
+    if (rc != PCVAE_OK) return rc;
+    return catalog_argmax_f32(x, R, Ef, N, D, true, seed, row_offset, idx, nullptr, ws, as_stream(stream), unres);
 }

@@ -1481,22 +1481,12 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
             constexpr int CT = D == 256 ? PIPE_CT256 : 4;
             if (catalog_bf16_pipelined(D, p.tiles_per_split)) {
                 constexpr int lds_pipe = PipeGeo<D, CT>::NB * 16384;
-                static bool attr_set3 = false;
-                if (!attr_set3) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_pipe_kernel<D, CT>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
-                    attr_set3 = true;
-                }
+                if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_ce_bf16_pipe_kernel<D, CT>), lds_pipe)) return rc_optin;
                 const dim3 g2((unsigned)(cdiv(p.R, PipeGeo<D, CT>::ROWS) * p.nsplit));
                 hipLaunchKernelGGL((catalog_ce_bf16_pipe_kernel<D, CT>), g2, dim3(256), lds_pipe, st, p);
                 if constexpr (pipe_splits_range<D, CT>()) {   // the rest of every range, added into the same partial
                     constexpr int lds_fast = 65536;
-                    static bool attr_set4 = false;
-                    if (!attr_set4) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_fast_kernel<D>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast);
-                        attr_set4 = true;
-                    }
+                    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_ce_bf16_fast_kernel<D>), lds_fast)) return rc_optin;
                     CatParamsB pr = p;
                     const int64_t nblk = (int64_t)grid.x / p.nsplit;   // row blocks of this kernel
                     pr.rem_mode = (int)std::max<int64_t>(1, std::min<int64_t>(p.nsplit, 256 / std::max<int64_t>(nblk, 1)));
@@ -1504,12 +1494,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
                 }
             } else if constexpr (!ALWAYS_PIPE) {
                 constexpr int lds_fast = 65536;  // ring of four 16 KB chunks (also holds the <= 64 KB synchronous tail image)
-                static bool attr_set = false;
-                if (!attr_set) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_fast_kernel<D>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_fast);
-                    attr_set = true;
-                }
+                if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_ce_bf16_fast_kernel<D>), lds_fast)) return rc_optin;
                 hipLaunchKernelGGL((catalog_ce_bf16_fast_kernel<D>), grid, block, lds_fast, st, p);
             }
         }
@@ -1518,12 +1503,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
     }
 #define PCVAE_CEB(MASKV, DXV)                                                                                    \
     do {                                                                                                         \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_bf16_kernel<D, MASKV, DXV>),          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                           \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
+        if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_ce_bf16_kernel<D, MASKV, DXV>), (int)lds)) return rc_optin;                                                                                                        \
         hipLaunchKernelGGL((catalog_ce_bf16_kernel<D, MASKV, DXV>), grid, block, lds, st, p);                    \
     } while (0)
     if (want_dx) {
@@ -2115,12 +2095,7 @@ static int launch_ce_x3(const float* rx, int64_t R, const uint16_t* Ex, const fl
     hipLaunchKernelGGL((catalog_row_bound_kernel<D>), dim3((unsigned)p.nrb), dim3(256), 0, st, rx, R, e_max_norm, flags);
     p.safe_flags = flags;
     constexpr int lds_pipe = XG::NB * XG::CB;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_ce_x3_pipe_kernel<D, CT, NC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
-        attr_set = true;
-    }
+    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_ce_x3_pipe_kernel<D, CT, NC>), lds_pipe)) return rc_optin;
     const dim3 grid((unsigned)(cdiv(R, XG::ROWS) * p.nsplit));
     hipLaunchKernelGGL((catalog_ce_x3_pipe_kernel<D, CT, NC>), grid, dim3(256), lds_pipe, st, p);
     int rc = check_launch(NC == 3 ? "catalog_ce_x6" : "catalog_ce_x3");
@@ -2179,27 +2154,15 @@ template <int D>
 static int launch_screened(ScreenParams p, const CatalogPlan& pa, const CatalogPlan& pb, int64_t Ns, int64_t N, int64_t* idx,
                            float* best, hipStream_t st) {
     const size_t lds = SCREEN_LDS_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 0>), (int)lds)) return rc_optin;
+    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 1>), (int)lds)) return rc_optin;
     const dim3 block(512);
     // long ranges: the software-pipelined screening kernels (one wave per SIMD, 64 rows per wave for D <= 128)
     constexpr int CT = D == 256 ? 2 : 4;
     using PG = PipeGeo<D, CT>;
     constexpr int lds_pipe = PG::NB * 16384 + SCREEN_PIPE_CAP * 16 + 16;
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 0>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_pipe);
-        attr_set2 = true;
-    }
+    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 0>), lds_pipe)) return rc_optin;
+    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 1>), lds_pipe)) return rc_optin;
     const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
     const int pipe_min = env_min ? atoi(env_min) : 512;
     p.N = Ns; p.nrb = pa.nrb; p.nsplit = pa.nsplit; p.tiles_per_split = pa.tiles_per_split; p.ntiles = pa.ntiles;

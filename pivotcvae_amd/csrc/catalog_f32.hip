@@ -45,6 +45,7 @@ struct CatParams {
     int64_t* pn;          // [nsplit][R]   argmax index
     const uint8_t* flags; // CE only, or null: one byte per 256-row block; only blocks whose flag is 1 are computed / written
     float dx_scale;       // CE: dx is written times this (the 1 / (R W) of the mean reduction: no separate scaling launch)
+    const uint8_t* unres; // sampling only, or null: one byte per ROW; only workgroups with a flagged row run, only flagged rows are written
 };
 
 template <int D>
@@ -340,6 +341,10 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_argmax_f32_ke
     const int64_t r = (int64_t)rb * 128 + wave * 32 + li;
     const bool row_ok = r < p.R;
     const int64_t rl = row_ok ? r : p.R - 1;
+    if (SAMPLE && p.unres) {   // the fallback of the rejection sampler: leave at once unless one of this workgroup's rows needs it
+        const int64_t rr = (int64_t)rb * 128 + (threadIdx.x & 127);
+        if (!__syncthreads_or(rr < p.R && p.unres[rr] != 0)) return;
+    }
 
     float xb[G::KS];
 #pragma unroll
@@ -413,6 +418,7 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_argmax_f32_ke
 __global__ void catalog_argmax_merge_kernel(CatParams p, int64_t* __restrict__ idx, float* __restrict__ bestv) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.R) return;
+    if (p.unres && !p.unres[r]) return;   // the rejection sampler drew this row: idx[r] stands (its partials were never written)
     float b = p.pm[r];
     int64_t n = p.pn[r];
     for (int j = 1; j < p.nsplit; ++j) {  // splits are in increasing-n order: strict '>' keeps the first maximum
@@ -511,10 +517,10 @@ int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D,
 }
 
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,
-                       uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st) {
+                       uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st, const uint8_t* unres) {
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);
     CatParams p{};
-    p.rx = x; p.E = E; p.R = R; p.N = N; p.seed = seed; p.row_offset = row_offset;
+    p.rx = x; p.E = E; p.R = R; p.N = N; p.seed = seed; p.row_offset = row_offset; p.unres = sample ? unres : nullptr;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
     p.pm = reinterpret_cast<float*>(ws);
     p.pn = reinterpret_cast<int64_t*>(p.pm + (((int64_t)pl.nsplit * R + 1) & ~(int64_t)1));

@@ -21,6 +21,10 @@ int check_launch(const char* what);
         }                                              \
     } while (0)
 
+// opt a kernel in to `bytes` of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize) once per (kernel, device), under a lock,
+// return code checked: the kernels over 64 KB cannot launch without it, and a process may drive several devices / threads
+int lds_optin(const void* kernel, int bytes);
+
 static inline hipStream_t as_stream(pcvae_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ---- per-kernel timing (pcvae_kernel_timer): HIP events ATTACHED to a dispatch (hipExtLaunchKernelGGL's start / stop events carry
@@ -78,6 +82,14 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
         k0 += W0; k1 += W1;
     }
     return Philox4{c0, c1, c2, c3};
+}
+
+// x % n for n >= 1 without a 64-bit division: magic = floor((2^64 - 1) / n) from the host; the quotient estimate is short of
+// floor(x / n) by at most 2.  The uniform item draws (candidate sets, rejection sampler) reduce 64 Philox bits with it.
+__device__ __forceinline__ uint64_t mod_magic(uint64_t x, uint64_t n, uint64_t magic) {
+    uint64_t r = x - __umul64hi(x, magic) * n;
+    while (r >= n) r -= n;
+    return r;
 }
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }

@@ -1,5 +1,8 @@
 // Host-side error text + ABI version for libpcvae_hip.so.
 #include "common.h"
+#include <mutex>
+#include <set>
+#include <utility>
 #include <vector>
 
 namespace pcvae {
@@ -18,6 +21,22 @@ int check_launch(const char* what) {
         set_error("%s: %s", what, hipGetErrorString(e));
         return PCVAE_ELAUNCH;
     }
+    return PCVAE_OK;
+}
+
+int lds_optin(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;   // (kernel, device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return PCVAE_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) on device %d: %s", bytes, dev, hipGetErrorString(e));
+        return PCVAE_ELAUNCH;
+    }
+    done.insert({kernel, dev});
     return PCVAE_OK;
 }
 

@@ -1238,7 +1238,11 @@ def catalog_argmax(x, table, prec=PREC_F32, return_best=False, screened=None):
 
 
 def catalog_sample(x, table, seed=0, row_offset=0, prec=PREC_F32):
-    """idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) (models/pivotcvae.py:349-351) via in-kernel Gumbel-max."""
+    """idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) (models/pivotcvae.py:349-351), drawn by REJECTION sampling: propose a uniform item,
+    accept it with probability sigmoid(score) - exactly the reference's distribution for ~2 dot products per row instead of the
+    [R, N] score matrix (csrc/catalog_sample.hip; rows that reject 4096 proposals in a row fall back to the exact Gumbel-max
+    kernel).  Scores are exact fp32 of the fp32 table whatever ``prec`` the training loss runs in: they cost nothing now, so
+    ``prec`` (kept for call compatibility) has nothing left to select."""
     table = _as_table(table)
     require_device(x, table.weight)
     x = _c2d(x.detach()).contiguous()

@@ -95,3 +95,36 @@ def candidate_raw(R, Cn, n_items, seed, row_offset=0):
     out = np.empty((R, 2 * k.shape[1]), np.int64)
     out[:, 0::2], out[:, 1::2] = a.astype(np.int64), b.astype(np.int64)
     return out[:, :Cn]
+
+
+REJECT_KMAX = 4096   # csrc/catalog_sample.hip: proposals before a row goes to the Gumbel-max kernel
+
+
+def sample_reject(x, E, seed, row_offset=0, kmax=REJECT_KMAX, margin=2e-6):
+    """pcvae_catalog_sample's rejection stage restated: proposal k of row r is Philox call (row, k, "RJCT") ->
+    item n_k = (x << 32 | y) mod N, u_k = fp32((fp32(z) + 0.5) * 2^-32); the sample is n_k of the LOWEST k with
+    u_k < sigmoid(<x_r, E_{n_k}>).  Scores here are fp64 (the kernel's are an fp32 fmaf chain), so a row is `safe` only when
+    no proposal up to and including the accepted one has |u - sigmoid| <= margin.
+    -> (idx [R] int64, -1 where all kmax proposals were rejected; k [R] accepted proposal number; safe [R] bool)"""
+    x = np.asarray(x, np.float64)
+    E64 = np.asarray(E, np.float64)
+    R, N = x.shape[0], E64.shape[0]
+    rows = np.arange(R, dtype=np.uint64) + np.uint64(row_offset)
+    c0 = (rows & MASK32).astype(np.uint32)
+    c1 = (rows >> np.uint64(32)).astype(np.uint32)
+    idx = np.full(R, -1, np.int64)
+    kacc = np.full(R, -1, np.int64)
+    safe = np.ones(R, bool)
+    live = np.ones(R, bool)
+    for k in range(kmax):
+        if not live.any():
+            break
+        a, b, z, _w = philox4x32_10(c0, c1, np.uint32(k), np.uint32(0x524A4354), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+        n = (((a.astype(np.uint64) << np.uint64(32)) | b.astype(np.uint64)) % np.uint64(N)).astype(np.int64)
+        u = ((z.astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -32)).astype(np.float64)
+        sig = 1.0 / (1.0 + np.exp(-np.einsum("rd,rd->r", x, E64[n])))
+        safe &= ~(live & (np.abs(u - sig) <= margin))
+        acc = live & (u < sig)
+        idx[acc], kacc[acc] = n[acc], k
+        live &= ~acc
+    return idx, kacc, safe

@@ -659,8 +659,53 @@ def test_catalog_argmax_screened_rejects_other_widths(ops):
         ops.catalog_argmax(rnd(4, 32, seed=1).to(DEV), unit_rows(100, 32, seed=2).to(DEV), screened=True)
 
 
+@pytest.mark.parametrize("R,N,D,scale,seed,off", [(500, 1000, 128, 3.0, 5, 0), (300, 37, 16, 6.0, 9, 1 << 35), (257, 20011, 64, 1.0, 1, 77),
+                                                  (64, 5003, 256, 2.0, 3, 5), (130, 999, 32, 4.0, 2, 0), (90, 500, 20, 3.0, 4, 9)])
+def test_catalog_sample_rejection_stream(ops, R, N, D, scale, seed, off):
+    """pcvae_catalog_sample draws by rejection: proposals k = 0, 1, .. of a row from Philox (seed, GLOBAL row, k), the sample is the
+    first accepted one.  The host restatement (tests/philox_ref.sample_reject) reproduces the ids EXACTLY on every row whose
+    accept / reject decisions are beyond fp32 rounding; shards reproduce the whole batch; a padded width (D = 20) is the same draw."""
+    x, E = rnd(R, D, seed=seed + 10, scale=scale), unit_rows(N, D, seed=seed + 20)
+    table = ops.CatalogTable(E.to(DEV))
+    idx = ops.catalog_sample(x.to(DEV), table, seed=seed, row_offset=off).cpu().numpy()
+    want, k, safe = philox_ref.sample_reject(x.numpy(), E.numpy(), seed, off)
+    assert (want >= 0).all() and safe.mean() > 0.99
+    np.testing.assert_array_equal(idx[safe], want[safe])
+    assert k.max() >= 2 and np.mean(k == 0) < 0.9            # rejections do happen: later proposals are exercised
+    lo = R // 3
+    part = ops.catalog_sample(x[lo:].contiguous().to(DEV), table, seed=seed, row_offset=off + lo).cpu().numpy()
+    np.testing.assert_array_equal(part, idx[lo:])
+    assert not np.array_equal(ops.catalog_sample(x.to(DEV), table, seed=seed + 1, row_offset=off).cpu().numpy(), idx)
+
+
+def test_catalog_sample_falls_back_to_gumbel_max_when_every_proposal_is_rejected(ops):
+    """a catalog whose items ALL score far below zero for some rows (sigmoid ~ 1e-13: no proposal is ever accepted): those rows
+    are drawn by the exact Gumbel-max kernel over the whole catalog, the others keep their rejection draw; frequencies of the
+    fallback rows follow Categorical(sigmoid(scores)) - the logits differ by up to 4 there, so the draw is far from uniform"""
+    N, D, R = 48, 16, 12000
+    g = torch.Generator().manual_seed(3)
+    base = torch.zeros(D)
+    base[0] = 1.0
+    E = orc.normalize_rows(base + 0.4 * (torch.rand(N, D, generator=g) - 0.5))     # every item near the first axis
+    hard = -30.0 * base + 3.0 * (torch.rand(D, generator=g) - 0.5)
+    hard[0] = -30.0
+    easy = rnd(1, D, seed=4, scale=2.0).reshape(-1)
+    x = torch.stack([hard if i % 2 == 0 else easy for i in range(R)])
+    table = ops.CatalogTable(E.to(DEV))
+    idx = ops.catalog_sample(x.to(DEV), table, seed=11).cpu().numpy()
+    want, _k, safe = philox_ref.sample_reject(x.numpy(), E.numpy(), 11)
+    assert (want[0::2] == -1).all() and (want[1::2] >= 0).all()
+    np.testing.assert_array_equal(idx[1::2][safe[1::2]], want[1::2][safe[1::2]])
+    sc = (hard.double() @ E.double().t())
+    probs = torch.softmax(torch.nn.functional.logsigmoid(sc), dim=0).numpy()
+    assert probs.max() / probs.min() > 5
+    freq = np.bincount(idx[0::2], minlength=N) / (R // 2)
+    assert np.abs(freq - probs).max() < 5 * np.sqrt(probs.max() / (R // 2))
+    np.testing.assert_array_equal(ops.catalog_sample(x.to(DEV), table, seed=11).cpu().numpy(), idx)
+
+
 def test_catalog_sample_distribution(ops):
-    """Categorical(sigmoid(scores)) by Gumbel-max: empirical frequencies match the probabilities."""
+    """Categorical(sigmoid(scores)) (rejection sampling): empirical frequencies match the probabilities."""
     N, D, R = 40, 16, 20000
     E = unit_rows(N, D, seed=1)
     q = rnd(1, D, seed=2, scale=3.0)
