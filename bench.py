@@ -535,7 +535,7 @@ class StepTimer:
             ops.CATALOG_CE_TIMING = None
             tr.capture_graph = was
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
-        # the pivot-selection kernel of a pt / spt / sgt train step (catalog argmax / Gumbel-max sampler), per step
+        # the pivot-selection kernel of a pt / spt / sgt train step (catalog argmax / rejection sampler), per step
         pivot_ms = sum(a.elapsed_time(b) for a, b in pivot_events) / max(steps, 1) if pivot_events else None
         graphed = graphed and tr._graph is not None and tr.capture_failed is None   # what actually happened, for the line's label
         return dict(dt=dt, steps=steps, kern_ms=kern_ms, pivot_ms=pivot_ms, graphed=graphed, elbo=(loss, rec, kld))
@@ -614,15 +614,25 @@ def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None, traffi
     return out
 
 
-def pivot_block(cfg, B_local, pivot_ms, step_ms):
-    """the pivot-selection kernel of a step (pt: catalog argmax; spt / sgt: Gumbel-max sampler over sigmoid scores): 2 B N D
-    algorithmic flops per step against the dense peak of the pipe it runs on"""
+def pivot_block(cfg, B_local, pivot_ms, step_ms, rule="pt"):
+    """the pivot-selection kernels of a step.  pt: the catalog argmax (bf16 screening + exact rescoring), 2 B N D algorithmic flops
+    per step against the dense peak of the pipe it runs on.  spt / sgt: the reference scores all B x N pairs and hands the matrix to
+    torch.multinomial; the rejection sampler draws from the same distribution with ~2 dot products per slate, so the 2 B N D flops
+    are not done at all - no flop rate is quoted for it, only its time."""
     N, D = cfg["N"], cfg["D"]
-    flops = 2.0 * B_local * N * D
-    tf = flops / (pivot_ms * 1e-3) / 1e12 if pivot_ms else 0.0
-    return {"ms_per_step": pivot_ms, "share_of_step": pivot_ms / step_ms if step_ms else None, "algorithmic_TFLOPs": tf,
-            "frac_of_bf16_peak": tf / PEAK_TFLOPS["bf16"], "frac_of_f32_mfma_peak": tf / PEAK_TFLOPS["f32"],
-            "algorithmic_flops_per_step": flops}
+    out = {"ms_per_step": pivot_ms, "share_of_step": pivot_ms / step_ms if step_ms else None}
+    if rule == "pt":
+        flops = 2.0 * B_local * N * D
+        tf = flops / (pivot_ms * 1e-3) / 1e12 if pivot_ms else 0.0
+        out.update({"kernel": "catalog_screen_pipe_kernel (bf16 screening) + exact fp32 rescoring", "algorithmic_TFLOPs": tf,
+                    "frac_of_bf16_peak": tf / PEAK_TFLOPS["bf16"], "algorithmic_flops_per_step": flops})
+    else:
+        out.update({"kernel": "catalog_sample_reject_kernel (+ the Gumbel-max kernel's launch, whose workgroups leave at once: no row "
+                              "was flagged)",
+                    "replaces": f"the [B, N] score matrix + sigmoid + torch.multinomial of models/pivotcvae.py:349-351 "
+                                f"({2.0 * B_local * N * D / 1e12:.2f} TFLOP per step): rejection sampling draws from exactly that "
+                                "categorical with ~2 gathered rows per slate"})
+    return out
 
 
 def pivot_rules_block(cfg, device, dtype, mlp, gt_pi_ms):
@@ -644,7 +654,7 @@ def pivot_rules_block(cfg, device, dtype, mlp, gt_pi_ms):
             ms = v["dt"] / v["steps"] * 1e3
             blk["train"] = {"value": B / (ms * 1e-3), "unit": "slates/s", "ms_per_step": ms, "vs_gt_pi_step": ms / gt_pi_ms,
                             "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
-                            "pivot_kernel": pivot_block(c2, B, v["pivot_ms"], ms) if v["pivot_ms"] else None}
+                            "pivot_kernel": pivot_block(c2, B, v["pivot_ms"], ms, m.TRAIN_RULE) if v["pivot_ms"] else None}
             del tr
         if m.INFER_RULE == "spi":
             g = torch.Generator(device=device).manual_seed(7)
@@ -660,7 +670,7 @@ def pivot_rules_block(cfg, device, dtype, mlp, gt_pi_ms):
                 torch.cuda.synchronize()
                 dtg = (time.perf_counter() - t0) / 3
             blk["generate"] = {"value": B / dtg, "unit": "slates/s", "ms_per_batch": dtg * 1e3,
-                               "note": "pivot by Categorical(sigmoid(scores)) (Gumbel-max kernel), the S slots by exact greedy argmax"}
+                               "note": "pivot by Categorical(sigmoid(scores)) (rejection sampler), the S slots by exact greedy argmax"}
         out[key] = blk
         del m
         torch.cuda.empty_cache()
@@ -889,7 +899,7 @@ def main():
         "roofline": roof,
     }
     if res.get("pivot_ms") is not None:
-        out["pivot_kernel"] = pivot_block(cfg, B // world, res["pivot_ms"], dt / args.steps * 1e3)
+        out["pivot_kernel"] = pivot_block(cfg, B // world, res["pivot_ms"], dt / args.steps * 1e3, getattr(model, "TRAIN_RULE", "gt"))
     single = rank == 0 and world == 1
     if single and not args.no_variants:
         # the same workload in the other arithmetics and in the reference's default masked mode (n_neg = 1000), each with its

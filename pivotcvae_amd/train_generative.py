@@ -143,8 +143,9 @@ class Trainer:
         # hipGraph capture of zero-grad + forward + backward (the ~90 small launches of a step become one graph
         # launch; matters when a rank only holds B/8 slates).  eps is drawn OUTSIDE the graph into a static buffer
         # because kernel arguments (Philox offsets) are frozen at capture; the in-kernel Bernoulli mask (n_neg < N)
-        # has the same problem, so that mode stays eager - and so do the SAMPLED pivot rules (spt / sgt): their Gumbel-max
-        # sampler takes (seed, row offset) as kernel arguments too, a replayed graph would redraw the same pivots every step.
+        # has the same problem, so that mode stays eager - and so do the candidate-set mode (its draw is keyed the same way) and
+        # the SAMPLED pivot rules (spt / sgt): their sampler takes (seed, row offset) as kernel arguments too, a replayed graph
+        # would redraw the same pivots every step.
         # The all-reduce and Adam stay outside the graph.
         self.capture_graph = bool(capture_graph) and n_neg is None and n_candidate is None and loss_fn is None and \
             getattr(model, "TRAIN_RULE", "gt") in ("gt", "pt")
