@@ -278,6 +278,93 @@ def eval_throughput(model, cfg, device, bs=1024, trials=2):
             "expected_clicks_min_mean_max_per_context": [[round(float(v), 4) for v in row] for row in stats.cpu()]}
 
 
+def pretrain_env_block(cfg, device, steps=5):
+    """Training the click model (pretrain_env.py:25-139: gather + whole-vector normalisation + ReLU MLP + BCE of the sigmoid +
+    backward incl. the embedding scatter-add + Adam with weight decay over ALL parameters, the item and user tables included) at this
+    config's shape, one resident batch.  With an N x D table among the parameters the step is the optimiser's stream over it:
+    zero-grad (1 write) + Adam (p, g, m, v read, p, m, v written) = 8 x 4 bytes per parameter against the HBM peak."""
+    from pivotcvae_amd.env.response_model import UserResponseModel_MLP
+    from pivotcvae_amd.pretrain_env import ResponseTrainer
+    N, S, D, B = cfg["N"], cfg["S"], cfg["D"], cfg["B"]
+    torch.manual_seed(6)
+    rm = UserResponseModel_MLP(8, N_USER - 1, D, S, [(S + 1) * D, 256, 256, S], "cpu", False)
+    a = (2.0 / D) ** 0.5
+    rm.docEmbed = torch.nn.Embedding(N, D, device=device)    # built on the device (a 10 GB host tensor is not needed for timing)
+    rm.docEmbed.weight.data.uniform_(-a, a)
+    rm.maxItemId = N - 1
+    rm = rm.to(device)
+    rm.device = device
+    tr = ResponseTrainer(rm, lr=1e-3, decay=1e-5)
+    s, r, u = synthetic_batch(cfg, B, device, seed=21)
+    for _ in range(2):
+        tr.step(s, u, r)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step(s, u, r)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    tr.opt.zero_grad()
+    tr.opt.step()
+    e1.record()
+    torch.cuda.synchronize()
+    opt_ms = e0.elapsed_time(e1)
+    n_par = tr.opt.flat.numel()
+    nbytes = 8.0 * 4 * n_par
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        vl = tr.validation_loss(s, u, r)
+    torch.cuda.synchronize()
+    dv = (time.perf_counter() - t0) / steps
+    out = {"value": 1.0 / dt, "unit": "steps/s", "slates_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B, "loss": float(loss),
+           "parameters": n_par, "of_which_item_table": N * D,
+           "dominant_kernel": {"kernel": "zero_kernel + adam_kernel over the flat buffer (the item table is a trained parameter "
+                                         "with weight decay: pretrain_env.py:59)", "bound": "hbm", "ms_per_step": opt_ms,
+                               "bytes_per_step": nbytes, "achieved": nbytes / (opt_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                               "frac": nbytes / (opt_ms * 1e-3) / 8e12, "share_of_step": opt_ms / (dt * 1e3)},
+           "validation": {"ms_per_batch": dv * 1e3, "slates_per_s": B / dv, "loss": float(vl),
+                          "note": "no-grad forward + BCE (pretrain_env.py:96-108)"},
+           "reference": "pretrain_env.py:76-92 (zero_grad, forward, BCELoss(sigmoid), backward, Adam.step with weight_decay)"}
+    del tr, rm
+    torch.cuda.empty_cache()
+    return out
+
+
+def validation_block(model, trainer, cfg, s, r, u, steps=3):
+    """The epoch loop's validation pass (train_generative.py:151-165: get_gen_loss under no_grad at n_neg = the dataset's candidate
+    count, default 1000), forward only: mask-train mode (sparse kept-rows kernel) and candidate mode (fused candidate kernel)."""
+    from pivotcvae_amd import ops
+    B = s.shape[0]
+    out = {}
+    for name, kw in (("mask_train_n_neg_1000", dict(n_neg=1000)), ("candidates_1000", dict(candidates=1000))):
+        ev = []
+
+        def begin():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            return e0, e1
+
+        with torch.no_grad():
+            model.loss(s, r, u, BETA, mask_seed=0x5641, **kw)
+            torch.cuda.synchronize()
+            ops.CATALOG_CE_TIMING = (begin, lambda p: (p[1].record(), ev.append(p)))
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss, rec, kld = model.loss(s, r, u, BETA, mask_seed=0x5641, **kw)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            ops.CATALOG_CE_TIMING = None
+        k_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        out[name] = {"ms_per_batch": dt * 1e3, "slates_per_s": B / dt, "loss": float(loss), "recLoss": float(rec),
+                     "dominant_kernel": {"kernel": "catalog_ce_sparse_kernel<%d, false>" % cfg["D"] if "n_neg" in kw
+                                         else "candidate_ce_kernel<%d, false>" % cfg["D"], "ms_per_launch": k_ms,
+                                         "share_of_batch": k_ms / (dt * 1e3)}}
+    out["reference"] = "train_generative.py:151-165 (model.eval(); no_grad; get_gen_loss(..., n_neg = valset.nCandidate))"
+    return out
+
+
 def generate_throughput(model, cfg, device, iters=3):
     """Greedy slate generation (recommend(return_item=True)): prior MLP -> z -> PSM -> catalog argmax (pivot) -> SCM ->
     catalog argmax (S slots).  Ids are always the exact fp32 ones (bit-exact against the reference arithmetic); for
@@ -968,6 +1055,10 @@ def main():
         if ASSEMBLE_RESULT:
             out["gather_roofline"]["train_step_kernel"] = dict(ASSEMBLE_RESULT)
         out["generate"] = generate_throughput(model, cfg, device)
+        if N >= 100_000 and cfg.get("model", "pivotcvae_gt_pi") != "listcvae":
+            # the other two phases of the reference's epoch loop (validation) and the click model's own training (pretrain_env)
+            out["validation"] = validation_block(model, trainer, cfg, s, r, u)
+            out["pretrain_env"] = pretrain_env_block(cfg, device)
         if args.config == "5":
             out["eval"] = eval_throughput(model, cfg, device)
     if use_dist:
