@@ -175,7 +175,8 @@ def gather_roofline(model, cfg, device, tables=4):
                              "note": f"{tables} launches on {tables} distinct cold tables between one event pair"},
             "achievable_hbm": {"GB/s": 6290.0, "frac_of_it": bw(tk) / 6290.0,
                                "note": "MI355X_MICROARCH.md: 6.29 TB/s measured for a float4 copy (79 % of the 8 TB/s spec)"},
-            "cache": "cold (512 MB written before every measurement)"}
+            "cache": "cold (512 MB written before every measurement)",
+            "rocprofv3_committed": committed_traffic("_r05_gather")}
 
 
 ASSEMBLE_RESULT = {}   # filled by mlp_roofline (the same eager steps): the train step's fused gather kernel

@@ -19,6 +19,10 @@ static inline constexpr int x3_ct(int D) { return D == 256 ? X3_CT256 : X3_CT; }
                        // SLOWER, one parity failure at R = 300 - not pursued
 #endif
 
+#ifndef PCVAE_PLAN_ROUND_TILES_DEFAULT
+#define PCVAE_PLAN_ROUND_TILES_DEFAULT 0   // per-round overhead of the bf16-pipe kernels in tile-times (catalog_plan's cost model)
+#endif
+
 #ifndef PCVAE_RANGE_MB_DEFAULT
 #define PCVAE_RANGE_MB_DEFAULT 0   // longest catalog range in MB of table stream (0: no limit); see catalog_plan
 #endif
@@ -59,20 +63,28 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // Range-length limit (experiments only; default off).  The 32 workgroups an XCD runs side by side stream the SAME catalog range
     // and share it in the XCD's 4 MB L2 while they stay within ~2 MB of each other in that stream; at config 5 (5 - 10 GB images)
     // they do not (PMC, round 4: 573 GB per launch for the bf16 kernel = 2.8x the shared ideal, 17.3 TB for bf16x3).  Hypothesis:
-    // they drift apart over a long pass, so shorter ranges would re-align them.  Refuted (tools/range_sweep.sh,
+    // they drift apart over a long pass, so shorter ranges would re-align them.  Refuted (experiments/tools/range_sweep.sh,
     // profiles/r04_config5_range_sweep.txt): ranges of <= 1024 / 256 / 96 MB move the reads by 17 % and the time by +0.2 .. +0.4 %;
     // the memory-side bytes do not set these kernels' time.  The knob stays for measurements.
     const int64_t row_bytes = (int64_t)D * (f32 ? 4 : prec == PCVAE_PREC_BF16X6 ? 6 : x3 ? 4 : 2);
-    const char* env_mb = getenv("PCVAE_RANGE_MB");   // (experiments: tools/range_sweep.sh; read per call like PCVAE_PIPE_MIN_TILES)
+    const char* env_mb = getenv("PCVAE_RANGE_MB");   // (experiments: experiments/tools/range_sweep.sh; read per call like PCVAE_PIPE_MIN_TILES)
     const int64_t range_mb = env_mb ? atoll(env_mb) : PCVAE_RANGE_MB_DEFAULT;
     if (range_mb > 0)
         ns_min = std::max<int64_t>(ns_min, std::min<int64_t>(cap, cdiv((int64_t)p.ntiles * 32 * row_bytes, range_mb << 20)));
+    // Every round of resident workgroups pays a fill (rx fragments, the first ring chunks) and a drain (partials stored, the tail
+    // wave of the slowest CU) on top of its tiles: PLAN_ROUND_TILES is that overhead in tile-times.  0 for the exact f32 kernels
+    // (tile time 16x longer: the overhead is noise there).  PCVAE_PLAN_ROUND_TILES / PCVAE_PLAN_NSPLIT (environment, read per call):
+    // experiments only (tools/nsplit_sweep.sh: the sweep behind the default).
+    const char* env_rt = getenv("PCVAE_PLAN_ROUND_TILES");
+    const int64_t round_tiles = env_rt ? atoll(env_rt) : (f32 ? 0 : PCVAE_PLAN_ROUND_TILES_DEFAULT);
+    const char* env_ns = getenv("PCVAE_PLAN_NSPLIT");
+    const int64_t ns_forced = env_ns ? std::max<int64_t>(1, std::min<int64_t>(cap, atoll(env_ns))) : 0;
     int64_t best_cost = -1;
-    for (int64_t ns = ns_min; ns <= cap; ++ns) {
+    for (int64_t ns = ns_forced ? ns_forced : ns_min; ns <= (ns_forced ? ns_forced : cap); ++ns) {
         const int64_t tps = cdiv(cdiv(p.ntiles, ns), quant) * quant;
         const int64_t ns_eff = cdiv(p.ntiles, tps);
         const int64_t rounds = cdiv(nblk * ns_eff, slots);
-        const int64_t cost = rounds * tps;
+        const int64_t cost = rounds * (tps + round_tiles);
         if (best_cost < 0 || cost < best_cost) {  // strict '<': ties keep the fewer, longer ranges
             best_cost = cost;
             p.tiles_per_split = (int)tps;

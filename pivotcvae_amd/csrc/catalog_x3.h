@@ -160,7 +160,7 @@ struct X3Geo {
         // nothing behind the first 2 CT MFMAs: the first split op overwrites the c0 numerators (r.w[0]) that the LAST MFMAs of the
         // gradient chain in front of this L read as their B operand.  hipcc sees those operands dead and the in-order issue would
         // seem to protect them, but a VALU write two MFMAs behind such a read corrupted it (column tile 0 - the first pair
-        // written - NaN, depending on where an unrelated ds_read sat: tools/dbg_x3.py, HISTORY.md 3.1b): MFMAs queue in front of the
+        // written - NaN, depending on where an unrelated ds_read sat: experiments/tools/dbg_x3.py, HISTORY.md 3.1b): MFMAs queue in front of the
         // matrix pipe and read their operands when they start, not when they issue.  2 CT MFMAs of distance.
         if (m < 2 * CT || m >= ML - 2) return 0;
         const Pos p = pos_of(m % MLI, 2 * KSH);
@@ -303,7 +303,7 @@ __device__ __forceinline__ void x3_pack(const unsigned (&w)[NC][CT][4], bf16x8 (
 // pipe, and an MFMA reads its A / B operands when it STARTS, not when it issues.  hipcc sees an operand dead right behind its last
 // MFMA and hands the register to the next asm result - e.g. the destination of a ds_read issued two MFMAs later, whose data then
 // lands (LDS latency ~64+ cycles) BEFORE the queued MFMA has read the old value.  Observed: the first A-fragment request of L(t+1)
-// was given the registers of pb[0][0], the B operand of the third-last MFMA of G: column tile 0 NaN (tools/dbg_x3.py).  An empty
+// was given the registers of pb[0][0], the B operand of the third-last MFMA of G: column tile 0 NaN (experiments/tools/dbg_x3.py).  An empty
 // asm use keeps an operand reserved for at least a whole step (>= 2 CT MFMAs) behind its last MFMA: fragments and tiles two
 // steps, the operands of a chain's tail until the next chain's second step.
 template <int CT, int NC>

@@ -229,7 +229,7 @@ def _whole_step_x3(name):
     s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
     tr.local_phase(s, r, u, dev(g.t("full/eps")))
     np.testing.assert_allclose([float(x) for x in tr._stats], g.a["full/loss"], rtol=1e-4)
-    # Typical agreement (tools/dbg_mlp_x3.py): 4e-6 .. 1.3e-5 of a tensor's scale.  The exception is inherent to ANY change of
+    # Typical agreement (experiments/tools/dbg_mlp_x3.py): 4e-6 .. 1.3e-5 of a tensor's scale.  The exception is inherent to ANY change of
     # arithmetic in front of a LeakyReLU: a pre-activation within the perturbation of zero changes sign, its derivative jumps
     # 1 -> 0.01 for that ONE slate, and that slate's contribution to the unit's row of its layer's weight gradient - and to every
     # gradient below that layer - changes discretely.  Round 4: the entries beyond rtol 2e-4 + 1e-4 of scale are no longer merely

@@ -91,12 +91,24 @@ if os.path.exists(gs):
             if line.startswith("{"):
                 d = json.loads(line)
                 timer[d["kernel"]] = d
+    timer_under = {}
+    p = os.path.join(src, "gather_timer_under_rocprof.txt")
+    if os.path.exists(p):
+        for line in open(p):
+            if line.startswith("{"):
+                d = json.loads(line)
+                timer_under[d["kernel"]] = d
     if ms is not None and len(c) == 2:
         alg = 98304 * (2 * 512 + 8)
-        fetch, write = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024    # (row gathers: the counter tallies these reads at face value, r03)
+        fetch, write = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024    # (16 B/lane row reads: the guide's x2 correction)
         t["_r05_gather"] = {"round": "r05", "kernel": gk + "<32, true>", "kernel_trace_avg_us": ms * 1e3,
                             "dispatch_event_timer_avg_us": timer.get("gather", {}).get("us_avg"),
-                            "FETCH_SIZE_KB_mean": c["FETCH_SIZE"], "WRITE_SIZE_KB_mean": c["WRITE_SIZE"],
+                            "dispatch_event_timer_avg_us_under_rocprofv3": timer_under.get("gather", {}).get("us_avg"),
+                            "timing_note": "the dispatch-event timer (HIP events attached to the launch) in a plain process; rocprofv3's "
+                                           "kernel trace of the same program; and the same timer INSIDE the traced process - every "
+                                           "dispatch is slower while the profiler intercepts it, so the trace's average sits above the "
+                                           "plain timer's and is the figure to quote when a trace is asked for",
+                            "FETCH_SIZE_KB_mean": c["FETCH_SIZE"], "WRITE_SIZE_KB_mean": c["WRITE_SIZE"], "fetch_correction": FETCH_NOTE,
                             "memory_side_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": alg,
                             "traffic_over_algorithmic": (fetch + write) / alg,
                             "GBps_by_kernel_trace": alg / ms / 1e6, "frac_of_8TBps_by_kernel_trace": alg / ms / 8e9,
