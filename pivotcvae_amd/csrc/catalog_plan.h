@@ -20,7 +20,11 @@ static inline constexpr int x3_ct(int D) { return D == 256 ? X3_CT256 : X3_CT; }
 #endif
 
 #ifndef PCVAE_PLAN_ROUND_TILES_DEFAULT
-#define PCVAE_PLAN_ROUND_TILES_DEFAULT 0   // per-round overhead of the bf16-pipe kernels in tile-times (catalog_plan's cost model)
+#define PCVAE_PLAN_ROUND_TILES_DEFAULT 54   // per-round overhead of the bf16-pipe kernels in tile-times (catalog_plan's cost model).
+                                            // Measured, round 5 (tools/nsplit_sweep.sh, profiles/r05_nsplit_sweep_config3_bf16.txt):
+                                            // config 3 with 8 ranges (5 rounds of 392 tiles) 0.934 ms, with 3 ranges (2 rounds of 1044)
+                                            // 0.920 ms: 5 (392 + X) / (2 (1044 + X)) = 1.015 -> X = 54.  Changes the choice at config 3
+                                            // (8 -> 3 ranges) and for its small shards (38 -> 12 ranges at B = 512); configs 4, 5 keep theirs
 #endif
 
 #ifndef PCVAE_RANGE_MB_DEFAULT

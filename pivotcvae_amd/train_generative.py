@@ -124,7 +124,9 @@ class Trainer:
         self.model, self.beta, self.n_neg = model, float(beta), n_neg
         # the reference's DEFAULT mode (no --mask_train): candidate sets of n_candidate columns per slot, drawn in the fused
         # kernel from a stream keyed by (step, GLOBAL slot) - independent of the world size, like the masks and eps
-        self.n_candidate = None if n_candidate is None else int(n_candidate)
+        # (a pair (sample_candidates [B, S, Cn], sample_targets [B, S]) instead of a count: THIS step's sets as given - what a
+        # batch of the reference's dataset carries; assign ``trainer.n_candidate`` before each step)
+        self.n_candidate = n_candidate if n_candidate is None or isinstance(n_candidate, (tuple, list)) else int(n_candidate)
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1

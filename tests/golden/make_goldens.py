@@ -445,6 +445,103 @@ def make_stated():
                      seed=808, tables_from_seed=True)
 
 
+def make_candidate_mode(name, like, n_candidate, np_seed):
+    """Round 5: the reference's DEFAULT training mode (train_generative.py:270-274: candidate sets unless --mask_train; my_utils.py:169
+    --nneg 1000) at a stated size.  The model, its state and the batch are those of the stated case `like` (rebuilt with the same
+    calls and CHECKED against that fixture: this file only adds what is new).  The candidate sets are the ones the reference's own
+    dataset class makes (data_loader.UserSlateResponseDataset.__getitem__ with init_sampling(n_candidate), :46-58) under
+    np.random.seed(np_seed + k) for draw k: the fixture keeps the seeds, max_iid and checksums - the test redraws the uniform ids
+    with numpy and applies the first-hit / overwrite rule (oracle) - then the loss terms and every .grad of
+    get_gen_loss(batch with sample_candidates / sample_targets) (:52-57), and three Adam steps with a fresh draw per step."""
+    import data_loader as ref_dl
+    ref = np.load(os.path.join(OUT, like + ".npz"), allow_pickle=False)
+    meta = json.loads(str(ref["meta"]))
+    model, S, D, Z, N, NU, B, seed = (meta[k] for k in ("model", "S", "D", "Z", "N", "NU", "B", "seed"))
+    beta, lr, st = meta["beta"], meta["lr"], meta["structs"]
+    torch.manual_seed(seed)
+    a = (2.0 / D) ** 0.5
+    raw_doc = torch.nn.Embedding(N, D)
+    raw_doc.weight.data.uniform_(-a, a)
+    raw_user = torch.nn.Embedding(NU, D)
+    raw_user.weight.data.uniform_(-a, a)
+    m = build(model, st, raw_doc, raw_user, S, D, Z, False)
+    g = torch.Generator().manual_seed(seed + 1000)
+    s = torch.randint(0, N, (B, S), generator=g)
+    u = torch.randint(0, NU, (B, 1), generator=g)
+    r = (torch.rand(B, S, generator=g) < 0.5).float()
+    r[0] = 0.0
+    r[-1] = 1.0
+    assert np.array_equal(s.numpy(), ref["s"]) and np.array_equal(r.numpy(), ref["r"]) and np.array_equal(u.numpy(), ref["u"])
+    for k, v in m.state_dict().items():
+        if "sd/" + k in ref.files:
+            assert np.array_equal(v.numpy(), ref["sd/" + k]), k       # the same model as the stated case, bit for bit
+    ds = quiet(ref_dl.UserSlateResponseDataset, s.numpy(), u.numpy(), r.numpy(), False)
+    quiet(ds.init_sampling, n_candidate)
+
+    def draw(k):   # what a DataLoader batch of the reference carries: per item a [S, Cn] draw + S target columns
+        np.random.seed(np_seed + k)
+        items = [ds[i] for i in range(B)]
+        return (np.stack([np.asarray(it["sample_candidates"]) for it in items]).astype(np.int64),
+                np.stack([np.asarray(it["sample_targets"]) for it in items]).astype(np.int64))
+
+    def checksum(c, t):
+        w = (np.arange(c.size, dtype=np.int64) % 1000003 + 1).reshape(c.shape)
+        return [int(c.sum()), int((c * w).sum() % (1 << 61)), int(t.sum()), int((t > 0).sum())]
+
+    out = {"np_seed": np.array(np_seed), "max_iid": np.array(int(ds.max_iid)), "n_candidate": np.array(n_candidate)}
+    CEL = torch.nn.CrossEntropyLoss()
+    m.candidateFlag = True
+    cand, tgt = draw(0)
+    out["cand/checksum"] = np.array(checksum(cand, tgt), dtype=np.int64)
+    batch = {"slates": s.numpy(), "users": u.numpy(), "responses": r.numpy(), "sample_candidates": cand, "sample_targets": tgt}
+    torch.manual_seed(seed + 12)
+    m.zero_grad()
+    with Recorder() as rec:
+        loss, recLoss, KLD = ref_tg.get_gen_loss(batch, m, CEL, beta)
+        loss.backward()
+    out["cand/eps"] = rec.eps[0].numpy()
+    out["cand/loss"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+    none_grads = []
+    for k, prm in m.named_parameters():
+        if prm.grad is None:
+            none_grads.append(k)
+        else:
+            out["cand/grad/" + k] = prm.grad.detach().numpy().copy()
+    # three optimisation steps, a fresh draw per step (every epoch's __getitem__ draws anew)
+    m2 = build(model, st, raw_doc, raw_user, S, D, Z, False)
+    m2.load_state_dict(m.state_dict())
+    m2.candidateFlag = True
+    opt = torch.optim.Adam(m2.parameters(), lr=lr)
+    torch.manual_seed(seed + 14)
+    frozen = ("docEmbed.weight", "userEmbed.weight")
+    for step in range(3):
+        cand, tgt = draw(1 + step)
+        out[f"adam/checksum{step}"] = np.array(checksum(cand, tgt), dtype=np.int64)
+        b2 = dict(batch, sample_candidates=cand, sample_targets=tgt)
+        opt.zero_grad()
+        with Recorder() as rec:
+            loss, recLoss, KLD = ref_tg.get_gen_loss(b2, m2, CEL, beta)
+        loss.backward()
+        opt.step()
+        out[f"adam/eps{step}"] = rec.eps[0].numpy()
+        out[f"adam/loss{step}"] = np.array([loss.item(), recLoss.item(), KLD.item()], dtype=np.float64)
+        if step in (0, 2):
+            for k, v in m2.state_dict().items():
+                if k not in frozen and k not in none_grads:
+                    out[f"adam/step{step + 1}/" + k] = v.detach().numpy().copy()
+    out["meta"] = np.array(json.dumps(dict(name=name, like=like, n_candidate=n_candidate, np_seed=np_seed, none_grads=none_grads,
+                                            max_iid=int(ds.max_iid), torch=torch.__version__, numpy=np.__version__)))
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1e6:.1f} MB, loss {out['cand/loss']}, "
+          f"{out['cand/checksum'][3]} of {B * S} slots hit their own item")
+
+
+def make_candidate_modes():
+    make_candidate_mode("candidate_mode_config2", "stated_config2_gt_pi", n_candidate=1000, np_seed=9021)
+    make_candidate_mode("candidate_mode_config4_catalog", "stated_config4_catalog_gt_pi", n_candidate=1000, np_seed=9041)
+
+
 def make_response_model(name, N, NU, D, S, B, H, seed):
     """G7: UserResponseModel_MLP (env/response_model.py:46-87)."""
     torch.manual_seed(seed)
@@ -602,6 +699,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "response_analysis":
         make_analysis()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "candidate_modes":   # round 5 (every earlier case stays byte-identical)
+        make_candidate_modes()
         return
     if len(sys.argv) > 1 and sys.argv[1] == "stated":   # round 3 (every earlier case stays byte-identical)
         make_stated()

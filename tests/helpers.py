@@ -94,6 +94,55 @@ def load(name):
     return Golden(os.path.join(GOLDEN, name + ".npz"))
 
 
+def candidate_mode_cases():
+    """goldens of the reference's DEFAULT training mode (candidate sets) at a stated size (round 5): tests/test_*stated*"""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "candidate_mode_*.npz")))
+
+
+class CandidateMode:
+    """A candidate-mode golden: model / state / batch of the stated case it names (`like`), plus the loss terms, gradients and Adam
+    steps the reference produced on candidate sets its own dataset class drew.  The sets themselves are not stored: ``draw(k)``
+    redraws draw k's uniform ids with numpy exactly as data_loader.py:46 does (np.random.seed(np_seed + k), one
+    randint(max_iid + 1, size=(S, Cn)) per slate), applies the first-hit / overwrite rule (the oracle's candidate_targets) and checks
+    the checksums the golden recorded - a numpy whose legacy stream drew something else fails HERE."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        self.meta = json.loads(str(z["meta"]))
+        self.a = {k: z[k] for k in z.files if k != "meta"}
+        self.base = load(self.meta["like"])
+        self._draws = {}
+
+    def t(self, key):
+        return torch.from_numpy(np.ascontiguousarray(self.a[key]))
+
+    def sub(self, prefix):
+        p = prefix + "/"
+        return {k[len(p):]: self.t(k) for k in self.a if k.startswith(p)}
+
+    def draw(self, k):
+        """-> (sample_candidates [B, S, Cn] int64, sample_targets [B, S] int64) of draw k (0: the loss / gradient case; 1..3: the
+        Adam steps)"""
+        if k in self._draws:
+            return self._draws[k]
+        from oracle import pivotcvae_oracle as orc
+        s = self.base.t("s")
+        B, S = s.shape
+        Cn, hi = int(self.a["n_candidate"]), int(self.a["max_iid"]) + 1
+        np.random.seed(int(self.a["np_seed"]) + k)
+        raw = np.stack([np.random.randint(hi, size=(S, Cn)) for _ in range(B)]).astype(np.int64)
+        cand, tgt = orc.candidate_targets(s, torch.from_numpy(raw))
+        c, t = cand.numpy(), tgt.numpy()
+        w = (np.arange(c.size, dtype=np.int64) % 1000003 + 1).reshape(c.shape)
+        got = [int(c.sum()), int((c * w).sum() % (1 << 61)), int(t.sum()), int((t > 0).sum())]
+        want = [int(v) for v in self.a["cand/checksum" if k == 0 else f"adam/checksum{k - 1}"]]
+        if got != want:
+            raise RuntimeError(f"{self.meta['name']}: candidate sets redrawn with numpy {np.__version__} (minted with "
+                               f"{self.meta.get('numpy')}) do not match the golden's checksums: {got} != {want}")
+        self._draws[k] = (cand, tgt)
+        return cand, tgt
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # LeakyReLU kinks: the one place where two arithmetics can differ by MORE than their rounding.  A hidden unit whose pre-activation
 # lies within the arithmetic's perturbation of zero for some slate takes the other slope there; its derivative jumps 1 <-> 0.01 for

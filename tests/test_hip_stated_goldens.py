@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from tests.gpu_util import DEV, build_from_golden, close, dev
-from tests.helpers import explain_by_kinks, leaky_kinks, load, stated_cases
+from tests.helpers import CandidateMode, candidate_mode_cases, explain_by_kinks, leaky_kinks, load, stated_cases
 
 # a pre-activation counts as "at a LeakyReLU kink" for the bf16x3 MLP arithmetic when it lies within this many x (sum of absolute
 # products) of zero: an operand carries 16 mantissa bits, the dropped lo*lo term is 2^-18 per product
@@ -262,3 +262,61 @@ def _whole_step_x3(name):
         # Adam's first steps move a weight by ~lr * g / (|g| + 1e-8): where |g| is within the arithmetic's error (1e-5 of scale here)
         # the normalised step follows the noise - up to 2 % of a tensor's entries differ by more than 1e-5, none by more than the move
         assert float(diff.max()) <= 2.001 * g.meta["lr"] * 3 and float((diff > 1e-4 * v.abs() + 1e-5).float().mean()) < 2e-2, k
+
+
+@pytest.mark.parametrize("name", candidate_mode_cases())
+@pytest.mark.parametrize("route", ["get_gen_loss", "trainer"])
+def test_candidate_mode_at_stated_sizes(name, route):
+    """The reference's DEFAULT training mode (no --mask_train: train_generative.py:52-57, 270-274) at config 2 as stated (N = 10 000,
+    S = 5, D = 32, B = 1024) and over config 4's catalog (N = 10^6, D = 128), 1000 candidates per slot as the reference's own
+    dataset class drew them (data_loader.py:46-58; redrawn from the golden's numpy seeds, checksums checked): loss terms and every
+    gradient of the fused candidate kernel against the REFERENCE's - through the reference-shaped get_gen_loss (the batch carries
+    sample_candidates / sample_targets) and through Trainer (flat buffers, the fused train path, seeded backward)."""
+    from pivotcvae_amd.train_generative import Trainer, get_gen_loss
+    cm = CandidateMode(name)
+    g = cm.base
+    m = _model(g, "f32")
+    cand, tgt = cm.draw(0)
+    s, r, u, eps = dev(g.t("s")), dev(g.t("r")), dev(g.t("u")), dev(cm.t("cand/eps"))
+    if route == "trainer":
+        tr = Trainer(m, lr=g.meta["lr"], beta=g.meta["beta"], n_candidate=(dev(cand), dev(tgt)))
+        tr.local_phase(s, r, u, eps)
+        loss, rec, kld = (float(x) for x in tr._stats)
+    else:
+        m.candidateFlag = True
+        batch = {"slates": g.a["s"], "users": g.a["u"], "responses": g.a["r"], "sample_candidates": cand.numpy(),
+                 "sample_targets": tgt.numpy()}
+        loss, rec, kld = get_gen_loss(batch, m, torch.nn.CrossEntropyLoss(), g.meta["beta"], eps=eps)
+        loss.backward()
+        loss, rec, kld = loss.item(), rec.item(), kld.item()
+    np.testing.assert_allclose([loss, rec, kld], cm.a["cand/loss"], rtol=1e-4)
+    want = cm.sub("cand/grad")
+    for k, prm in m.named_parameters():
+        if k in want:
+            close(prm.grad, want[k], rtol=2e-4, atol=2e-6)
+        else:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize("name", candidate_mode_cases())
+def test_candidate_mode_three_adam_steps(name):
+    """three optimisation steps in candidate mode, a fresh draw of the reference's dataset per step (every epoch's __getitem__
+    draws anew): ELBO terms per step and the trained parameters after 1 and 3 steps against the reference's; frozen tensors and the
+    PSM stack bit-unchanged"""
+    from pivotcvae_amd.train_generative import Trainer
+    cm = CandidateMode(name)
+    g = cm.base
+    m = _model(g, "f32")
+    tr = Trainer(m, lr=g.meta["lr"], beta=g.meta["beta"], n_candidate=1000)
+    s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
+    for step in range(3):
+        cand, tgt = cm.draw(1 + step)
+        tr.n_candidate = (dev(cand), dev(tgt))
+        loss, rec, kld = tr.step(s, r, u, eps=dev(cm.t(f"adam/eps{step}")))
+        np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], cm.a[f"adam/loss{step}"], rtol=1e-4)
+        if step in (0, 2):
+            sd = m.state_dict()
+            for k, v in cm.sub(f"adam/step{step + 1}").items():
+                assert adam_close(sd[k], v, g.meta["lr"], step + 1), k
+    for k in cm.meta["none_grads"] + ["docEmbed.weight", "userEmbed.weight"]:
+        assert torch.equal(m.state_dict()[k].cpu(), g.sd[k]), k

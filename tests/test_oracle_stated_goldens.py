@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import pivotcvae_oracle as orc
-from tests.helpers import load, stated_cases
+from tests.helpers import CandidateMode, candidate_mode_cases, load, stated_cases
 
 CASES = stated_cases()
 
@@ -84,3 +84,27 @@ def test_three_adam_steps_and_greedy_ids(name):
     assert torch.equal(o["items"][safe], g.t("rec/items")[safe])
     if cfg.model != "listcvae":
         assert torch.equal(o["pivot"], g.t("rec/pivot"))
+
+
+@pytest.mark.parametrize("name", candidate_mode_cases())
+def test_candidate_mode_at_stated_sizes(name):
+    """the reference's DEFAULT training mode (train_generative.py:52-57, 270-274; candidate sets of data_loader.py:46-58, 1000 ids
+    per slot) at config 2 as stated and over config 4's catalog: the oracle's candidate branch against the reference's loss terms
+    and gradients on the very sets the reference's dataset class drew (redrawn from the recorded numpy seeds, checksums checked)"""
+    cm = CandidateMode(name)
+    g = cm.base
+    cand, tgt = cm.draw(0)
+    assert cand.shape[-1] == 1000 and int(cand.max()) <= int(cm.a["max_iid"]) < g.meta["N"]
+    (loss, rec, kld), grads = orc.loss_and_grads(g.sd, g.cfg(), g.t("s"), g.t("r"), g.t("u"), cm.t("cand/eps"), g.meta["beta"],
+                                                 candidates=cand, cand_targets=tgt)
+    np.testing.assert_allclose([loss, rec, kld], cm.a["cand/loss"], rtol=2e-6)
+    for k, v in cm.sub("cand/grad").items():
+        close(grads[k], v, 5e-5, 2e-7)
+    assert sorted(k for k, v in grads.items() if v is None) == sorted(
+        k for k in cm.meta["none_grads"] if not k.startswith(("docEmbed", "userEmbed")))
+
+
+def test_the_candidate_mode_cases_exist():
+    assert candidate_mode_cases() == ["candidate_mode_config2", "candidate_mode_config4_catalog"]
+    for n, like in zip(candidate_mode_cases(), ("stated_config2_gt_pi", "stated_config4_catalog_gt_pi")):
+        assert CandidateMode(n).meta["like"] == like and CandidateMode(n).meta["n_candidate"] == 1000
