@@ -272,7 +272,7 @@ int pcvae_catalog_ce_sparse(const float* rx, int64_t R, const float* E, int64_t 
  * the backward of the mean-reduced loss needs no scaling launch when the upstream gradient is 1 (train_generative.py:59,133)  */
 int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                                    float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
-                                   float dx_scale, pcvae_stream_t stream);
+                                   float dx_scale, const uint64_t* seed_dev, pcvae_stream_t stream);
 int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
                             float e_max_norm, const int64_t* target, float keep_prob, uint64_t seed, uint64_t row_offset,
                             const uint8_t* keep_mask, float* nll, float* lse, float* dx, float dx_scale, void* ws,
@@ -290,6 +290,10 @@ int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E, const voi
 int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
                          uint64_t seed, uint64_t row_offset, int64_t* idx, void* ws, size_t ws_bytes,
                          pcvae_stream_t stream);
+/* the same at stream position row_offset + *row_offset_dev (row_offset_dev NULL: as above) */
+int pcvae_catalog_sample_at(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
+                            uint64_t seed, uint64_t row_offset, const uint64_t* row_offset_dev, int64_t* idx, void* ws,
+                            size_t ws_bytes, pcvae_stream_t stream);
 
 /* fp32 table -> bf16 hi (round-to-nearest-even) and optional bf16 lo (residual) copies */
 int pcvae_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, pcvae_stream_t stream);
@@ -344,7 +348,11 @@ int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, const int64_t*
  *     D in {16, 32, 64, 128, 256} (other widths: zero-padded by the caller), N < 2^31 - 1.                                  */
 int pcvae_candidate_ce(const float* rx, int64_t R, const float* E, int64_t N, int D, int Cn, const int64_t* feature,
                        uint64_t seed, uint64_t row_offset, const int64_t* cand, const int64_t* cand_target, float* nll,
-                       float* lse, float* dx, float dx_scale, int64_t* tgt_out, pcvae_stream_t stream);
+                       float* lse, float* dx, float dx_scale, int64_t* tgt_out, const uint64_t* seed_dev, pcvae_stream_t stream);
+/*     seed_dev (here, in pcvae_catalog_ce_sparse_scaled; row_offset_dev in pcvae_catalog_sample_at): NULL, or a device word the
+ *     kernel reads its seed (stream position) from at run time instead of the by-value argument - kernel arguments are frozen when
+ *     a step is captured into a hipGraph, a device word is not: pcvae_set_words writes it before each replay.                      */
+int pcvae_set_words(uint64_t* dst, uint64_t a, uint64_t b, pcvae_stream_t stream);   /* dst[0] = a, dst[1] = b, on the stream */
 
 /* ---------------------------------------------------------------------------------------------
  * K8  Adam over one flat fp32 buffer                    train_generative.py:103,134

@@ -31,6 +31,7 @@ struct CandParams {
     int64_t R, N;
     int Cn;
     uint64_t seed, row_offset, magic;   // magic = floor((2^64 - 1) / N): exact x % N without a 64-bit division
+    const uint64_t* seed_dev;    // or null: the seed is read from this device word instead (a captured graph replays with a new seed)
     float* nll;                  // [R]
     float* lse;                  // [R] or null
     float* dx;                   // [R, D] or null
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
     const float4 xa = *reinterpret_cast<const float4*>(p.rx + r * D + 4 * j);
     const float4 xb = *reinterpret_cast<const float4*>(p.rx + r * D + D / 2 + 4 * j);
     const uint64_t grow = p.row_offset + (uint64_t)r;
+    const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
     const bool drawn = p.cand == nullptr;
     const int64_t f = drawn ? p.feature[r] : -1;
     const int64_t* crow = drawn ? nullptr : p.cand + r * (int64_t)Cn;
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
         if (drawn) {
             for (int c = c0 + 2 * lane; c < c0 + cnt; c += 128) {   // a lane draws columns c, c + 1 from one Philox call
                 const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(c >> 1), 0x43414E44u /*"CAND"*/,
-                                                 (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+                                                 (uint32_t)seed, (uint32_t)(seed >> 32));
                 const int64_t v0 = (int64_t)mod_magic(((uint64_t)ph.x << 32) | ph.y, (uint64_t)p.N, p.magic);
                 const int64_t v1 = (int64_t)mod_magic(((uint64_t)ph.z << 32) | ph.w, (uint64_t)p.N, p.magic);
                 const bool two = c + 1 < c0 + cnt;
@@ -214,7 +216,8 @@ int launch_cand(const CandParams& p, hipStream_t st) {
 
 extern "C" int pcvae_candidate_ce(const float* rx, int64_t R, const float* E, int64_t N, int D, int Cn, const int64_t* feature,
                                   uint64_t seed, uint64_t row_offset, const int64_t* cand, const int64_t* cand_target, float* nll,
-                                  float* lse, float* dx, float dx_scale, int64_t* tgt_out, pcvae_stream_t stream) {
+                                  float* lse, float* dx, float dx_scale, int64_t* tgt_out, const uint64_t* seed_dev,
+                                  pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && nll, "candidate_ce: null pointer");
     PCVAE_REQUIRE((cand != nullptr) == (cand_target != nullptr), "candidate_ce: cand and cand_target come together");
     PCVAE_REQUIRE(cand || feature, "candidate_ce: give the slots' true items (feature) or candidate sets (cand + cand_target)");
@@ -224,7 +227,8 @@ extern "C" int pcvae_candidate_ce(const float* rx, int64_t R, const float* E, in
                   "candidate_ce: rx/E/dx must be 16-byte aligned");
     PCVAE_REQUIRE(cdiv(R, 4) <= 2147483647LL, "candidate_ce: R too large");
     if (R == 0) return PCVAE_OK;
-    CandParams p{rx, E, feature, cand, cand_target, R, N, Cn, seed, row_offset, ~0ull / (uint64_t)N, nll, lse, dx, dx_scale, tgt_out};
+    CandParams p{rx, E, feature, cand, cand_target, R, N, Cn, seed, row_offset, ~0ull / (uint64_t)N, seed_dev, nll, lse, dx, dx_scale,
+                 tgt_out};
     switch (D) {
         case 16: return launch_cand<16>(p, as_stream(stream));
         case 32: return launch_cand<32>(p, as_stream(stream));

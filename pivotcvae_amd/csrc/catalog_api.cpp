@@ -135,6 +135,12 @@ extern "C" int pcvae_catalog_argmax(const float* x, int64_t R, const void* E, co
 extern "C" int pcvae_catalog_sample(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
                                     int prec, uint64_t seed, uint64_t row_offset, int64_t* idx, void* ws,
                                     size_t ws_bytes, pcvae_stream_t stream) {
+    return pcvae_catalog_sample_at(x, R, E, E_lo, N, D, prec, seed, row_offset, nullptr, idx, ws, ws_bytes, stream);
+}
+
+extern "C" int pcvae_catalog_sample_at(const float* x, int64_t R, const void* E, const void* E_lo, int64_t N, int D,
+                                       int prec, uint64_t seed, uint64_t row_offset, const uint64_t* row_offset_dev, int64_t* idx,
+                                       void* ws, size_t ws_bytes, pcvae_stream_t stream) {
     PCVAE_REQUIRE(x && E && idx && ws, "catalog_sample: null pointer");
     PCVAE_REQUIRE(R > 0 && N > 0, "catalog_sample: empty problem R=%lld N=%lld", (long long)R, (long long)N);
     PCVAE_REQUIRE(supported_d(D), "catalog_sample: unsupported D=%d (16, 32, 64, 128, 256)", D);
@@ -151,7 +157,7 @@ extern "C" int pcvae_catalog_sample(const float* x, int64_t R, const void* E, co
     //    the exact Gumbel-max kernel over the whole catalog - its workgroups leave at once when none of their rows is flagged
     uint8_t* unres = reinterpret_cast<uint8_t*>(ws) + catalog_sample_unres_offset(R, N, D);
     const float* Ef = reinterpret_cast<const float*>(E);
-    int rc = catalog_sample_reject(x, R, Ef, N, D, seed, row_offset, idx, unres, as_stream(stream));
+    int rc = catalog_sample_reject(x, R, Ef, N, D, seed, row_offset, row_offset_dev, idx, unres, as_stream(stream));
     if (rc != PCVAE_OK) return rc;
-    return catalog_argmax_f32(x, R, Ef, N, D, true, seed, row_offset, idx, nullptr, ws, as_stream(stream), unres);
+    return catalog_argmax_f32(x, R, Ef, N, D, true, seed, row_offset, idx, nullptr, ws, as_stream(stream), unres, row_offset_dev);
 }

@@ -45,6 +45,7 @@ struct CatParams {
     int64_t* pn;          // [nsplit][R]   argmax index
     const uint8_t* flags; // CE only, or null: one byte per 256-row block; only blocks whose flag is 1 are computed / written
     float dx_scale;       // CE: dx is written times this (the 1 / (R W) of the mean reduction: no separate scaling launch)
+    const uint64_t* row_offset_dev;   // sampling only, or null: added to row_offset (graph replay at a new stream position)
     const uint8_t* unres; // sampling only, or null: one byte per ROW; only workgroups with a flagged row run, only flagged rows are written
 };
 
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1)) catalog_argmax_f32_ke
             sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xb[s], sacc, 0, 0, 0);
         }
         if (SAMPLE) {
-            const uint64_t grow = p.row_offset + (uint64_t)rl;
+            const uint64_t grow = p.row_offset + (p.row_offset_dev ? *p.row_offset_dev : 0ull) + (uint64_t)rl;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint64_t nb = (uint64_t)(n0 + 8 * q + 4 * h);
@@ -517,10 +518,12 @@ int catalog_ce_f32(const float* rx, int64_t R, const float* E, int64_t N, int D,
 }
 
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,
-                       uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st, const uint8_t* unres) {
+                       uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st, const uint8_t* unres,
+                       const uint64_t* row_offset_dev) {
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);
     CatParams p{};
     p.rx = x; p.E = E; p.R = R; p.N = N; p.seed = seed; p.row_offset = row_offset; p.unres = sample ? unres : nullptr;
+    p.row_offset_dev = sample ? row_offset_dev : nullptr;
     p.nrb = pl.nrb; p.nsplit = pl.nsplit; p.tiles_per_split = pl.tiles_per_split; p.ntiles = pl.ntiles;
     p.pm = reinterpret_cast<float*>(ws);
     p.pn = reinterpret_cast<int64_t*>(p.pm + (((int64_t)pl.nsplit * R + 1) & ~(int64_t)1));

@@ -143,10 +143,11 @@ int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const
                             int64_t* idx, float* best, void* ws, hipStream_t st);
 // sample = true: Gumbel-max draw from Categorical(sigmoid(scores)); with `unres` [R] only for the rows flagged there
 int catalog_argmax_f32(const float* x, int64_t R, const float* E, int64_t N, int D, bool sample, uint64_t seed,
-                       uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st, const uint8_t* unres = nullptr);
+                       uint64_t row_offset, int64_t* idx, float* best, void* ws, hipStream_t st, const uint8_t* unres = nullptr,
+                       const uint64_t* row_offset_dev = nullptr);
 // rejection sampler of Categorical(sigmoid(scores)) (catalog_sample.hip): idx[r] for every row it resolves, unres[r] = 1 otherwise
 int catalog_sample_reject(const float* x, int64_t R, const float* E, int64_t N, int D, uint64_t seed, uint64_t row_offset,
-                          int64_t* idx, uint8_t* unres, hipStream_t st);
+                          const uint64_t* row_offset_dev, int64_t* idx, uint8_t* unres, hipStream_t st);
 // where the sampler's per-row flags live in the catalog workspace: behind the argmax partials of the f32 plan
 static inline size_t catalog_sample_unres_offset(int64_t R, int64_t N, int D) {
     const CatalogPlan pl = catalog_plan(R, N, D, PCVAE_PREC_F32);

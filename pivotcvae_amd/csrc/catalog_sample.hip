@@ -30,6 +30,7 @@ struct SampleParams {
     const float* E;     // [N, D] fp32
     int64_t R, N;
     uint64_t seed, row_offset, magic;
+    const uint64_t* row_offset_dev;   // or null: added to row_offset (a captured graph replays at a new stream position)
     int64_t* idx;       // [R]
     uint8_t* unres;     // [R]: 1 = all CS_KMAX proposals rejected (idx[r] is not written)
 };
@@ -45,7 +46,7 @@ __global__ void __launch_bounds__(256) catalog_sample_reject_kernel(SampleParams
     const int j = lane % LPI, grp = lane / LPI;
     const float4 xa = *reinterpret_cast<const float4*>(p.x + r * D + 4 * j);
     const float4 xb = *reinterpret_cast<const float4*>(p.x + r * D + D / 2 + 4 * j);
-    const uint64_t grow = p.row_offset + (uint64_t)r;
+    const uint64_t grow = p.row_offset + (p.row_offset_dev ? *p.row_offset_dev : 0ull) + (uint64_t)r;
 
     int64_t found = -1;
     for (int k0 = 0; k0 < CS_KMAX && found < 0; k0 += IPS * CS_UNR) {
@@ -107,8 +108,8 @@ int launch_reject(const SampleParams& p, hipStream_t st) {
 namespace pcvae {
 
 int catalog_sample_reject(const float* x, int64_t R, const float* E, int64_t N, int D, uint64_t seed, uint64_t row_offset,
-                          int64_t* idx, uint8_t* unres, hipStream_t st) {
-    SampleParams p{x, E, R, N, seed, row_offset, ~0ull / (uint64_t)N, idx, unres};
+                          const uint64_t* row_offset_dev, int64_t* idx, uint8_t* unres, hipStream_t st) {
+    SampleParams p{x, E, R, N, seed, row_offset, ~0ull / (uint64_t)N, row_offset_dev, idx, unres};
     switch (D) {
         case 16: return launch_reject<16>(p, st);
         case 32: return launch_reject<32>(p, st);

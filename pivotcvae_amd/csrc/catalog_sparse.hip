@@ -36,6 +36,7 @@ struct SparseParams {
     float* lse;             // [R] or null
     float* dx;              // [R, D] or null
     float dx_scale;         // dx is written times this
+    const uint64_t* seed_dev;   // or null: the seed is read from this device word instead (a captured graph replays with a new seed)
 };
 
 // gap of the Bernoulli(p) process from 52 random bits: floor(ln U * inv_log_q), U = (2 u + 1) / 2^53 in (0, 1)
@@ -68,6 +69,7 @@ __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) 
     const int64_t tgt = p.target[r];
     const bool t_ok = tgt >= 0 && tgt < p.N;
     const uint64_t grow = p.row_offset + (uint64_t)r;
+    const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
 
     // this lane's catalog segment and the state of its gap chain
     const int64_t seg = (p.N + 63) / 64;
@@ -99,7 +101,7 @@ __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) 
                 if (have) { g = g_next; have = false; }
                 else {
                     const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)lane + 64u * call, SP_TAG,
-                                                     (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+                                                     (uint32_t)seed, (uint32_t)(seed >> 32));
                     ++call;
                     g = sp_gap(ph.x, ph.y, p.inv_log_q);
                     g_next = sp_gap(ph.z, ph.w, p.inv_log_q);
@@ -212,19 +214,19 @@ int launch_sparse(const SparseParams& p, hipStream_t st) {
 extern "C" int pcvae_catalog_ce_sparse(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                                        float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
                                        pcvae_stream_t stream) {
-    return pcvae_catalog_ce_sparse_scaled(rx, R, E, N, D, target, keep_prob, seed, row_offset, nll, lse, dx, 1.0f, stream);
+    return pcvae_catalog_ce_sparse_scaled(rx, R, E, N, D, target, keep_prob, seed, row_offset, nll, lse, dx, 1.0f, nullptr, stream);
 }
 
 extern "C" int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                                               float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse,
-                                              float* dx, float dx_scale, pcvae_stream_t stream) {
+                                              float* dx, float dx_scale, const uint64_t* seed_dev, pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && target && nll, "catalog_ce_sparse: null pointer");
     PCVAE_REQUIRE(R > 0 && N > 0 && N < 2147483647LL, "catalog_ce_sparse: bad problem R=%lld N=%lld", (long long)R, (long long)N);
     PCVAE_REQUIRE(keep_prob > 0.f && keep_prob < 1.f, "catalog_ce_sparse: keep_prob must be in (0, 1)");
     PCVAE_REQUIRE(((uintptr_t)rx % 16 == 0) && ((uintptr_t)E % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0),
                   "catalog_ce_sparse: rx/E/dx must be 16-byte aligned");
     PCVAE_REQUIRE(cdiv(R, 4) <= 2147483647LL, "catalog_ce_sparse: R too large");
-    SparseParams p{rx, E, target, R, N, seed, row_offset, 1.0 / log1p(-(double)keep_prob), nll, lse, dx, dx_scale};
+    SparseParams p{rx, E, target, R, N, seed, row_offset, 1.0 / log1p(-(double)keep_prob), nll, lse, dx, dx_scale, seed_dev};
     switch (D) {
         case 16: return launch_sparse<16>(p, as_stream(stream));
         case 32: return launch_sparse<32>(p, as_stream(stream));

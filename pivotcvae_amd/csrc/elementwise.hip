@@ -831,6 +831,19 @@ __global__ void __launch_bounds__(256) zero_kernel(uint4* __restrict__ p16, size
     if (blockIdx.x == 0 && threadIdx.x < ntail) tail[threadIdx.x] = 0;
 }
 
+// the step-dependent words (mask / candidate seed, sampler stream position) of a hipGraph-replayed step: written by this one-thread
+// kernel BEFORE the replay, read by the captured kernels through their seed_dev / row_offset_dev arguments
+__global__ void set_words_kernel(uint64_t* dst, uint64_t a, uint64_t b) {
+    dst[0] = a;
+    dst[1] = b;
+}
+
+extern "C" int pcvae_set_words(uint64_t* dst, uint64_t a, uint64_t b, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(dst && ((uintptr_t)dst % 8 == 0), "set_words: null or misaligned pointer");
+    hipLaunchKernelGGL(set_words_kernel, dim3(1), dim3(1), 0, as_stream(stream), dst, a, b);
+    return check_launch("set_words");
+}
+
 extern "C" int pcvae_zero(void* p, size_t nbytes, pcvae_stream_t stream) {
     PCVAE_REQUIRE(p || nbytes == 0, "zero: bad arguments");
     if (nbytes == 0) return PCVAE_OK;
@@ -1180,13 +1193,85 @@ extern "C" int pcvae_candidate_draw(const int64_t* feature, int64_t R, int64_t n
 }
 
 // =============================================================================================
-// K9: candidate-set scores.  fwd: lane per candidate (each lane streams its own table row, the rx
-// row is wave-uniform); bwd: wave per slate row, lanes over d (coalesced row reads).
+// K9 (materialised form, behind forward()'s dense-p contract; the training loss uses the fused pcvae_candidate_ce): candidate-set
+// scores p[r, c] = <E[cand[r, c]], rx_r> and their backward drx_r = sum_c dp[r, c] E[cand[r, c]].  Same access pattern as the fused
+// kernel: a wave owns a slate row and holds rx_r (bwd: the accumulator) in registers, a lane group of LPI lanes reads one table row
+// with 16-byte loads (CS_UNR rows in flight per lane group); widths that are not a multiple of 4 take the scalar kernels.
 // =============================================================================================
-__global__ void __launch_bounds__(256) candidate_scores_kernel(const float* __restrict__ rx, int64_t R,
-                                                               const float* __restrict__ E, int D,
-                                                               const int64_t* __restrict__ cand, int Cn,
-                                                               float* __restrict__ p) {
+constexpr int CS_UNR = 4;
+
+template <int LPI, bool BWD>
+__global__ void __launch_bounds__(256) candidate_rows_kernel(const float* __restrict__ x, int64_t R, const float* __restrict__ E, int D,
+                                                             const int64_t* __restrict__ cand, int Cn, float* __restrict__ out) {
+    // fwd: x = rx [R, D], out = p [R, Cn].   bwd: x = dp [R, Cn], out = drx [R, D].   A lane covers chunks j, j + LPI, .. of 4 floats.
+    constexpr int IPS = 64 / LPI;
+    constexpr int MAXC = 4;                       // chunks per lane: D <= 16 * LPI
+    const int lane = threadIdx.x & 63, j = lane % LPI, grp = lane / LPI;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int nch = D >> 2;
+    float4 acc[MAXC];
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) {
+        const int ch = j + q * LPI;
+        acc[q] = (!BWD && ch < nch) ? *reinterpret_cast<const float4*>(x + r * D + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int64_t* crow = cand + r * (int64_t)Cn;
+    for (int c0 = 0; c0 < Cn; c0 += IPS * CS_UNR) {
+        float4 e[CS_UNR][MAXC];
+        float w[CS_UNR];
+        bool ok[CS_UNR];
+#pragma unroll
+        for (int u = 0; u < CS_UNR; ++u) {
+            const int c = c0 + u * IPS + grp;
+            ok[u] = c < Cn;
+            const float* row = E + (ok[u] ? crow[c] : 0) * (int64_t)D;
+            w[u] = (BWD && ok[u]) ? x[r * (int64_t)Cn + c] : 0.f;
+#pragma unroll
+            for (int q = 0; q < MAXC; ++q) {
+                const int ch = j + q * LPI;
+                e[u][q] = (ok[u] && ch < nch) ? *reinterpret_cast<const float4*>(row + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CS_UNR; ++u) {
+            if (BWD) {
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q) {
+                    acc[q].x = fmaf(w[u], e[u][q].x, acc[q].x); acc[q].y = fmaf(w[u], e[u][q].y, acc[q].y);
+                    acc[q].z = fmaf(w[u], e[u][q].z, acc[q].z); acc[q].w = fmaf(w[u], e[u][q].w, acc[q].w);
+                }
+            } else {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q) {
+                    s = fmaf(e[u][q].x, acc[q].x, s); s = fmaf(e[u][q].y, acc[q].y, s);
+                    s = fmaf(e[u][q].z, acc[q].z, s); s = fmaf(e[u][q].w, acc[q].w, s);
+                }
+#pragma unroll
+                for (int o = 1; o < LPI; o <<= 1) s += __shfl_xor(s, o, 64);
+                if (ok[u] && j == 0) out[r * (int64_t)Cn + c0 + u * IPS + grp] = s;
+            }
+        }
+    }
+    if (BWD) {
+#pragma unroll
+        for (int q = 0; q < MAXC; ++q) {
+#pragma unroll
+            for (int o = LPI; o < 64; o <<= 1) {   // sum the lane groups' partial rows
+                acc[q].x += __shfl_xor(acc[q].x, o, 64); acc[q].y += __shfl_xor(acc[q].y, o, 64);
+                acc[q].z += __shfl_xor(acc[q].z, o, 64); acc[q].w += __shfl_xor(acc[q].w, o, 64);
+            }
+            const int ch = j + q * LPI;
+            if (grp == 0 && ch < nch) *reinterpret_cast<float4*>(out + r * D + 4 * ch) = acc[q];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) candidate_scores_scalar_kernel(const float* __restrict__ rx, int64_t R,
+                                                                      const float* __restrict__ E, int D,
+                                                                      const int64_t* __restrict__ cand, int Cn,
+                                                                      float* __restrict__ p) {
     const int64_t total = R * (int64_t)Cn;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / Cn;
@@ -1198,20 +1283,10 @@ __global__ void __launch_bounds__(256) candidate_scores_kernel(const float* __re
     }
 }
 
-extern "C" int pcvae_candidate_scores(const float* rx, int64_t R, const float* E, int64_t N, int D,
-                                      const int64_t* cand, int Cn, float* p, pcvae_stream_t stream) {
-    PCVAE_REQUIRE(rx && E && cand && p && D > 0 && Cn > 0 && N > 0, "candidate_scores: bad arguments");
-    if (R == 0) return PCVAE_OK;
-    const int64_t blocks = std::min<int64_t>(cdiv(R * Cn, 256), 256 * 16);
-    hipLaunchKernelGGL(candidate_scores_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), rx, R, E, D,
-                       cand, Cn, p);
-    return check_launch("candidate_scores");
-}
-
-__global__ void __launch_bounds__(256) candidate_scores_bwd_kernel(const float* __restrict__ dp, int64_t R,
-                                                                   const float* __restrict__ E, int D,
-                                                                   const int64_t* __restrict__ cand, int Cn,
-                                                                   float* __restrict__ drx) {
+__global__ void __launch_bounds__(256) candidate_scores_bwd_scalar_kernel(const float* __restrict__ dp, int64_t R,
+                                                                          const float* __restrict__ E, int D,
+                                                                          const int64_t* __restrict__ cand, int Cn,
+                                                                          float* __restrict__ drx) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
@@ -1226,12 +1301,52 @@ __global__ void __launch_bounds__(256) candidate_scores_bwd_kernel(const float* 
     }
 }
 
+// lanes per table row: the smallest power of two >= D / 16 (a lane then holds at most 4 chunks of 4 floats), at least 2
+static int cand_lpi(int D) {
+    int lpi = 2;
+    while (lpi * 16 < D) lpi <<= 1;
+    return lpi;
+}
+
+template <bool BWD>
+static int launch_candidate_rows(const float* x, int64_t R, const float* E, int D, const int64_t* cand, int Cn, float* out,
+                                 hipStream_t st) {
+    const dim3 grid((unsigned)cdiv(R, 4)), block(256);
+    switch (cand_lpi(D)) {
+        case 2: hipLaunchKernelGGL((candidate_rows_kernel<2, BWD>), grid, block, 0, st, x, R, E, D, cand, Cn, out); break;
+        case 4: hipLaunchKernelGGL((candidate_rows_kernel<4, BWD>), grid, block, 0, st, x, R, E, D, cand, Cn, out); break;
+        case 8: hipLaunchKernelGGL((candidate_rows_kernel<8, BWD>), grid, block, 0, st, x, R, E, D, cand, Cn, out); break;
+        case 16: hipLaunchKernelGGL((candidate_rows_kernel<16, BWD>), grid, block, 0, st, x, R, E, D, cand, Cn, out); break;
+        case 32: hipLaunchKernelGGL((candidate_rows_kernel<32, BWD>), grid, block, 0, st, x, R, E, D, cand, Cn, out); break;
+        default: hipLaunchKernelGGL((candidate_rows_kernel<64, BWD>), grid, block, 0, st, x, R, E, D, cand, Cn, out); break;
+    }
+    return check_launch(BWD ? "candidate_scores_bwd" : "candidate_scores");
+}
+
+static bool cand_vec_ok(const float* a, const float* E, const float* out, int D, bool bwd) {
+    return D % 4 == 0 && D <= 1024 && ((uintptr_t)E % 16 == 0) && ((uintptr_t)(bwd ? out : a) % 16 == 0);
+}
+
+extern "C" int pcvae_candidate_scores(const float* rx, int64_t R, const float* E, int64_t N, int D,
+                                      const int64_t* cand, int Cn, float* p, pcvae_stream_t stream) {
+    PCVAE_REQUIRE(rx && E && cand && p && D > 0 && Cn > 0 && N > 0, "candidate_scores: bad arguments");
+    if (R == 0) return PCVAE_OK;
+    PCVAE_REQUIRE(cdiv(R, 4) <= 2147483647LL, "candidate_scores: R too large");
+    if (cand_vec_ok(rx, E, p, D, false)) return launch_candidate_rows<false>(rx, R, E, D, cand, Cn, p, as_stream(stream));
+    const int64_t blocks = std::min<int64_t>(cdiv(R * Cn, 256), 256 * 16);
+    hipLaunchKernelGGL(candidate_scores_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), rx, R, E, D,
+                       cand, Cn, p);
+    return check_launch("candidate_scores");
+}
+
 extern "C" int pcvae_candidate_scores_bwd(const float* dp, int64_t R, const float* E, int64_t N, int D,
                                           const int64_t* cand, int Cn, float* drx, pcvae_stream_t stream) {
     PCVAE_REQUIRE(dp && E && cand && drx && D > 0 && Cn > 0 && N > 0, "candidate_scores_bwd: bad arguments");
     if (R == 0) return PCVAE_OK;
+    PCVAE_REQUIRE(cdiv(R, 4) <= 2147483647LL, "candidate_scores_bwd: R too large");
+    if (cand_vec_ok(dp, E, drx, D, true)) return launch_candidate_rows<true>(dp, R, E, D, cand, Cn, drx, as_stream(stream));
     const int64_t blocks = std::min<int64_t>(cdiv(R, 4), 256 * 8);
-    hipLaunchKernelGGL(candidate_scores_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dp, R, E,
+    hipLaunchKernelGGL(candidate_scores_bwd_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), dp, R, E,
                        D, cand, Cn, drx);
     return check_launch("candidate_scores_bwd");
 }

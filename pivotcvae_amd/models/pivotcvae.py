@@ -89,7 +89,10 @@ class UserPivotCVAE(BaseCVAE):
         else:  # sgt: scores of the ground-truth pivot's own embedding against the catalog
             query = ops.gather_rows(self.docEmbed.weight, true_pivot)
         B = query.shape[0]
-        off = self._next_offset(B) if sample_offset is None else int(sample_offset)
+        if sample_offset is None:
+            off = self._next_offset(B)
+        else:   # an int, or (int, device word added to it) for a hipGraph-replayed step
+            off = sample_offset if isinstance(sample_offset, (tuple, list)) else int(sample_offset)
         return ops.catalog_sample(query, table, seed=self.rng_seed ^ 0x5A17, row_offset=off, prec=self.catalog_precision)
 
     def pick_pivot(self, pivot_output, true_pivot, sample_offset=None):

@@ -4,6 +4,7 @@ Every function takes ROCm tensors, marshals raw pointers + the current HIP strea
 libpcvae_hip.so and returns tensors allocated by torch's caching allocator.  Backward passes are
 hand-written (they call the backward kernels); nothing here falls back to eager PyTorch math.
 """
+import ctypes
 import os
 
 import torch
@@ -1035,6 +1036,22 @@ def x3_width(D):
     return X3_MAX_PADDED if D < X3_MAX_PADDED else None
 
 
+def _word(v):
+    """a seed / stream position given by value (int) or as a DEVICE word (a 1-element int64 tensor: a hipGraph-replayed step reads
+    it at run time, kernel arguments are frozen at capture) -> (by-value argument, device pointer or None)"""
+    if torch.is_tensor(v):
+        if v.numel() != 1 or v.dtype not in (torch.int64, torch.uint64) or not v.is_cuda:
+            raise TypeError("a device-word seed is a 1-element int64 tensor on the ROCm device")
+        return 0, ctypes.c_void_p(v.data_ptr())
+    return int(v), None
+
+
+def set_words_(words, a, b):
+    """words[0] = a, words[1] = b on the current stream (one tiny launch; the step-dependent words of a replayed hipGraph)"""
+    check(lib().pcvae_set_words(ptr(words, torch.int64), int(a) & 0xFFFFFFFFFFFFFFFF, int(b) & 0xFFFFFFFFFFFFFFFF, stream()), "set_words")
+    return words
+
+
 SPARSE_MAX_KEEP_PROB = 0.03   # above this the dense masked kernel (one pass over the catalog) is the cheaper one
 
 
@@ -1061,9 +1078,10 @@ def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, wa
     dx = torch.empty(R, D, dtype=F32, device=rx.device) if want_dx else None
     timing = CATALOG_CE_TIMING
     tok = timing[0]() if timing else None
-    check(lib().pcvae_catalog_ce_sparse_scaled(ptr(rx, F32), R, ptr(E, F32), N, D, ptr(target), float(keep_prob), int(seed),
-                                               int(row_offset), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), stream()),
-          "catalog_ce_sparse")
+    seed_val, seed_dev = _word(seed)
+    check(lib().pcvae_catalog_ce_sparse_scaled(ptr(rx, F32), R, ptr(E, F32), N, D, ptr(target), float(keep_prob), seed_val,
+                                               int(row_offset), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), seed_dev,
+                                               stream()), "catalog_ce_sparse")
     if timing:
         timing[1](tok)
     if dx is not None and D != D0:
@@ -1111,6 +1129,11 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
     prec = effective_precision(prec, D0)
     if keep_mask is None and keep_prob < 1.0 and sparse_ce_applies(keep_prob, N):
         return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx, dx_scale)
+    if torch.is_tensor(seed):
+        if keep_mask is None and keep_prob < 1.0:
+            raise RuntimeError("a device-word mask seed (hipGraph replay) exists for the sparse kept-rows kernel only "
+                               f"(keep_prob <= {SPARSE_MAX_KEEP_PROB})")
+        seed = 0   # no in-kernel draw in this call
     if keep_mask is not None or keep_prob < 1.0:
         prec = PREC_F32 if prec in (PREC_BF16X3, PREC_BF16X6) else prec   # masked calls: the split-bf16 kernels are max-free / mask-free
     E, E_lo = table.operands(prec)
@@ -1255,8 +1278,11 @@ def catalog_sample(x, table, seed=0, row_offset=0, prec=PREC_F32):
     ws = _workspace(x.device, lib().pcvae_catalog_ws_bytes(R, N, D, 0))
     timing = PIVOT_TIMING
     tok = timing[0]() if timing else None
-    check(lib().pcvae_catalog_sample(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, PREC_F32, int(seed), int(row_offset),
-                                     ptr(idx), ptr(ws), ws.numel(), stream()), "catalog_sample")
+    off_val, off_dev = (int(row_offset), None)
+    if isinstance(row_offset, (tuple, list)):    # (by-value part, device word added to it): a hipGraph-replayed step
+        off_val, off_dev = int(row_offset[0]), _word(row_offset[1])[1]
+    check(lib().pcvae_catalog_sample_at(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, PREC_F32, int(seed), off_val, off_dev,
+                                        ptr(idx), ptr(ws), ws.numel(), stream()), "catalog_sample")
     if timing:
         timing[1](tok)
     return idx
@@ -1347,9 +1373,10 @@ def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offs
     tcol = torch.empty(R, dtype=torch.int64, device=rx.device) if want_target else None
     timing = CATALOG_CE_TIMING   # the step's reconstruction kernel, whichever it is (bench.py times it on the launch stream)
     tok = timing[0]() if timing else None
-    check(lib().pcvae_candidate_ce(ptr(rx, F32), R, ptr(E, F32), N, D, Cn, ptr(feature), int(seed), int(row_offset), ptr(cand),
-                                   ptr(cand_target), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), ptr(tcol), stream()),
-          "candidate_ce")
+    seed_val, seed_dev = _word(seed)
+    check(lib().pcvae_candidate_ce(ptr(rx, F32), R, ptr(E, F32), N, D, Cn, ptr(feature), seed_val, int(row_offset), ptr(cand),
+                                   ptr(cand_target), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), ptr(tcol), seed_dev,
+                                   stream()), "candidate_ce")
     if timing:
         timing[1](tok)
     if dx is not None and D != D0:

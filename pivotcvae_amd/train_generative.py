@@ -149,8 +149,15 @@ class Trainer:
         # the SAMPLED pivot rules (spt / sgt): their sampler takes (seed, row offset) as kernel arguments too, a replayed graph
         # would redraw the same pivots every step.
         # The all-reduce and Adam stay outside the graph.
-        self.capture_graph = bool(capture_graph) and n_neg is None and n_candidate is None and loss_fn is None and \
-            getattr(model, "TRAIN_RULE", "gt") in ("gt", "pt")
+        # Round 5: the in-kernel draws no longer block capture - the sparse mask kernel, the fused candidate kernel and the rejection
+        # sampler can read their step-dependent word (seed / stream position) from DEVICE memory (``self._words``, written by one
+        # tiny launch before each replay).  What still stays eager: the dense masked kernels (n_neg / N > ops.SPARSE_MAX_KEEP_PROB),
+        # candidate sets handed in per step, an injected loss_fn.
+        N_items = model.docEmbed.weight.shape[0]
+        masked_ok = n_neg is None or ops.sparse_ce_applies(float(n_neg) / N_items, N_items)
+        self.capture_graph = bool(capture_graph) and loss_fn is None and masked_ok and \
+            (n_candidate is None or not isinstance(n_candidate, (tuple, list)))
+        self._words = None   # int64 [2] on the device: (mask / candidate seed = global step, sampler stream position) of the replayed step
         self._graph = None
         self._static = None
         # hipGraph replay reads its own static input buffers.  Default: the caller's s / r / u are copied into them on EVERY step
@@ -171,18 +178,19 @@ class Trainer:
         lo = self.rank * per
         return [t[lo:lo + per] for t in tensors], lo
 
-    def _local(self, s, r, u, eps, row_offset, eps_offset):
-        """zero-grad + local loss + backward (this rank's shard)."""
+    def _local(self, s, r, u, eps, row_offset, eps_offset, words=None):
+        """zero-grad + local loss + backward (this rank's shard).  ``words``: the device words of a captured step (the seed and the
+        sampler position are then read from them at run time; the by-value ones are what an eager step passes)."""
         B, S = s.shape
         self.opt.zero_grad()
         kw = dict(beta=self.beta, n_neg=self.n_neg, eps=eps, row_offset=row_offset, inv_count=1.0 / (B * S * self.world),
-                  eps_offset=eps_offset, mask_seed=self.global_step)
+                  eps_offset=eps_offset, mask_seed=self.global_step if words is None else words[0:1])
         if self.n_candidate is not None:
             kw["candidates"] = self.n_candidate
         if self._own_loss and getattr(self.model, "TRAIN_RULE", "gt") in ("spt", "sgt"):
             # sampled pivots: the sampler's stream position is the slate's GLOBAL index in the run, like eps - independent of how
-            # the batch is sharded over ranks
-            kw["sample_offset"] = eps_offset // self.model.latent_size
+            # the batch is sharded over ranks (captured step: this shard's offset by value + the step's base from the device word)
+            kw["sample_offset"] = eps_offset // self.model.latent_size if words is None else (row_offset, words[1:2])
         if self._own_loss:
             # d(rec + beta KLD) = 1 d rec + beta d KLD: seeding backward with the two constants saves the mul / add / fill / mul
             # launches of forming the sum and differentiating it (the logged loss is formed in step(), one launch)
@@ -204,6 +212,11 @@ class Trainer:
         Z = self.model.latent_size
         st = dict(s=s.clone(), r=r.clone(), u=u.clone(), eps=torch.zeros(B, Z, dtype=torch.float32, device=s.device),
                   row_offset=row_offset)
+        dynamic = self.n_neg is not None or self.n_candidate is not None or getattr(self.model, "TRAIN_RULE", "gt") in ("spt", "sgt")
+        if dynamic and self._words is None:
+            self._words = torch.zeros(2, dtype=torch.int64, device=s.device)
+        st["words"] = self._words if dynamic else None
+        st["mode"] = self._mode()
         torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -212,7 +225,7 @@ class Trainer:
         warm = {}
         with torch.cuda.stream(side), ops.workspace_holder(warm):  # warm-up: scratch buffers, bf16 table copies, kernel attributes
             for _ in range(2):
-                self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
+                self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0, st["words"])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         st["ws"] = {}
@@ -223,8 +236,14 @@ class Trainer:
         # thread_local: CUDA / HIP calls other threads make while this one captures (RCCL's watchdog polling its events) must not
         # invalidate the capture
         with torch.cuda.graph(graph, capture_error_mode="thread_local"), ops.workspace_holder(_FixedWorkspace(st["ws"])):
-            st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0)
+            st["out"] = self._local(st["s"], st["r"], st["u"], st["eps"], row_offset, 0, st["words"])
         self._graph, self._static = graph, st
+
+    def _mode(self):
+        """what a captured step has baked in besides shapes: the loss mode and the pivot rule (a step in another mode runs eagerly)"""
+        nc = self.n_candidate
+        return (self.n_neg, "given" if isinstance(nc, (tuple, list)) else nc, getattr(self.model, "TRAIN_RULE", "gt"),
+                getattr(self.model, "catalog_precision", None), getattr(self.model, "mlp_x3", None))
 
     def prepare_graph(self, s, r, u, row_offset=0):
         """Capture the hipGraph of a step for this batch shape now (no parameter update, no collective: two warm-up passes of
@@ -254,7 +273,7 @@ class Trainer:
         eps_offset = (self.global_step * gb + row_offset) * Z
         self.prepare_graph(s, r, u, row_offset)
         if self.capture_graph and self._graph is not None and tuple(s.shape) == tuple(self._static["s"].shape) \
-                and row_offset == self._static["row_offset"]:
+                and row_offset == self._static["row_offset"] and self._static["mode"] == self._mode():
             st = self._static
             # the graph reads its own input buffers: copy the caller's batch in, unless the caller promised (resident_batch) that
             # tensors it passes again are unchanged - then only weak references to the last batch are kept, nothing is pinned
@@ -270,6 +289,8 @@ class Trainer:
                 ops.philox_normal_(st["eps"], seed=self.model.rng_seed, offset=eps_offset)
             else:
                 st["eps"].copy_(eps)
+            if st["words"] is not None:   # this step's seed and the sampler's base position (eager: mask_seed, sample_offset - row_offset)
+                ops.set_words_(st["words"], self.global_step, eps_offset // Z - row_offset)
             self._graph.replay()
             loss, rec, kld = st["out"]
         else:

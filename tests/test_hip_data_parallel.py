@@ -212,7 +212,6 @@ def test_candidate_mode_and_sampled_pivots_under_sharding(W, tile_mode):
             m = make_model(N, S, D, "f32", variant=variant)
             m.rng_seed = 99
             tr = Trainer(m, lr=3e-4, beta=0.001, n_candidate=300, world_size=W if mode == "sharded" else None)
-            assert not tr.capture_graph
             out = []
             for _ in range(2):
                 st, g, e = simulated_step(tr, W, s, r, u) if mode == "sharded" else single_step(tr, s, r, u)
@@ -226,6 +225,35 @@ def test_candidate_mode_and_sampled_pivots_under_sharding(W, tile_mode):
             assert 0.5 * np.log(300) < st1[1] < 1.5 * np.log(300)     # a CE over 300 candidates, not over the catalog
             if k == 0:
                 grads_close(res["single"][0], gW, g1, tol=tile_mode)
+
+
+@pytest.mark.parametrize("mode", ["n_neg", "candidates", "sgt", "spt+candidates"])
+def test_graph_replay_of_the_in_kernel_draw_modes_follows_the_eager_trajectory(mode, monkeypatch):
+    """Round 5: the sparse mask kernel, the fused candidate kernel and the rejection sampler read their step-dependent word (seed /
+    stream position) from DEVICE memory when a step is captured, so these modes replay as a hipGraph too: four steps of a
+    captured trainer (a rank in the middle of a sharded batch: row_offset > 0) equal four eager steps - the draws are the same ones
+    (same seeds, same positions), so ELBO terms agree to rounding and the parameters to Adam's step noise - and consecutive steps
+    really draw differently."""
+    from pivotcvae_amd.train_generative import Trainer
+    monkeypatch.setenv("PCVAE_GEMM_SMALL_BELOW", "0")   # one GEMM tile path in both runs
+    N, S, D, B, gb, lo = 50021, 10, 128, 64, 256, 128
+    s, r, u = batch(N, S, B, seed=8)
+    variant = {"sgt": "pivotcvae_sgt_pi", "spt+candidates": "pivotcvae_spt_pi"}.get(mode, "pivotcvae_gt_pi")
+    kw = {"n_neg": dict(n_neg=1000), "candidates": dict(n_candidate=300), "sgt": {}, "spt+candidates": dict(n_candidate=200)}[mode]
+    runs = []
+    for graph in (False, True):
+        m = make_model(N, S, D, "f32", variant=variant)
+        m.rng_seed = 77
+        tr = Trainer(m, lr=3e-4, beta=0.001, capture_graph=graph, **kw)
+        out = [[float(x) for x in tr.step(s, r, u, global_batch=gb, row_offset=lo)] for _ in range(4)]
+        assert tr.capture_graph == graph and (tr._graph is not None) == graph and tr.capture_failed is None
+        runs.append((out, tr.opt.flat.clone(), m.last_pivot.clone()))
+    (e_out, e_flat, e_piv), (g_out, g_flat, g_piv) = runs
+    np.testing.assert_allclose(g_out, e_out, rtol=5e-6)
+    assert e_out[0][1] != e_out[1][1] and e_out[1][1] != e_out[2][1]
+    assert torch.equal(e_piv, g_piv)                          # the last step's (sampled) pivots: the same stream position
+    diff = (g_flat - e_flat).abs()
+    assert float(diff.max()) <= 2.001 * 3e-4 * 4 and float((diff > 3e-6).float().mean()) < 2e-3
 
 
 def test_in_kernel_streams_are_bitwise_independent_of_the_sharding():
