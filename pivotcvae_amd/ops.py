@@ -1278,9 +1278,10 @@ def catalog_sample(x, table, seed=0, row_offset=0, prec=PREC_F32):
     ws = _workspace(x.device, lib().pcvae_catalog_ws_bytes(R, N, D, 0))
     timing = PIVOT_TIMING
     tok = timing[0]() if timing else None
-    off_val, off_dev = (int(row_offset), None)
     if isinstance(row_offset, (tuple, list)):    # (by-value part, device word added to it): a hipGraph-replayed step
         off_val, off_dev = int(row_offset[0]), _word(row_offset[1])[1]
+    else:
+        off_val, off_dev = int(row_offset), None
     check(lib().pcvae_catalog_sample_at(ptr(x, F32), R, ptr(E), ptr(E_lo), N, D, PREC_F32, int(seed), off_val, off_dev,
                                         ptr(idx), ptr(ws), ws.numel(), stream()), "catalog_sample")
     if timing:
