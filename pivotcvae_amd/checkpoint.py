@@ -7,7 +7,9 @@ class by the reference's module path (``models.pivotcvae.UserPivotCVAE``, ``env.
 does not exist next to this package - and the reference's own ``__dict__`` layout is not the product's.  So:
 
   1. the pickle is read with an ``Unpickler`` whose ``find_class`` maps every class of the reference's model / environment modules
-     to an inert shell ``nn.Module`` (no reference code is imported or needed; torch's own classes resolve as usual);
+     to an inert shell ``nn.Module`` (no reference code is imported or needed) and resolves ONLY an allowlist of other globals
+     (torch's tensor / parameter rebuild functions, ``nn.Module`` layer classes, ``OrderedDict``, a few builtins): anything else
+     raises ``UnpicklingError`` instead of being imported and called - ``torch.load(weights_only=False)`` on its own would run it;
   2. the shell holds what the reference object held: hyper-parameters as attributes, parameters through ``state_dict()``;
   3. the PRODUCT class of the same name is built through its normal constructor from those hyper-parameters and takes the
      shell's ``state_dict`` (key names are identical by design: SURVEY.md 8b) - bit for bit, the frozen tables included.
@@ -42,11 +44,40 @@ def _shell(module, name):
     return _shells[key]
 
 
+# Everything ELSE a module pickle may name: an allowlist.  torch.load(weights_only=False) runs a full pickle machine - a "checkpoint"
+# may name any importable callable and have it called on load - so the unpickler here refuses every global that a whole-module pickle
+# of these model classes does not need.  (What it still trusts: torch's own tensor / parameter rebuild functions and nn.Module
+# classes.  A checkpoint from an untrusted source is better converted to a state_dict by its owner.)
+_ALLOWED = {
+    "collections": {"OrderedDict", "defaultdict"},
+    "builtins": {"set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "complex", "bytes", "bytearray", "slice",
+                 "range", "object", "str"},
+    "torch._utils": {"_rebuild_tensor_v2", "_rebuild_tensor", "_rebuild_parameter", "_rebuild_parameter_with_state",
+                     "_rebuild_qtensor", "_rebuild_device_tensor_from_numpy"},
+    "torch": {"Size", "device", "dtype", "Tensor", "FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage",
+              "IntStorage", "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "float32", "float64", "float16", "bfloat16",
+              "int64", "int32", "int16", "int8", "uint8", "bool"},
+    "torch.storage": {"UntypedStorage", "TypedStorage", "_load_from_bytes"},
+    "torch.nn.parameter": {"Parameter", "Buffer"},
+    "torch._tensor": {"_rebuild_from_type_v2"},
+    "numpy.core.multiarray": {"_reconstruct", "scalar"}, "numpy._core.multiarray": {"_reconstruct", "scalar"},
+    "numpy": {"ndarray", "dtype"}, "_codecs": {"encode"}, "copyreg": {"_reconstructor"},
+}
+_ALLOWED["__builtin__"] = _ALLOWED["builtins"]   # (Python-2 style name pickle still emits for set)
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         if module in _REF_MODULES:
             return _shell(module, name)
-        return super().find_class(module, name)
+        if name in _ALLOWED.get(module, ()):
+            return super().find_class(module, name)
+        if module.startswith("torch.nn.modules."):   # the layers a model holds: nn.Module subclasses only, nothing callable besides
+            obj = super().find_class(module, name)
+            if isinstance(obj, type) and issubclass(obj, nn.Module):
+                return obj
+        raise pickle.UnpicklingError(f"reference checkpoint names {module}.{name}: not something a pickled PivotCVAE / click-model "
+                                     "module needs - refused (pivotcvae_amd.checkpoint loads model pickles, not arbitrary ones)")
 
 
 class _PickleModule:

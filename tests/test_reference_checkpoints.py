@@ -90,3 +90,21 @@ def test_loaded_reference_models_behave_as_the_reference_did():
     rm = ck.load_reference_pickle(CLICK, device=DEV)
     logits = rm(gr.t("s").to(DEV), gr.t("u").to(DEV))
     torch.testing.assert_close(logits.cpu(), gr.t("logits"), rtol=1e-5, atol=1e-5)   # G7
+
+
+def test_a_pickle_that_names_anything_else_is_refused(tmp_path):
+    """torch.load(weights_only=False) is a full pickle machine; the checkpoint reader resolves the reference's classes to inert
+    shells and an allowlist of what a module pickle needs - a "checkpoint" that names any other callable is refused, not run"""
+    import pickle
+    from pivotcvae_amd.checkpoint import read_reference_pickle
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > " + str(tmp_path / "pwned"),))
+
+    path = tmp_path / "evil.pt"
+    torch.save({"model": Evil()}, open(path, "wb"))
+    with pytest.raises(pickle.UnpicklingError, match="refused"):
+        read_reference_pickle(str(path))
+    assert not (tmp_path / "pwned").exists()
