@@ -642,7 +642,7 @@ ARITH = {"f32": ("f32", PEAK_TFLOPS["f32"], 1), "bf16": ("bf16", PEAK_TFLOPS["bf
 GATHER_L2_TBPS, GATHER_FABRIC_TBPS, HBM_TBPS = 17.8, 8.6, 8.0
 
 
-def sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic=None):
+def sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic=None, elem_bytes=4):
     """The sparse (n_neg << N) kernel is a row gather: R (n_neg + 1) rows of 4 D bytes REQUESTED, out of a table of only 4 N D bytes
     - every table row is re-read ~R n_neg / N times, so most requests are served by the caches, not by HBM, and pricing the
     requested bytes against the HBM peak is not a roofline (round 2 did: 0.93 at config 4, 1.10 at config 3).  The bound here is a
@@ -651,8 +651,8 @@ def sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic=None):
     the rest comes over the fabric from the Infinity Cache / HBM).  frac = that time / the measured time, always <= 1 unless the
     kernel beats the guide's gather loop.  `traffic` = the L2's memory-side bytes of one launch from the committed rocprofv3
     FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json; on gfx950 Infinity-Cache hits are included in it)."""
-    requested = float(R_local) * sparse_kept * D * 4
-    table = float(N) * D * 4
+    requested = float(R_local) * sparse_kept * D * elem_bytes   # (elem_bytes = 2: the bf16-row variants of configs 3 / 5)
+    table = float(N) * D * elem_bytes
     compulsory = min(table, requested) + float(R_local) * (2 * D * 4 + 8 + 8)   # table once + rx read + dx written + nll, lse
     reread = max(requested - min(table, requested), 0.0)
     h = min(1.0, 4.0 * 2 ** 20 / table)   # share of uniformly random requests an XCD's L2 serves
@@ -672,19 +672,21 @@ def sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic=None):
                           f"{requested / 1e9:.1f} GB are requested out of a {table / 1e9:.2f} GB table"}
 
 
-def candidate_roofline(R_local, N, D, Cn, kern_ms, traffic=None):
+def candidate_roofline(R_local, N, D, Cn, kern_ms, traffic=None, bf16_rows=False):
     """the fused candidate-set kernel is the same uniformly random row gather as the sparse kernel - R (Cn + 1) rows of 4 D bytes
     requested (Cn candidates + the target row once more for the gradient) - priced on the same cache + HBM gather-time model"""
-    out = sparse_roofline(f"candidate_ce_kernel<{D}, true>", R_local, N, D, kern_ms, Cn + 1, traffic)
+    out = sparse_roofline(f"candidate_ce_kernel<{D}, true, {'true' if bf16_rows else 'false'}>", R_local, N, D, kern_ms, Cn + 1, traffic,
+                          elem_bytes=2 if bf16_rows else 4)
+    out["rows"] = "bf16 table rows widened exactly, fp32 products and sums" if bf16_rows else "fp32 table rows (the reference's arithmetic)"
     out["replaces"] = ("candidate_draw -> [R, Cn] int64 ids -> candidate_scores_kernel -> [R, Cn] p -> dense_ce_kernel -> [R, Cn] dp -> "
                        "candidate_scores_bwd_kernel (the reference: randint on the host + embedding [R, Cn, D] + bmm + CrossEntropyLoss "
                        "+ autograd); none of those arrays exists here")
     return out
 
 
-def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None, traffic=None):
+def roofline_block(name, R_local, N, D, dtype, kern_ms, sparse_kept=None, traffic=None, bf16_rows=False):
     if sparse_kept is not None:
-        return sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic)
+        return sparse_roofline(name, R_local, N, D, kern_ms, sparse_kept, traffic, elem_bytes=2 if bf16_rows else 4)
     flops = 4.0 * R_local * N * D   # logits 2RND + gradient direction 2RND (SURVEY.md 8d)
     _, peak, mult = ARITH[dtype]
     ach = flops / (kern_ms * 1e-3) / 1e12 if kern_ms > 0 else 0.0
@@ -951,14 +953,18 @@ def main():
     loss, rec, kld = res["elbo"]
     sparse = args.n_neg is not None and ops.sparse_ce_applies(args.n_neg / N, N)
     cand_mode = args.n_candidate is not None
+    # the gather kernels read bf16 rows where the config's stated arithmetic is bf16 (configs 3 / 5), the fp32 table otherwise
+    bf16_rows = args.dtype == "bf16" and D in ops.BF16_DIMS
+    rows_dtype = "bf16 rows, fp32 accumulate" if bf16_rows else "f32"
     if cand_mode:
         roof = candidate_roofline(R_local, N, D, args.n_candidate, kern_ms,
-                                  committed_traffic(f"config{args.config}_cand{args.n_candidate}_gpus{world}"))
+                                  committed_traffic(f"config{args.config}_cand{args.n_candidate}_gpus{world}"), bf16_rows)
         sparse = True
     else:
         roof = roofline_block(kernel_name(R_local, N, D, args.dtype) if not sparse else "catalog_ce_sparse_kernel",
                               R_local, N, D, args.dtype, kern_ms, sparse_kept=(args.n_neg + 1) if sparse else None,
-                              traffic=committed_traffic(f"config{args.config}_nneg{args.n_neg}_gpus{world}") if sparse else None)
+                              traffic=committed_traffic(f"config{args.config}_nneg{args.n_neg}_gpus{world}") if sparse else None,
+                              bf16_rows=bf16_rows)
     if not sparse:
         roof["kernel"] += " (events also span its row-bound prologue and merge kernels, <1% together)"
         roof["traffic"] = committed_traffic(f"config{args.config}_{args.dtype}_gpus{world}")
@@ -971,7 +977,7 @@ def main():
                   else f"slates/sec config {args.config}",
         "value": B * args.steps / dt, "unit": "slates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": ARITH[args.dtype][0], "data": "synthetic",
+        "dtype": rows_dtype if (cand_mode or sparse) else ARITH[args.dtype][0], "data": "synthetic",
         "config": {"workload": f"{'ListCVAE' if cfg.get('model') == 'listcvae' else 'PivotCVAE ' + cfg.get('model', 'pivotcvae_gt_pi')[10:]} train step (fwd+bwd+Adam), catalog N={N} slate K={S} emb D={D} "
                                f"global batch B={B}, " + (f"candidate sets of {args.n_candidate} ids per slot drawn in-kernel (the reference's default mode: no --mask_train)"
                                                           if cand_mode else "full-catalog softmax" + ("" if args.n_neg is None else f" n_neg={args.n_neg}")),
@@ -1022,22 +1028,23 @@ def main():
         if args.n_neg is None and N >= 100_000:
             v = light_variant(n_neg=1000)   # train_generative.py:44 default; in-kernel Philox keep set (sparse path: only kept rows are read)
             variants["n_neg_1000"] = {"value": B * v["steps"] / v["dt"], "unit": "slates/s", "ms_per_step": v["dt"] / v["steps"] * 1e3,
-                                      "dtype": "f32", "launch": v["launch"],
+                                      "dtype": rows_dtype, "launch": v["launch"],
                                       "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
                                       "roofline": roofline_block("catalog_ce_sparse_kernel", R_local, N, D, "f32", v["kern_ms"],
                                                                  sparse_kept=1001,
-                                                                 traffic=committed_traffic(f"config{args.config}_nneg1000_gpus{world}"))}
+                                                                 traffic=committed_traffic(f"config{args.config}_nneg1000_gpus{world}"),
+                                                                 bf16_rows=bf16_rows)}
         if args.n_neg is None and not cand_mode and N >= 100_000:
             # the reference's DEFAULT mode (train_generative.py:270-274: candidate sets unless --mask_train; my_utils.py:169
             # --nneg 1000): ONE fused launch per step draws the sets, gathers, scores, takes the CE and the gradient
             for cn in (1000, 50):
                 v = light_variant(n_candidate=cn)
                 variants[f"candidates_nneg{cn}"] = {
-                    "value": B * v["steps"] / v["dt"], "unit": "slates/s", "ms_per_step": v["dt"] / v["steps"] * 1e3, "dtype": "f32",
+                    "value": B * v["steps"] / v["dt"], "unit": "slates/s", "ms_per_step": v["dt"] / v["steps"] * 1e3, "dtype": rows_dtype,
                     "launch": v["launch"],
                     "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
                     "roofline": candidate_roofline(R_local, N, D, cn, v["kern_ms"],
-                                                   committed_traffic(f"config{args.config}_cand{cn}_gpus{world}"))}
+                                                   committed_traffic(f"config{args.config}_cand{cn}_gpus{world}"), bf16_rows)}
         trainer.capture_graph = was_graph
         out["variants"] = variants
     if single and not args.no_variants and cfg.get("model") != "listcvae" and N * D <= 2.6e8:

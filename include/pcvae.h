@@ -270,7 +270,7 @@ int pcvae_catalog_ce_sparse(const float* rx, int64_t R, const float* E, int64_t 
                             pcvae_stream_t stream);
 /* the same two calls writing dx * dx_scale: the 1 / (rows * world_size) of CrossEntropyLoss's mean folded into the kernel, so that
  * the backward of the mean-reduced loss needs no scaling launch when the upstream gradient is 1 (train_generative.py:59,133)  */
-int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
+int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const void* E, int prec, int64_t N, int D, const int64_t* target,
                                    float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
                                    float dx_scale, const uint64_t* seed_dev, pcvae_stream_t stream);
 int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E, const void* E_lo, int64_t N, int D, int prec,
@@ -345,8 +345,11 @@ int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, const int64_t*
  *     s_c = <rx_r, E[id_c]> (fp32 fmaf chains) ;  nll[r] = logsumexp_c s_c - s_t ;  lse[r] optional ;
  *     dx[r, :] = dx_scale * (sum_c softmax_c E[id_c] - E[id_t])  (optional) ;  tgt_out[r] = the target column used (optional).
  *     A candidate id or target outside its range makes that row's outputs NaN (the reference raises an index error).
- *     D in {16, 32, 64, 128, 256} (other widths: zero-padded by the caller), N < 2^31 - 1.                                  */
-int pcvae_candidate_ce(const float* rx, int64_t R, const float* E, int64_t N, int D, int Cn, const int64_t* feature,
+ *     D in {16, 32, 64, 128, 256} (other widths: zero-padded by the caller), N < 2^31 - 1.
+ *     prec = PCVAE_PREC_F32: E = the fp32 table (the reference's arithmetic).  prec = PCVAE_PREC_BF16 (here and in
+ *     pcvae_catalog_ce_sparse_scaled): E = the bf16 copy of pcvae_split_bf16 - half the gathered bytes; rows are widened exactly,
+ *     products and sums stay fp32 (the stated arithmetic of configs 3 / 5; tolerances of the bf16 catalog kernels).           */
+int pcvae_candidate_ce(const float* rx, int64_t R, const void* E, int prec, int64_t N, int D, int Cn, const int64_t* feature,
                        uint64_t seed, uint64_t row_offset, const int64_t* cand, const int64_t* cand_target, float* nll,
                        float* lse, float* dx, float dx_scale, int64_t* tgt_out, const uint64_t* seed_dev, pcvae_stream_t stream);
 /*     seed_dev (here, in pcvae_catalog_ce_sparse_scaled; row_offset_dev in pcvae_catalog_sample_at): NULL, or a device word the

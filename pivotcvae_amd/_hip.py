@@ -66,7 +66,7 @@ SIGNATURES = {
     "pcvae_catalog_ce_variant": [_L, _L, _I, _I],
     "pcvae_catalog_ce": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _F, _U64, _U64, _P, _P, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_ce_sparse": [_P, _L, _P, _L, _I, _P, _F, _U64, _U64, _P, _P, _P, _P],
-    "pcvae_catalog_ce_sparse_scaled": [_P, _L, _P, _L, _I, _P, _F, _U64, _U64, _P, _P, _P, _F, _P, _P],
+    "pcvae_catalog_ce_sparse_scaled": [_P, _L, _P, _I, _L, _I, _P, _F, _U64, _U64, _P, _P, _P, _F, _P, _P],
     "pcvae_catalog_ce_scaled": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _F, _U64, _U64, _P, _P, _P, _P, _F, _P, _SZ, _P],
     "pcvae_catalog_argmax": [_P, _L, _P, _P, _L, _I, _I, _F, _P, _P, _P, _SZ, _P],
     "pcvae_catalog_sample": [_P, _L, _P, _P, _L, _I, _I, _U64, _U64, _P, _P, _SZ, _P],
@@ -79,7 +79,7 @@ SIGNATURES = {
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_candidate_scores_bwd": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],
-    "pcvae_candidate_ce": [_P, _L, _P, _L, _I, _I, _P, _U64, _U64, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "pcvae_candidate_ce": [_P, _L, _P, _I, _L, _I, _I, _P, _U64, _U64, _P, _P, _P, _P, _P, _F, _P, _P, _P],
     "pcvae_set_words": [_P, _U64, _U64, _P],
     "pcvae_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "pcvae_adam_step_l2": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _F, _P],

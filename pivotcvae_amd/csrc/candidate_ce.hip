@@ -20,11 +20,10 @@ using namespace pcvae;
 namespace {
 
 constexpr int CC_CAP = 2048;   // ids per wave and LDS batch (4 waves x 8 KB); Cn <= CC_CAP is one batch
-constexpr int CC_UNR = 4;      // lane-group steps in flight per lane (2 x 16-byte loads each)
 
 struct CandParams {
     const float* rx;             // [R, D]
-    const float* E;              // [N, D] fp32
+    const void* E;               // [N, D] fp32, or bf16 (the BF16 instantiations)
     const int64_t* feature;      // [R] true items              (drawn mode: cand == null)
     const int64_t* cand;         // [R, Cn] given candidate ids (given mode) or null
     const int64_t* cand_target;  // [R] target columns          (given mode)
@@ -44,8 +43,9 @@ __device__ __forceinline__ void cc_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int D, bool WANT_DX>
+template <int D, bool WANT_DX, bool BF16>
 __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
+    using Row = GatherRow<D, BF16>;
     constexpr int LPI = D / 8;            // lanes per item: a lane holds columns [4 j, 4 j + 4) and [D/2 + 4 j, D/2 + 4 j + 4)
     constexpr int IPS = 64 / LPI;         // items per step of a wave
     __shared__ int lst_all[4][CC_CAP];
@@ -56,8 +56,8 @@ __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
     const int j = lane % LPI, grp = lane / LPI;
     const int Cn = p.Cn;
 
-    const float4 xa = *reinterpret_cast<const float4*>(p.rx + r * D + 4 * j);
-    const float4 xb = *reinterpret_cast<const float4*>(p.rx + r * D + D / 2 + 4 * j);
+    const float4 xa = *reinterpret_cast<const float4*>(p.rx + r * D + Row::col_a(j));
+    const float4 xb = *reinterpret_cast<const float4*>(p.rx + r * D + Row::col_b(j));
     const uint64_t grow = p.row_offset + (uint64_t)r;
     const uint64_t seed = p.seed_dev ? *p.seed_dev : p.seed;
     const bool drawn = p.cand == nullptr;
@@ -128,23 +128,22 @@ __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
         if (overwrite && c0 == 0 && lane == 0) lst[0] = t_ok ? (int)f : 0;   // (lane 0 drew column 0 itself: same-thread ordering)
         cc_wave_sync();   // the list is read back by other lanes of this wave
 
-        for (int i0 = 0; i0 < cnt; i0 += IPS * CC_UNR) {
-            float4 ea[CC_UNR], eb[CC_UNR];
-            bool ok[CC_UNR];
+        for (int i0 = 0; i0 < cnt; i0 += IPS * Row::UNR) {
+            typename Row::Raw raw[Row::UNR];
+            bool ok[Row::UNR];
 #pragma unroll
-            for (int u = 0; u < CC_UNR; ++u) {
+            for (int u = 0; u < Row::UNR; ++u) {
                 const int i = i0 + u * IPS + grp;
                 ok[u] = i < cnt;
-                const int64_t n = ok[u] ? (int64_t)lst[i] : 0;
-                const float* e = p.E + n * D;
-                ea[u] = ok[u] ? *reinterpret_cast<const float4*>(e + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-                eb[u] = ok[u] ? *reinterpret_cast<const float4*>(e + D / 2 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                raw[u] = ok[u] ? Row::load_raw(p.E, (int64_t)lst[i], j) : Row::zero();
             }
 #pragma unroll
-            for (int u = 0; u < CC_UNR; ++u) {
-                float s = ea[u].x * xa.x;
-                s = fmaf(ea[u].y, xa.y, s); s = fmaf(ea[u].z, xa.z, s); s = fmaf(ea[u].w, xa.w, s);
-                s = fmaf(eb[u].x, xb.x, s); s = fmaf(eb[u].y, xb.y, s); s = fmaf(eb[u].z, xb.z, s); s = fmaf(eb[u].w, xb.w, s);
+            for (int u = 0; u < Row::UNR; ++u) {
+                float4 ea_u, eb_u;
+                Row::widen(raw[u], ea_u, eb_u);
+                float s = ea_u.x * xa.x;
+                s = fmaf(ea_u.y, xa.y, s); s = fmaf(ea_u.z, xa.z, s); s = fmaf(ea_u.w, xa.w, s);
+                s = fmaf(eb_u.x, xb.x, s); s = fmaf(eb_u.y, xb.y, s); s = fmaf(eb_u.z, xb.z, s); s = fmaf(eb_u.w, xb.w, s);
 #pragma unroll
                 for (int o = 1; o < LPI; o <<= 1) s += __shfl_xor(s, o, 64);   // every lane of the group holds the logit
                 if (ok[u]) {
@@ -154,10 +153,10 @@ __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
                     const float pe = __expf(s - m_new);
                     l = l * sc + pe;
                     if (WANT_DX) {
-                        ua.x = fmaf(pe, ea[u].x, ua.x * sc); ua.y = fmaf(pe, ea[u].y, ua.y * sc);
-                        ua.z = fmaf(pe, ea[u].z, ua.z * sc); ua.w = fmaf(pe, ea[u].w, ua.w * sc);
-                        ub.x = fmaf(pe, eb[u].x, ub.x * sc); ub.y = fmaf(pe, eb[u].y, ub.y * sc);
-                        ub.z = fmaf(pe, eb[u].z, ub.z * sc); ub.w = fmaf(pe, eb[u].w, ub.w * sc);
+                        ua.x = fmaf(pe, ea_u.x, ua.x * sc); ua.y = fmaf(pe, ea_u.y, ua.y * sc);
+                        ua.z = fmaf(pe, ea_u.z, ua.z * sc); ua.w = fmaf(pe, ea_u.w, ua.w * sc);
+                        ub.x = fmaf(pe, eb_u.x, ub.x * sc); ub.y = fmaf(pe, eb_u.y, ub.y * sc);
+                        ub.z = fmaf(pe, eb_u.z, ub.z * sc); ub.w = fmaf(pe, eb_u.w, ub.w * sc);
                     }
                     m = m_new;
                 }
@@ -194,31 +193,35 @@ __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
         float4 ta = make_float4(NAN, NAN, NAN, NAN), tb = ta;
         if (!poison) {
             const float w = p.dx_scale / l, q = p.dx_scale;
-            const float4 a = *reinterpret_cast<const float4*>(p.E + tid * D + 4 * j);
-            const float4 b = *reinterpret_cast<const float4*>(p.E + tid * D + D / 2 + 4 * j);
+            float4 a, b;
+            Row::load(p.E, tid, j, a, b);
             ta = make_float4(ua.x * w - a.x * q, ua.y * w - a.y * q, ua.z * w - a.z * q, ua.w * w - a.w * q);
             tb = make_float4(ub.x * w - b.x * q, ub.y * w - b.y * q, ub.z * w - b.z * q, ub.w * w - b.w * q);
         }
-        *reinterpret_cast<float4*>(p.dx + r * D + 4 * j) = ta;
-        *reinterpret_cast<float4*>(p.dx + r * D + D / 2 + 4 * j) = tb;
+        *reinterpret_cast<float4*>(p.dx + r * D + Row::col_a(j)) = ta;
+        *reinterpret_cast<float4*>(p.dx + r * D + Row::col_b(j)) = tb;
     }
 }
 
 template <int D>
-int launch_cand(const CandParams& p, hipStream_t st) {
+int launch_cand(const CandParams& p, bool bf16, hipStream_t st) {
     const dim3 grid((unsigned)cdiv(p.R, 4)), block(256);
-    if (p.dx) PCVAE_LAUNCH_TIMED(PCVAE_TIMER_CANDIDATE_CE, (candidate_ce_kernel<D, true>), grid, block, 0, st, p);
-    else PCVAE_LAUNCH_TIMED(PCVAE_TIMER_CANDIDATE_CE, (candidate_ce_kernel<D, false>), grid, block, 0, st, p);
+#define PCVAE_CAND(DXV, BFV) PCVAE_LAUNCH_TIMED(PCVAE_TIMER_CANDIDATE_CE, (candidate_ce_kernel<D, DXV, BFV>), grid, block, 0, st, p)
+    if (p.dx) { if (bf16) PCVAE_CAND(true, true); else PCVAE_CAND(true, false); }
+    else { if (bf16) PCVAE_CAND(false, true); else PCVAE_CAND(false, false); }
+#undef PCVAE_CAND
     return check_launch("candidate_ce");
 }
 
 }  // namespace
 
-extern "C" int pcvae_candidate_ce(const float* rx, int64_t R, const float* E, int64_t N, int D, int Cn, const int64_t* feature,
+extern "C" int pcvae_candidate_ce(const float* rx, int64_t R, const void* E, int prec, int64_t N, int D, int Cn, const int64_t* feature,
                                   uint64_t seed, uint64_t row_offset, const int64_t* cand, const int64_t* cand_target, float* nll,
                                   float* lse, float* dx, float dx_scale, int64_t* tgt_out, const uint64_t* seed_dev,
                                   pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && nll, "candidate_ce: null pointer");
+    PCVAE_REQUIRE(prec == PCVAE_PREC_F32 || prec == PCVAE_PREC_BF16, "candidate_ce: precision mode %d (fp32 or bf16 table rows)", prec);
+    const bool bf16 = prec == PCVAE_PREC_BF16;
     PCVAE_REQUIRE((cand != nullptr) == (cand_target != nullptr), "candidate_ce: cand and cand_target come together");
     PCVAE_REQUIRE(cand || feature, "candidate_ce: give the slots' true items (feature) or candidate sets (cand + cand_target)");
     PCVAE_REQUIRE(R >= 0 && N > 0 && N < 2147483647LL && Cn > 0, "candidate_ce: bad problem R=%lld N=%lld Cn=%d", (long long)R,
@@ -230,11 +233,11 @@ extern "C" int pcvae_candidate_ce(const float* rx, int64_t R, const float* E, in
     CandParams p{rx, E, feature, cand, cand_target, R, N, Cn, seed, row_offset, ~0ull / (uint64_t)N, seed_dev, nll, lse, dx, dx_scale,
                  tgt_out};
     switch (D) {
-        case 16: return launch_cand<16>(p, as_stream(stream));
-        case 32: return launch_cand<32>(p, as_stream(stream));
-        case 64: return launch_cand<64>(p, as_stream(stream));
-        case 128: return launch_cand<128>(p, as_stream(stream));
-        case 256: return launch_cand<256>(p, as_stream(stream));
+        case 16: return launch_cand<16>(p, bf16, as_stream(stream));
+        case 32: return launch_cand<32>(p, bf16, as_stream(stream));
+        case 64: return launch_cand<64>(p, bf16, as_stream(stream));
+        case 128: return launch_cand<128>(p, bf16, as_stream(stream));
+        case 256: return launch_cand<256>(p, bf16, as_stream(stream));
     }
     pcvae::set_error("candidate_ce: unsupported D=%d (16, 32, 64, 128, 256)", D);
     return PCVAE_EINVAL;

@@ -22,12 +22,11 @@ using namespace pcvae;
 namespace {
 
 constexpr int SP_CAP = 2048;          // kept-list entries per wave and batch (LDS: 4 waves x 8 KB)
-constexpr int SP_UNR = 4;             // item groups in flight per lane (2 x 16-byte loads each)
 constexpr uint32_t SP_TAG = 0x53504152u;   // "SPAR"
 
 struct SparseParams {
     const float* rx;        // [R, D]
-    const float* E;         // [N, D] fp32
+    const void* E;          // [N, D] fp32, or bf16 (the BF16 instantiations)
     const int64_t* target;  // [R]
     int64_t R, N;
     uint64_t seed, row_offset;
@@ -53,8 +52,9 @@ __device__ __forceinline__ void sp_wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int D, bool WANT_DX>
+template <int D, bool WANT_DX, bool BF16>
 __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) {
+    using Row = GatherRow<D, BF16>;
     constexpr int LPI = D / 8;            // lanes per item: a lane holds columns [4 j, 4 j + 4) and [D/2 + 4 j, D/2 + 4 j + 4)
     constexpr int IPS = 64 / LPI;         // items per step of a wave
     __shared__ int lst_all[4][SP_CAP];
@@ -64,8 +64,8 @@ __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) 
     int* lst = lst_all[wave];
     const int j = lane % LPI, grp = lane / LPI;
 
-    const float4 xa = *reinterpret_cast<const float4*>(p.rx + r * D + 4 * j);
-    const float4 xb = *reinterpret_cast<const float4*>(p.rx + r * D + D / 2 + 4 * j);
+    const float4 xa = *reinterpret_cast<const float4*>(p.rx + r * D + Row::col_a(j));
+    const float4 xb = *reinterpret_cast<const float4*>(p.rx + r * D + Row::col_b(j));
     const int64_t tgt = p.target[r];
     const bool t_ok = tgt >= 0 && tgt < p.N;
     const uint64_t grow = p.row_offset + (uint64_t)r;
@@ -121,24 +121,23 @@ __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) 
         n_kept += cnt;
         sp_wave_sync();   // the list is read back by other lanes of this wave
 
-        // ---- gather + dot + online softmax, IPS items per step, SP_UNR steps in flight
-        for (int i0 = 0; i0 < cnt; i0 += IPS * SP_UNR) {
-            float4 ea[SP_UNR], eb[SP_UNR];
-            bool ok[SP_UNR];
+        // ---- gather + dot + online softmax, IPS items per step, GatherRow::UNR steps in flight
+        for (int i0 = 0; i0 < cnt; i0 += IPS * Row::UNR) {
+            typename Row::Raw raw[Row::UNR];
+            bool ok[Row::UNR];
 #pragma unroll
-            for (int u = 0; u < SP_UNR; ++u) {
+            for (int u = 0; u < Row::UNR; ++u) {
                 const int i = i0 + u * IPS + grp;
                 ok[u] = i < cnt;
-                const int64_t n = ok[u] ? (int64_t)lst[i] : 0;
-                const float* e = p.E + n * D;
-                ea[u] = ok[u] ? *reinterpret_cast<const float4*>(e + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
-                eb[u] = ok[u] ? *reinterpret_cast<const float4*>(e + D / 2 + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                raw[u] = ok[u] ? Row::load_raw(p.E, (int64_t)lst[i], j) : Row::zero();
             }
 #pragma unroll
-            for (int u = 0; u < SP_UNR; ++u) {
-                float s = ea[u].x * xa.x;
-                s = fmaf(ea[u].y, xa.y, s); s = fmaf(ea[u].z, xa.z, s); s = fmaf(ea[u].w, xa.w, s);
-                s = fmaf(eb[u].x, xb.x, s); s = fmaf(eb[u].y, xb.y, s); s = fmaf(eb[u].z, xb.z, s); s = fmaf(eb[u].w, xb.w, s);
+            for (int u = 0; u < Row::UNR; ++u) {
+                float4 ea_u, eb_u;
+                Row::widen(raw[u], ea_u, eb_u);
+                float s = ea_u.x * xa.x;
+                s = fmaf(ea_u.y, xa.y, s); s = fmaf(ea_u.z, xa.z, s); s = fmaf(ea_u.w, xa.w, s);
+                s = fmaf(eb_u.x, xb.x, s); s = fmaf(eb_u.y, xb.y, s); s = fmaf(eb_u.z, xb.z, s); s = fmaf(eb_u.w, xb.w, s);
 #pragma unroll
                 for (int o = 1; o < LPI; o <<= 1) s += __shfl_xor(s, o, 64);   // every lane of the group holds the logit
                 if (ok[u]) {
@@ -148,10 +147,10 @@ __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) 
                     const float pe = __expf(s - m_new);
                     l = l * sc + pe;
                     if (WANT_DX) {
-                        ua.x = fmaf(pe, ea[u].x, ua.x * sc); ua.y = fmaf(pe, ea[u].y, ua.y * sc);
-                        ua.z = fmaf(pe, ea[u].z, ua.z * sc); ua.w = fmaf(pe, ea[u].w, ua.w * sc);
-                        ub.x = fmaf(pe, eb[u].x, ub.x * sc); ub.y = fmaf(pe, eb[u].y, ub.y * sc);
-                        ub.z = fmaf(pe, eb[u].z, ub.z * sc); ub.w = fmaf(pe, eb[u].w, ub.w * sc);
+                        ua.x = fmaf(pe, ea_u.x, ua.x * sc); ua.y = fmaf(pe, ea_u.y, ua.y * sc);
+                        ua.z = fmaf(pe, ea_u.z, ua.z * sc); ua.w = fmaf(pe, ea_u.w, ua.w * sc);
+                        ub.x = fmaf(pe, eb_u.x, ub.x * sc); ub.y = fmaf(pe, eb_u.y, ub.y * sc);
+                        ub.z = fmaf(pe, eb_u.z, ub.z * sc); ub.w = fmaf(pe, eb_u.w, ub.w * sc);
                     }
                     m = m_new;
                 }
@@ -190,22 +189,24 @@ __global__ void __launch_bounds__(256) catalog_ce_sparse_kernel(SparseParams p) 
         const float w = sk / L * p.dx_scale;
         float4 ta = make_float4(NAN, NAN, NAN, NAN), tb = ta;
         if (t_ok) {
-            const float4 a = *reinterpret_cast<const float4*>(p.E + tgt * D + 4 * j);
-            const float4 b = *reinterpret_cast<const float4*>(p.E + tgt * D + D / 2 + 4 * j);
+            float4 a, b;
+            Row::load(p.E, tgt, j, a, b);
             const float q = p.dx_scale;
             ta = make_float4(ua.x * w - a.x * q, ua.y * w - a.y * q, ua.z * w - a.z * q, ua.w * w - a.w * q);
             tb = make_float4(ub.x * w - b.x * q, ub.y * w - b.y * q, ub.z * w - b.z * q, ub.w * w - b.w * q);
         }
-        *reinterpret_cast<float4*>(p.dx + r * D + 4 * j) = ta;
-        *reinterpret_cast<float4*>(p.dx + r * D + D / 2 + 4 * j) = tb;
+        *reinterpret_cast<float4*>(p.dx + r * D + Row::col_a(j)) = ta;
+        *reinterpret_cast<float4*>(p.dx + r * D + Row::col_b(j)) = tb;
     }
 }
 
 template <int D>
-int launch_sparse(const SparseParams& p, hipStream_t st) {
+int launch_sparse(const SparseParams& p, bool bf16, hipStream_t st) {
     const dim3 grid((unsigned)cdiv(p.R, 4)), block(256);
-    if (p.dx) hipLaunchKernelGGL((catalog_ce_sparse_kernel<D, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((catalog_ce_sparse_kernel<D, false>), grid, block, 0, st, p);
+#define PCVAE_SPARSE(DXV, BFV) hipLaunchKernelGGL((catalog_ce_sparse_kernel<D, DXV, BFV>), grid, block, 0, st, p)
+    if (p.dx) { if (bf16) PCVAE_SPARSE(true, true); else PCVAE_SPARSE(true, false); }
+    else { if (bf16) PCVAE_SPARSE(false, true); else PCVAE_SPARSE(false, false); }
+#undef PCVAE_SPARSE
     return check_launch("catalog_ce_sparse");
 }
 
@@ -214,13 +215,18 @@ int launch_sparse(const SparseParams& p, hipStream_t st) {
 extern "C" int pcvae_catalog_ce_sparse(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
                                        float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse, float* dx,
                                        pcvae_stream_t stream) {
-    return pcvae_catalog_ce_sparse_scaled(rx, R, E, N, D, target, keep_prob, seed, row_offset, nll, lse, dx, 1.0f, nullptr, stream);
+    return pcvae_catalog_ce_sparse_scaled(rx, R, E, PCVAE_PREC_F32, N, D, target, keep_prob, seed, row_offset, nll, lse, dx, 1.0f,
+                                          nullptr, stream);
 }
 
-extern "C" int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const float* E, int64_t N, int D, const int64_t* target,
+extern "C" int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const void* E, int prec, int64_t N, int D,
+                                              const int64_t* target,
                                               float keep_prob, uint64_t seed, uint64_t row_offset, float* nll, float* lse,
                                               float* dx, float dx_scale, const uint64_t* seed_dev, pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && target && nll, "catalog_ce_sparse: null pointer");
+    PCVAE_REQUIRE(prec == PCVAE_PREC_F32 || prec == PCVAE_PREC_BF16, "catalog_ce_sparse: precision mode %d (fp32 or bf16 table rows)",
+                  prec);
+    const bool bf16 = prec == PCVAE_PREC_BF16;
     PCVAE_REQUIRE(R > 0 && N > 0 && N < 2147483647LL, "catalog_ce_sparse: bad problem R=%lld N=%lld", (long long)R, (long long)N);
     PCVAE_REQUIRE(keep_prob > 0.f && keep_prob < 1.f, "catalog_ce_sparse: keep_prob must be in (0, 1)");
     PCVAE_REQUIRE(((uintptr_t)rx % 16 == 0) && ((uintptr_t)E % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0),
@@ -228,11 +234,11 @@ extern "C" int pcvae_catalog_ce_sparse_scaled(const float* rx, int64_t R, const 
     PCVAE_REQUIRE(cdiv(R, 4) <= 2147483647LL, "catalog_ce_sparse: R too large");
     SparseParams p{rx, E, target, R, N, seed, row_offset, 1.0 / log1p(-(double)keep_prob), nll, lse, dx, dx_scale, seed_dev};
     switch (D) {
-        case 16: return launch_sparse<16>(p, as_stream(stream));
-        case 32: return launch_sparse<32>(p, as_stream(stream));
-        case 64: return launch_sparse<64>(p, as_stream(stream));
-        case 128: return launch_sparse<128>(p, as_stream(stream));
-        case 256: return launch_sparse<256>(p, as_stream(stream));
+        case 16: return launch_sparse<16>(p, bf16, as_stream(stream));
+        case 32: return launch_sparse<32>(p, bf16, as_stream(stream));
+        case 64: return launch_sparse<64>(p, bf16, as_stream(stream));
+        case 128: return launch_sparse<128>(p, bf16, as_stream(stream));
+        case 256: return launch_sparse<256>(p, bf16, as_stream(stream));
     }
     pcvae::set_error("catalog_ce_sparse: unsupported D=%d (16, 32, 64, 128, 256)", D);
     return PCVAE_EINVAL;

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <type_traits>
 #include "../../include/pcvae.h"
 
 namespace pcvae {
@@ -91,6 +92,54 @@ __device__ __forceinline__ uint64_t mod_magic(uint64_t x, uint64_t n, uint64_t m
     while (r >= n) r -= n;
     return r;
 }
+
+// ---- one table row for a lane group of D / 8 lanes (the gather kernels: sparse K5, K9) ------------------------------------------
+// fp32 table: lane j holds columns [4 j, 4 j + 4) and [D/2 + 4 j, D/2 + 4 j + 4) - two 16-byte loads, each a contiguous half row over
+// the group.  bf16 table (the stated arithmetic of configs 3 / 5; rows of 2 D bytes): lane j holds columns [8 j, 8 j + 8) - ONE
+// 16-byte load; the values are widened exactly (a bf16 is the top half of an fp32), products and sums stay fp32.
+#ifndef PCVAE_GATHER_UNR_F32
+#define PCVAE_GATHER_UNR_F32 4
+#endif
+#ifndef PCVAE_GATHER_UNR_BF16
+#define PCVAE_GATHER_UNR_BF16 8
+#endif
+template <int D, bool BF16>
+struct GatherRow {
+    struct RawF32 { float4 a, b; };
+    struct RawBF16 { uint4 w; };
+    // what a lane keeps in flight per row: 32 bytes of fp32 or 16 bytes of bf16 - so twice as many bf16 rows for the same registers
+    using Raw = typename std::conditional<BF16, RawBF16, RawF32>::type;
+    static constexpr int UNR = BF16 ? PCVAE_GATHER_UNR_BF16 : PCVAE_GATHER_UNR_F32;   // lane-group steps in flight per lane
+    static __device__ __forceinline__ int col_a(int j) { return BF16 ? 8 * j : 4 * j; }
+    static __device__ __forceinline__ int col_b(int j) { return BF16 ? 8 * j + 4 : D / 2 + 4 * j; }
+    static __device__ __forceinline__ Raw zero() {
+        Raw r;
+        if constexpr (BF16) r.w = make_uint4(0u, 0u, 0u, 0u);
+        else { r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a; }
+        return r;
+    }
+    static __device__ __forceinline__ Raw load_raw(const void* E, int64_t n, int j) {
+        Raw r;
+        if constexpr (BF16) r.w = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(E) + n * D + 8 * j);
+        else {
+            const float* e = reinterpret_cast<const float*>(E) + n * D;
+            r.a = *reinterpret_cast<const float4*>(e + 4 * j);
+            r.b = *reinterpret_cast<const float4*>(e + D / 2 + 4 * j);
+        }
+        return r;
+    }
+    static __device__ __forceinline__ void widen(const Raw& r, float4& a, float4& b) {
+        if constexpr (BF16) {
+            a = make_float4(__uint_as_float(r.w.x << 16), __uint_as_float(r.w.x & 0xffff0000u), __uint_as_float(r.w.y << 16),
+                            __uint_as_float(r.w.y & 0xffff0000u));
+            b = make_float4(__uint_as_float(r.w.z << 16), __uint_as_float(r.w.z & 0xffff0000u), __uint_as_float(r.w.w << 16),
+                            __uint_as_float(r.w.w & 0xffff0000u));
+        } else { a = r.a; b = r.b; }
+    }
+    static __device__ __forceinline__ void load(const void* E, int64_t n, int j, float4& a, float4& b) {
+        widen(load_raw(E, n, j), a, b);
+    }
+};
 
 __device__ __forceinline__ float leaky(float x) { return x > 0.f ? x : kLeakySlope * x; }
 

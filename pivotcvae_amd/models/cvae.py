@@ -152,9 +152,9 @@ class BaseCVAE(nn.Module):
             if isinstance(candidates, (tuple, list)):
                 cand, tgt = candidates
                 return ops.candidate_ce(rows, self.catalog_table(), cand=cand, cand_target=tgt, inv_count=inv_count,
-                                        unit_upstream=terms_only)
+                                        unit_upstream=terms_only, prec=self.catalog_precision)
             return ops.candidate_ce(rows, self.catalog_table(), int(candidates), s.reshape(-1), mask_seed, row_offset * S,
-                                    inv_count=inv_count, unit_upstream=terms_only)
+                                    inv_count=inv_count, unit_upstream=terms_only, prec=self.catalog_precision)
         N = self.docEmbed.weight.shape[0]
         keep_prob = 1.0 if n_neg is None else float(n_neg) / N
         if keep_prob > 1.0:

@@ -1060,14 +1060,24 @@ def sparse_ce_applies(keep_prob, N):
     return 0.0 < keep_prob <= SPARSE_MAX_KEEP_PROB and N < 2 ** 31 - 1
 
 
-def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, want_dx=True, dx_scale=1.0):
-    """catalog_ce_raw for keep_prob << 1: only the kept rows of the fp32 table are read (pcvae_catalog_ce_sparse).
-    -> (nll [R], lse [R], dx [R, D] or None).  Exact fp32 whatever the table's precision mode is."""
+def _gather_table(table, D0, prec):
+    """the table the gather kernels (sparse K5, K9) read for a precision mode -> (tensor, width, PREC_F32 | PREC_BF16): bf16 rows
+    (half the gathered bytes; widened exactly, fp32 products and sums) where the model computes its catalog contraction in bf16
+    and the width has a bf16 table (configs 3 / 5 as stated); the fp32 table - the reference's arithmetic - in every other mode"""
+    if prec == PREC_BF16 and D0 in BF16_DIMS:
+        return table.operands(PREC_BF16)[0], D0, PREC_BF16
+    E, D = table.padded()
+    return E, D, PREC_F32
+
+
+def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, want_dx=True, dx_scale=1.0, prec=PREC_F32):
+    """catalog_ce_raw for keep_prob << 1: only the kept rows of the table are read (pcvae_catalog_ce_sparse).
+    -> (nll [R], lse [R], dx [R, D] or None).  Exact fp32 of the fp32 table, except under ``prec`` = bf16 (_gather_table)."""
     table = _as_table(table)
     require_device(rx, table.weight, target)
     rx = _c2d(rx).contiguous()
     R, D0 = rx.shape
-    E, D = table.padded()
+    E, D, gprec = _gather_table(table, D0, prec)
     rx = _pad_cols(rx, D)
     N = E.shape[0]
     target = target.reshape(-1).to(torch.int64).contiguous()
@@ -1079,7 +1089,7 @@ def catalog_ce_sparse_raw(rx, table, target, keep_prob, seed=0, row_offset=0, wa
     timing = CATALOG_CE_TIMING
     tok = timing[0]() if timing else None
     seed_val, seed_dev = _word(seed)
-    check(lib().pcvae_catalog_ce_sparse_scaled(ptr(rx, F32), R, ptr(E, F32), N, D, ptr(target), float(keep_prob), seed_val,
+    check(lib().pcvae_catalog_ce_sparse_scaled(ptr(rx, F32), R, ptr(E), gprec, N, D, ptr(target), float(keep_prob), seed_val,
                                                int(row_offset), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), seed_dev,
                                                stream()), "catalog_ce_sparse")
     if timing:
@@ -1128,7 +1138,7 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
             raise ValueError("catalog_ce: keep_mask must be [R, N]")
     prec = effective_precision(prec, D0)
     if keep_mask is None and keep_prob < 1.0 and sparse_ce_applies(keep_prob, N):
-        return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx, dx_scale)
+        return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx, dx_scale, prec)
     if torch.is_tensor(seed):
         if keep_mask is None and keep_prob < 1.0:
             raise RuntimeError("a device-word mask seed (hipGraph replay) exists for the sparse kept-rows kernel only "
@@ -1341,7 +1351,7 @@ def candidate_draw(slates, n_items, n_candidate, seed=0, row_offset=0, raw=None)
 
 
 def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offset=0, cand=None, cand_target=None, want_dx=True,
-                     dx_scale=1.0, want_target=False):
+                     dx_scale=1.0, want_target=False, prec=PREC_F32):
     """The candidate-set softmax CE in ONE launch (pcvae_candidate_ce): -> (nll [R], lse [R], dx [R, D] * dx_scale or None,
     target column [R] or None).  Either ``cand`` [R, Cn] + ``cand_target`` [R] (sets as given: a batch of the reference's dataset,
     a recorded draw) or ``feature`` [R] + ``n_candidate`` (sets drawn in-kernel from the stream of ``candidate_draw``)."""
@@ -1349,7 +1359,7 @@ def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offs
     require_device(rx, table.weight, feature, cand, cand_target)
     rx = _c2d(rx).contiguous()
     R, D0 = rx.shape
-    E, D = table.padded()
+    E, D, gprec = _gather_table(table, D0, prec)
     rx = _pad_cols(rx, D)
     N = E.shape[0]
     if cand is not None:
@@ -1375,7 +1385,7 @@ def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offs
     timing = CATALOG_CE_TIMING   # the step's reconstruction kernel, whichever it is (bench.py times it on the launch stream)
     tok = timing[0]() if timing else None
     seed_val, seed_dev = _word(seed)
-    check(lib().pcvae_candidate_ce(ptr(rx, F32), R, ptr(E, F32), N, D, Cn, ptr(feature), seed_val, int(row_offset), ptr(cand),
+    check(lib().pcvae_candidate_ce(ptr(rx, F32), R, ptr(E), gprec, N, D, Cn, ptr(feature), seed_val, int(row_offset), ptr(cand),
                                    ptr(cand_target), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), ptr(tcol), seed_dev,
                                    stream()), "candidate_ce")
     if timing:
@@ -1390,10 +1400,10 @@ class _CandidateCE(torch.autograd.Function):
     _CatalogCE: the kernel writes the direction times inv_count and a registered constant-1 seed hands it on without a launch)."""
 
     @staticmethod
-    def forward(ctx, rx, table, n_candidate, feature, seed, row_offset, cand, cand_target, inv_count, unit_upstream):
+    def forward(ctx, rx, table, n_candidate, feature, seed, row_offset, cand, cand_target, inv_count, unit_upstream, prec):
         want_dx = rx.requires_grad
         nll, _lse, dx, _t = candidate_ce_raw(rx.detach(), table, n_candidate, feature, seed, row_offset, cand, cand_target, want_dx,
-                                             dx_scale=float(inv_count) if unit_upstream else 1.0)
+                                             dx_scale=float(inv_count) if unit_upstream else 1.0, prec=prec)
         out = torch.empty((), dtype=F32, device=rx.device)
         check(lib().pcvae_sum(ptr(nll, F32), nll.numel(), float(inv_count), ptr(out, F32), stream()), "sum")
         ctx.inv_count = float(inv_count)
@@ -1406,23 +1416,23 @@ class _CandidateCE(torch.autograd.Function):
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
         if ctx.unit and _is_unit_seed(g):
-            return (dx,) + (None,) * 9
+            return (dx,) + (None,) * 10
         g = g.contiguous()
         out = torch.empty_like(dx)
         check(lib().pcvae_scale_rows(ptr(dx, F32), _ld(dx), ptr(out, F32), _ld(out), dx.shape[0], dx.shape[1],
                                      ptr(g, F32), 1.0 if ctx.unit else ctx.inv_count, stream()), "scale_rows")
-        return (out,) + (None,) * 9
+        return (out,) + (None,) * 10
 
 
 def candidate_ce(rx, table, n_candidate=None, feature=None, seed=0, row_offset=0, cand=None, cand_target=None, inv_count=None,
-                 unit_upstream=False):
+                 unit_upstream=False, prec=PREC_F32):
     """CrossEntropyLoss(bmm(docEmbed(candidates), rx), sample_targets) (models/pivotcvae.py:265-271, train_generative.py:52-57)
     without the [R, Cn] ids, the [R, Cn, D] rows or the [R, Cn] logits: loss and d rx from one launch.
 
     ``inv_count`` defaults to 1/R (the 'mean'); data-parallel ranks pass 1/(R_local * world_size)."""
     R = rx.shape[0]
     return _CandidateCE.apply(rx, _as_table(table), n_candidate, feature, seed, row_offset, cand, cand_target,
-                              (1.0 / R) if inv_count is None else inv_count, unit_upstream)
+                              (1.0 / R) if inv_count is None else inv_count, unit_upstream, prec)
 
 
 def urm_forward(E, item_bias, U, user_bias, slates, users, pos_bias=None, pos_dep=None, mr_factor=None):

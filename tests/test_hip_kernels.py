@@ -805,6 +805,45 @@ def test_candidate_ce_fused_draws_the_documented_stream(ops, R, S, N, D, Cn, see
     assert not torch.equal(ops.candidate_ce_raw(rx.to(DEV), table, Cn, sl.to(DEV).reshape(-1), seed + 1, off)[1], lse)
 
 
+@pytest.mark.parametrize("R,N,D,Cn", [(66, 3000, 64, 257), (130, 5000, 128, 1000), (9, 300, 256, 70), (5, 50, 128, 4500)])
+def test_gather_kernels_on_bf16_rows(ops, R, N, D, Cn):
+    """prec = bf16 (the stated arithmetic of configs 3 / 5): the fused candidate kernel and the sparse mask kernel gather rows of the
+    bf16 table (half the bytes), widen them exactly and keep products and sums in fp32 - so against the oracle on the
+    bf16-ROUNDED table they meet the fp32 tolerances (same draws as the fp32 mode: the streams do not depend on the precision)."""
+    from pivotcvae_amd._hip import PREC_BF16
+    rx, E = rnd(R, D, seed=1, scale=3.0), unit_rows(N, D, seed=2)
+    Eb = E.to(torch.bfloat16).float()
+    g = torch.Generator().manual_seed(3)
+    cand = torch.randint(0, N, (R, Cn), generator=g)
+    tgt = torch.randint(0, Cn, (R,), generator=g)
+    table = ops.CatalogTable(E.to(DEV))
+    tol = max(2e-6, 1e-7 * Cn ** 0.5)
+    want_nll, want_lse, want_dx = orc.candidate_ce(rx, Eb, cand, tgt)
+    nll, lse, dx, _ = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand.to(DEV), cand_target=tgt.to(DEV), prec=PREC_BF16)
+    np.testing.assert_allclose(nll.cpu().double().numpy(), want_nll.numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(lse.cpu().double().numpy(), want_lse.numpy(), rtol=2e-6, atol=2e-6)
+    assert (dx.cpu().double() - want_dx).abs().max() <= tol * max(1.0, float(want_dx.abs().max()))
+    f32 = ops.candidate_ce_raw(rx.to(DEV), table, cand=cand.to(DEV), cand_target=tgt.to(DEV))
+    assert not torch.equal(f32[0], nll) and (f32[0] - nll).abs().max() < 3e-2     # another table, the same problem
+    # drawn in-kernel: the same sets in both precisions
+    feat = torch.randint(0, N, (R,), generator=g)
+    a = ops.candidate_ce_raw(rx.to(DEV), table, Cn, feat.to(DEV), 5, 3, want_target=True, prec=PREC_BF16)
+    b = ops.candidate_ce_raw(rx.to(DEV), table, Cn, feat.to(DEV), 5, 3, want_target=True)
+    assert torch.equal(a[3], b[3])
+    # the sparse mask kernel on bf16 rows against the dense masked oracle on the rounded table, the kept set rebuilt on the host
+    p = min(0.02, 300.0 / N)
+    tg = torch.randint(0, N, (R,), generator=g)
+    nll, lse, dx = ops.catalog_ce_sparse_raw(rx.to(DEV), table, tg.to(DEV), p, seed=77, row_offset=9, prec=PREC_BF16)
+    keep = philox_ref.sparse_keep_mask(R, N, p, 77, 9)
+    wn, wl, wd = co.ce(rx.numpy(), Eb.numpy(), tg.numpy(), keep)
+    np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
+    np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
+    # ... and catalog_ce routes a bf16 model's masked call there
+    r2 = ops.catalog_ce_raw(rx.to(DEV), table, tg.to(DEV), keep_prob=p, seed=77, row_offset=9, prec=PREC_BF16)
+    assert torch.equal(r2[0], nll) and torch.equal(r2[2], dx)
+
+
 def test_candidate_ce_fused_bad_ids_poison_their_row_only(ops):
     """the reference raises an index error on an id outside the table; the kernel cannot raise: that row's outputs are NaN, every
     other row is untouched, nothing is read out of bounds"""

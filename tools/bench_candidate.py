@@ -36,7 +36,19 @@ def one(args):
     table = ops.CatalogTable(E)
     R, Cn, D = args.R, args.Cn, args.D
     res = {"R": R, "N": args.N, "D": D, "Cn": Cn, "requested_GB": R * Cn * D * 4 / 1e9}
-    ms, (nll, lse, dx, _) = timed(lambda: ops.candidate_ce_raw(rx, table, Cn, feat, 7, 0), args.iters)
+    from pivotcvae_amd._hip import PREC_BF16, PREC_F32
+    prec = PREC_BF16 if args.bf16 else PREC_F32
+    res["rows"] = "bf16" if args.bf16 else "f32"
+    if args.bf16:
+        res["requested_GB"] /= 2
+    ms, (nll, lse, dx, _) = timed(lambda: ops.candidate_ce_raw(rx, table, Cn, feat, 7, 0, prec=prec), args.iters)
+    if args.bf16:
+        res["fused_drawn_ms"] = ms
+        res["fused_drawn_TBps_requested"] = R * Cn * D * 2 / (ms * 1e-3) / 1e12
+        ms2, _ = timed(lambda: ops.catalog_ce_sparse_raw(rx, table, feat, Cn / args.N, seed=7, prec=prec), args.iters)
+        res["sparse_n_neg_ms"] = ms2
+        print(json.dumps(res))
+        return
     res["fused_drawn_ms"] = ms
     res["fused_drawn_TBps_requested"] = R * Cn * D * 4 / (ms * 1e-3) / 1e12
     res["nll_mean"] = float(nll.mean())
@@ -74,13 +86,14 @@ if __name__ == "__main__":
     ap.add_argument("--scale", type=float, default=0.3)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--fused-only", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="gather rows of the bf16 table (configs 3 / 5's stated arithmetic)")
     ap.add_argument("--libs", nargs="*")
     a = ap.parse_args()
     if not a.libs:
         one(a)
     else:
         base = [sys.executable, os.path.abspath(__file__), "--R", str(a.R), "--N", str(a.N), "--D", str(a.D), "--Cn", str(a.Cn),
-                "--iters", str(a.iters), "--scale", str(a.scale), "--fused-only"]
+                "--iters", str(a.iters), "--scale", str(a.scale), "--fused-only"] + (["--bf16"] if a.bf16 else [])
         for _ in range(a.rounds):
             for l in a.libs:
                 out = subprocess.run(base, env=dict(os.environ, PCVAE_LIB=os.path.abspath(l)), capture_output=True, text=True)

@@ -8,7 +8,7 @@ mkdir -p build/variants
 OBJ=build/variants/$(basename $OUT .so).o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -I pivotcvae_amd/csrc "$@" -x hip -c pivotcvae_amd/csrc/$TU.hip -o $OBJ
 OBJS=""
-for o in error elementwise gemm_f32 catalog_f32 catalog_bf16 catalog_sparse catalog_api; do
+for o in error elementwise gemm_f32 catalog_f32 catalog_bf16 catalog_sparse candidate_ce catalog_sample catalog_api; do
   if [ $o = $TU ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS pivotcvae_amd/lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
