@@ -101,7 +101,7 @@ __device__ __forceinline__ uint64_t mod_magic(uint64_t x, uint64_t n, uint64_t m
 #define PCVAE_GATHER_UNR_F32 4
 #endif
 #ifndef PCVAE_GATHER_UNR_BF16
-#define PCVAE_GATHER_UNR_BF16 8
+#define PCVAE_GATHER_UNR_BF16 4   // (4, 6, 8, 12 measured: the same time - these kernels sit at the fabric's byte rate, not at a latency bound)
 #endif
 template <int D, bool BF16>
 struct GatherRow {

@@ -867,7 +867,7 @@ def test_candidate_ce_fused_bad_ids_poison_their_row_only(ops):
     d = ops.candidate_ce_raw(rx.to(DEV), table, Cn, feat.to(DEV), 1, 0)
     assert torch.isnan(d[0].cpu()[3]) and torch.isnan(d[2].cpu()[3]).all() and torch.isfinite(d[0].cpu()[good & (torch.arange(R) != 3)]).all()
     from pivotcvae_amd import _hip
-    rc = _hip.lib().pcvae_candidate_ce(_hip.ptr(rx.to(DEV)), R, _hip.ptr(table.weight), N, D, Cn, None, 0, 0, None, None,
+    rc = _hip.lib().pcvae_candidate_ce(_hip.ptr(rx.to(DEV)), R, _hip.ptr(table.weight), _hip.PREC_F32, N, D, Cn, None, 0, 0, None, None,
                                        _hip.ptr(torch.empty(R, device=DEV)), None, None, 1.0, None, None, _hip.stream())
     assert rc == -1 and b"candidate_ce" in _hip.lib().pcvae_last_error()
 
