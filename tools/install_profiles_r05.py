@@ -38,10 +38,10 @@ def avg_ms(name, kern):
 FETCH_NOTE = "x2 (gfx950: 128-B requests tallied at 64 B for 16 B/lane reads; MI355X_MICROARCH.md HBM section)"
 # (workload, kernel substring in the PMC csv / the kernel stats, traffic.json key, algorithmic bytes per launch, what they are)
 JOBS = [
-    ("cand1000_config4", "candidate_ce_kernel<128, true>", "config4_cand1000_gpus1", R4 * 1001 * 512.0 + R4 * (2 * 512 + 24),
+    ("cand1000_config4", "candidate_ce_kernel<128, true, false>", "config4_cand1000_gpus1", R4 * 1001 * 512.0 + R4 * (2 * 512 + 24),
      "REQUESTED bytes: 1000 candidate rows + the target row of 512 B per slate slot, rx read, dx + nll + lse written "
      "(a 0.51 GB table: every row is re-read ~82 times, from the caches)"),
-    ("cand50_config4", "candidate_ce_kernel<128, true>", "config4_cand50_gpus1", R4 * 51 * 512.0 + R4 * (2 * 512 + 24),
+    ("cand50_config4", "candidate_ce_kernel<128, true, false>", "config4_cand50_gpus1", R4 * 51 * 512.0 + R4 * (2 * 512 + 24),
      "REQUESTED bytes: 50 candidate rows + the target row per slate slot, rx, dx, nll, lse"),
     ("bf16_config4", "catalog_ce_bf16_pipe_kernel<128, 4>", "config4_bf16_gpus1", 256e6 + R4 * 128 * 4 + 2 * 2 * R4 * 130 * 4,
      "bf16 table once + rx + the ranges' partials written and read"),

@@ -3,6 +3,7 @@
 #   part A: config 4 - the default line (headline + variants incl. candidates_nneg1000 / _nneg50 + pivot_rules); the reference's
 #           DEFAULT training mode as its own line (--n_candidate 1000 / 50): kernel stats + FETCH_SIZE / WRITE_SIZE passes of
 #           candidate_ce_kernel<128, true>; the sampled-rule step (pivotcvae_spt_pi) kernel stats
+#   part C: config 3 on the round-5 plan; candidate mode on bf16 rows at configs 3 / 5; config 3's full line
 #   part B: the gather evidence on this tree (tools/profile_gather.sh); bf16 / bf16x3 FETCH / WRITE passes at config 4 (traffic.json's
 #           two stale entries)
 PART=${1:-A}
@@ -39,6 +40,16 @@ if [ "$PART" = "A" ]; then
     pmc cand${cn}_config4 WRITE_SIZE "WRITE_SIZE" --n_candidate $cn --steps 3 --warmup 1 $LEAN
   done
   stats spt_config4 --model pivotcvae_spt_pi --steps 3 --warmup 1 $LEAN
+elif [ "$PART" = "C" ]; then
+  # config 3 on the round-5 plan (3 ranges), candidate mode on bf16 rows at configs 3 / 5 (their stated arithmetic)
+  stats bf16_config3 --config 3 --steps 20 --warmup 5 --no-graph $LEAN
+  for c in 3 5; do
+    python3 $ROOT/bench.py --config $c --n_candidate 1000 --steps 10 --warmup 3 $LEAN > $OUT/cand1000_config$c.log 2>&1
+    grep '^{"metric"' $OUT/cand1000_config$c.log | tail -1 > $OUT/cand1000_config${c}_bench.json
+    stats cand1000_config$c --config $c --n_candidate 1000 --steps 5 --warmup 2 $LEAN
+  done
+  python3 $ROOT/bench.py --config 3 --steps 20 --warmup 5 > $OUT/bench3.log 2>&1
+  grep '^{"metric"' $OUT/bench3.log | tail -1 > $OUT/config3_bench.json
 elif [ "$PART" = "B" ]; then
   bash $ROOT/tools/profile_gather.sh > $OUT/gather.log 2>&1
   cp $ROOT/gpurun_out/prof_gather/gather_kernel_stats.csv $OUT/gather_kernel_stats.csv
