@@ -173,6 +173,58 @@ def test_config4_default_masked_mode_at_stated_size():
     assert abs(r0.item() - np.log(cfg["N"])) < 0.2 and r1.item() < r0.item() + 1e-3
 
 
+@pytest.mark.parametrize("config,prec", [("4", "f32"), ("5", "bf16")])
+def test_default_candidate_mode_at_stated_size(config, prec):
+    """configs 4 and 5 at their stated sizes in the reference's DEFAULT training mode (candidate sets, 1000 ids per slot, drawn in
+    the fused kernel; config 5 on bf16 rows, its stated arithmetic): two graph-replayed steps; on a row sample the kernel's nll /
+    lse / gradient direction equal an fp64 softmax over the very sets it drew (the draw read back through pcvae_candidate_draw:
+    the same stream), computed by torch on the device; the step's reconstruction term is the mean of the per-row nll; the PSM
+    stack and the tables are bit-unchanged; two steps draw different sets."""
+    import bench
+    from pivotcvae_amd import ops
+    from pivotcvae_amd._hip import PREC_NAMES
+    from pivotcvae_amd.train_generative import Trainer
+    cfg = bench.CONFIGS[config]
+    N, S, D, B, Cn = cfg["N"], cfg["S"], cfg["D"], cfg["B"], 1000
+    model, _ = bench.build_model(cfg, torch.device(DEV), prec)
+    model.rng_seed = 3
+    s, r, u = bench.synthetic_batch(cfg, B, torch.device(DEV))
+    frozen = {k: v.detach().clone() for k, v in model.state_dict().items() if k.startswith(("psm_", "userEmbed"))}
+    tr = Trainer(model, lr=bench.LR, beta=bench.BETA, n_candidate=Cn, capture_graph=True)
+    l0, r0, k0 = tr.step(s, r, u)
+    l1, r1, k1 = tr.step(s, r, u)
+    assert tr._graph is not None and tr.capture_failed is None
+    for t in (l0, r0, k0, l1, r1, k1):
+        assert torch.isfinite(t).item()
+    assert abs(r0.item() - np.log(Cn)) < 0.2 and r0.item() != r1.item()     # untrained model: logits ~ 0 -> rec ~ ln Cn
+    for k, v in frozen.items():
+        assert torch.equal(model.state_dict()[k], v), k
+    # the kernel on rows the model produces, against fp64 on the sets it drew (seed = the next step's: global_step)
+    eps = torch.randn(B, bench.Z, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    rx = model_rx(model, s, r, u, eps)
+    table = model.catalog_table()
+    feat = s.reshape(-1)
+    nll, lse, dx, tcol = ops.candidate_ce_raw(rx, table, Cn, feat, 2, 0, want_target=True, prec=PREC_NAMES[prec])
+    rows = torch.arange(0, rx.shape[0], max(1, rx.shape[0] // 512), device=DEV)[:512]
+    # candidate_draw keys its stream by (row_offset + local row): every sampled row is redrawn at its own global offset
+    drawn = [ops.candidate_draw(feat[i].view(1, 1), N, Cn, seed=2, row_offset=int(i)) for i in rows.tolist()]
+    cand = torch.stack([c.view(Cn) for c, _ in drawn])
+    tg = torch.stack([t.view(()) for _, t in drawn])
+    assert torch.equal(tg, tcol[rows])
+    E = model.docEmbed.weight.detach()
+    Er = (E.to(torch.bfloat16).float() if prec == "bf16" else E)[cand].double()            # [512, Cn, D]
+    sc = torch.einsum("rcd,rd->rc", Er, rx[rows].double())
+    lse64 = torch.logsumexp(sc, 1)
+    nll64 = lse64 - sc.gather(1, tg.view(-1, 1)).view(-1)
+    dx64 = torch.einsum("rc,rcd->rd", torch.softmax(sc, 1), Er) - Er[torch.arange(rows.numel()), tg]
+    assert float((lse[rows].double() - lse64).abs().max()) < 3e-6 and float((nll[rows].double() - nll64).abs().max()) < 4e-6
+    assert float((dx[rows].double() - dx64).abs().max()) < 3e-6 * max(1.0, float(dx64.abs().max()))
+    # the step's reconstruction term = the mean of the per-row nll (same seed as step 0 of a fresh trainer: global_step 0)
+    with torch.no_grad():
+        _, rec, _ = model.loss(s, r, u, bench.BETA, eps=eps, mask_seed=2, candidates=Cn)
+    np.testing.assert_allclose(rec.item(), nll.mean().item(), rtol=2e-6)
+
+
 def test_graph_replay_next_to_an_rccl_all_reduce_follows_the_eager_trajectory():
     """the data-parallel step as the 8-GPU run executes it on every rank - hipGraph replay of zero-grad + forward + backward, then
     the all-reduce of the flat gradient buffer + statistics tail on RCCL, then Adam - with a 1-rank RCCL group (the collective is
