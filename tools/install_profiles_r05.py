@@ -98,12 +98,20 @@ if os.path.exists(gs):
             if line.startswith("{"):
                 d = json.loads(line)
                 timer_under[d["kernel"]] = d
+    floor_trace = None   # the one-row launches of the D = 64 instance: what a dispatch costs in the traced process
+    for r in csv.DictReader(open(gs)):
+        if "gather_rows_coal_kernel<16" in r["Name"]:
+            floor_trace = float(r["AverageNs"]) / 1e3
     if ms is not None and len(c) == 2:
         alg = 98304 * (2 * 512 + 8)
         fetch, write = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024    # (16 B/lane row reads: the guide's x2 correction)
         t["_r05_gather"] = {"round": "r05", "kernel": gk + "<32, true>", "kernel_trace_avg_us": ms * 1e3,
                             "dispatch_event_timer_avg_us": timer.get("gather", {}).get("us_avg"),
                             "dispatch_event_timer_avg_us_under_rocprofv3": timer_under.get("gather", {}).get("us_avg"),
+                            "launch_floor_us": {"dispatch_event_timer_plain": timer.get("floor", {}).get("us_avg"),
+                                                "dispatch_event_timer_under_rocprofv3": timer_under.get("floor", {}).get("us_avg"),
+                                                "rocprofv3_kernel_trace": floor_trace,
+                                                "what": "the same kernel family moving ONE row: the cost of a dispatch with nothing to move"},
                             "timing_note": "the dispatch-event timer (HIP events attached to the launch) in a plain process; rocprofv3's "
                                            "kernel trace of the same program; and the same timer INSIDE the traced process - every "
                                            "dispatch is slower while the profiler intercepts it, so the trace's average sits above the "
