@@ -69,7 +69,7 @@ for stale, fresh in (("_round1", "_r05_bf16_config4"), ("_source", "_r05_bf16x3_
         del t[stale]   # the entries that described earlier rounds' kernels under the current keys
 
 # the gather (K1): rocprofv3's average duration must agree with the dispatch-event timer; FETCH + WRITE = the algorithmic bytes
-gk = "gather_rows_coal_kernel"
+gk = "gather_rows_coal_kernel<32"   # the D = 128 instance (the <16> one is the one-row launch floor)
 gs = os.path.join(src, "gather_kernel_stats.csv")
 if os.path.exists(gs):
     ms = None
@@ -105,7 +105,7 @@ if os.path.exists(gs):
     if ms is not None and len(c) == 2:
         alg = 98304 * (2 * 512 + 8)
         fetch, write = c["FETCH_SIZE"] * 1024 * 2, c["WRITE_SIZE"] * 1024    # (16 B/lane row reads: the guide's x2 correction)
-        t["_r05_gather"] = {"round": "r05", "kernel": gk + "<32, true>", "kernel_trace_avg_us": ms * 1e3,
+        t["_r05_gather"] = {"round": "r05", "kernel": "gather_rows_coal_kernel<32, true>", "kernel_trace_avg_us": ms * 1e3,
                             "dispatch_event_timer_avg_us": timer.get("gather", {}).get("us_avg"),
                             "dispatch_event_timer_avg_us_under_rocprofv3": timer_under.get("gather", {}).get("us_avg"),
                             "launch_floor_us": {"dispatch_event_timer_plain": timer.get("floor", {}).get("us_avg"),
@@ -113,9 +113,8 @@ if os.path.exists(gs):
                                                 "rocprofv3_kernel_trace": floor_trace,
                                                 "what": "the same kernel family moving ONE row: the cost of a dispatch with nothing to move"},
                             "timing_note": "the dispatch-event timer (HIP events attached to the launch) in a plain process; rocprofv3's "
-                                           "kernel trace of the same program; and the same timer INSIDE the traced process - every "
-                                           "dispatch is slower while the profiler intercepts it, so the trace's average sits above the "
-                                           "plain timer's and is the figure to quote when a trace is asked for",
+                                           "kernel trace of the same program; and the same timer INSIDE the traced process (the event pair "
+                                           "then also spans the profiler's own packets: not a kernel duration)",
                             "FETCH_SIZE_KB_mean": c["FETCH_SIZE"], "WRITE_SIZE_KB_mean": c["WRITE_SIZE"], "fetch_correction": FETCH_NOTE,
                             "memory_side_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": alg,
                             "traffic_over_algorithmic": (fetch + write) / alg,
