@@ -617,10 +617,12 @@ class StepTimer:
             was = tr.capture_graph
             tr.capture_graph = False
             ops.CATALOG_CE_TIMING = (hook_begin, hook_end)
+            ops.PIVOT_TIMING = (hook_begin, pivot_end)
             for _ in range(steps):
                 tr.step(s, r, u, global_batch=self.B, row_offset=self.lo)
             torch.cuda.synchronize()
             ops.CATALOG_CE_TIMING = None
+            ops.PIVOT_TIMING = None
             tr.capture_graph = was
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
         # the pivot-selection kernel of a pt / spt / sgt train step (catalog argmax / rejection sampler), per step
