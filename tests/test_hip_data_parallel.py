@@ -174,7 +174,7 @@ def test_w_simulated_ranks_equal_the_single_process_step(W, prec, fused, tile_mo
 @pytest.mark.parametrize("W", [2, 8])
 def test_masked_mode_and_sampled_pivots_under_sharding(W, tile_mode):
     """the reference's default n_neg = 1000 (sparse kept-rows kernel, mask keyed by GLOBAL row) and a sampled-pivot rule (sgt:
-    Gumbel-max sampler keyed by GLOBAL slate index): the sharded job reproduces the single-process one"""
+    rejection sampler keyed by GLOBAL slate index): the sharded job reproduces the single-process one"""
     from pivotcvae_amd.train_generative import Trainer
     N, S, D, B = 50021, 10, 128, 256
     s, r, u = batch(N, S, B, seed=3)
@@ -201,7 +201,7 @@ def test_masked_mode_and_sampled_pivots_under_sharding(W, tile_mode):
 @pytest.mark.parametrize("W", [2, 8])
 def test_candidate_mode_and_sampled_pivots_under_sharding(W, tile_mode):
     """the reference's DEFAULT mode (candidate sets, train_generative.py:52-57) through the fused kernel - sets drawn in-kernel from
-    a stream keyed by (step, GLOBAL slot) - alone and together with a sampled-pivot rule (spt: the PSM output's Gumbel-max sample,
+    a stream keyed by (step, GLOBAL slot) - alone and together with a sampled-pivot rule (spt: a rejection-sampled pivot from the PSM output,
     keyed by GLOBAL slate index): the sharded job reproduces the single-process one, and two steps draw different sets"""
     from pivotcvae_amd.train_generative import Trainer
     N, S, D, B = 50021, 10, 128, 256
@@ -292,7 +292,7 @@ def test_in_kernel_streams_are_bitwise_independent_of_the_sharding():
         sl = slice(w * per * S, (w + 1) * per * S)
         a, b, c, _ = ops.candidate_ce_raw(rx[sl].contiguous(), table, 50, tgt[sl].contiguous(), 13, w * per * S)
         assert torch.equal(a, cn[sl]) and torch.equal(b, cl[sl]) and torch.equal(c, cx[sl])
-    # sampled pivots (Gumbel-max over sigmoid scores)
+    # sampled pivots (rejection sampling from Categorical(sigmoid(scores)))
     q = rx[:B].contiguous()
     ids = ops.catalog_sample(q, table, seed=17, row_offset=40)
     for w in range(W):
