@@ -987,7 +987,9 @@ def main():
                    "global_batch": B, "per_gpu_batch": B // world, "parallelism": f"dp{world}",
                    "rccl_ranks": dist.get_world_size() if use_dist else 1,
                    **({"rehearsal": "all ranks on ONE GPU, gloo collectives: checks the N > 1 path, not its speed"} if rehearsal else {}),
-                   "catalog_arithmetic": {"bf16x3": X3_ARITHMETIC, "bf16x6": X6_ARITHMETIC}.get(args.dtype, args.dtype),
+                   "catalog_arithmetic": ("gather kernel: " + ("rows of the bf16 table widened exactly, " if bf16_rows else "rows of the fp32 table, ")
+                                          + "fp32 fmaf dot products, fp32 online softmax (the full-catalog MFMA kernels are not on this path)")
+                   if (cand_mode or sparse) else {"bf16x3": X3_ARITHMETIC, "bf16x6": X6_ARITHMETIC}.get(args.dtype, args.dtype),
                    "mlp_arithmetic": args.mlp if args.mlp == "f32" else
                    "bf16x3 in the train step's 64 x 64-tile GEMM launches (operands split into bf16 hi + lo in registers, 3 bf16 MFMAs per "
                    "product, fp32 accumulate: gradients within 1e-4 of each tensor's scale of the fp32 reference, ELBO ~1e-6; "
