@@ -434,7 +434,8 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
 
     if trainer is None:
         if model.candidateFlag:   # the reference's default mode: the fused candidate kernel inside the trainer's own (seeded) step
-            trainer = Trainer(model, lr=lr, beta=beta, n_neg=None, process_group=process_group, n_candidate=n_cand)
+            trainer = Trainer(model, lr=lr, beta=beta, n_neg=None, process_group=process_group, n_candidate=n_cand,
+                              capture_graph=capture_graph)
         else:
             trainer = Trainer(model, lr=lr, beta=beta, n_neg=None if n_neg >= N else n_neg, process_group=process_group,
                               capture_graph=capture_graph)

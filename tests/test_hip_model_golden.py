@@ -574,6 +574,38 @@ def test_terms_only_loss_applies_any_upstream_gradient():
         close(grads[1][k], grads[0][k], rtol=1e-5, atol=1e-8)
 
 
+def test_train_on_dataset_graph_replay_equals_eager_in_candidate_mode(tmp_path):
+    """the same in the reference's DEFAULT mode (model.candidateFlag: candidate sets drawn in the fused kernel, their seed read from
+    a device word by the replayed graph): histories and final parameters of the replayed and the eager epoch loop agree"""
+    from pivotcvae_amd.train_generative import train_on_dataset
+    g = load("pivotcvae_gt_pi_user")
+    gen = torch.Generator().manual_seed(3)
+    L, N, S = 256, g.meta["N"], g.meta["S"]
+    train = {"slates": torch.randint(0, N, (L, S), generator=gen).numpy(), "users": torch.randint(0, g.meta["NU"], (L, 1), generator=gen).numpy(),
+             "responses": (torch.rand(L, S, generator=gen) < 0.5).float().numpy(), "nCandidate": 40}
+    val = {k: v[:64] for k, v in train.items() if k != "nCandidate"}
+
+    class Log:
+        lines = []
+
+        def log(self, msg):
+            self.lines.append(msg)
+
+    res = {}
+    for graph in (False, True):
+        model = build_from_golden(g)
+        model.candidateFlag = True
+        hist = train_on_dataset(train, val, model, str(tmp_path / f"cand{int(graph)}.pkl"), Log(), None, bs=64, epochs=3, lr=3e-3,
+                                decay=0.0, beta=0.001, n_neg=N, seed=11, capture_graph=graph)
+        res[graph] = (hist, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    assert not any("capture failed" in l for l in Log.lines)
+    np.testing.assert_allclose(res[True][0]["train"], res[False][0]["train"], rtol=2e-6)
+    np.testing.assert_allclose(res[True][0]["val"], res[False][0]["val"], rtol=2e-6)
+    assert res[False][0]["train"][-1] < res[False][0]["train"][0]
+    for k, v in res[False][1].items():
+        assert float((res[True][1][k] - v).abs().max()) <= 1e-6, k
+
+
 def test_train_on_dataset_graph_replay_equals_eager(tmp_path):
     """the epoch loop with hipGraph replay of the step against eager launches: same seed, same permutations, nothing read back inside
     an epoch - histories and final parameters must agree to rounding (round 3: a memset node in the captured graph raced with the
