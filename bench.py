@@ -440,6 +440,50 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_baseline_candidates(model, st, cfg, n_candidate):
+    """The reference's DEFAULT mode on the host cores: the oracle's candidate branch (embedding [Bs, S, Cn, D] + bmm + CE + backward +
+    Adam) on a bounded sample, the candidate sets drawn the reference's way (numpy randint per slate + the first-hit / overwrite rule,
+    data_loader.py:46-58), + HIP-vs-oracle ELBO on the same sets."""
+    import numpy as np
+    from oracle import pivotcvae_oracle as orc
+    S, D, N = cfg["S"], cfg["D"], cfg["N"]
+    Bs = max(8, min(cfg["B"], int(2.5e8 // (S * n_candidate * D))))      # the gathered rows [Bs, S, Cn, D] fp32 stay under 1 GB
+    steps = 5
+    dev = model.docEmbed.weight.device
+    s, r, u = synthetic_batch(cfg, Bs, dev, seed=11)
+    eps = torch.randn(Bs, Z, generator=torch.Generator().manual_seed(2))
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ocfg = orc.Config(cfg.get("model", "pivotcvae_gt_pi"), S, D, Z, False, st)
+    sc, rc, uc = s.cpu(), r.cpu(), u.cpu()
+    np.random.seed(3)
+    t0 = time.perf_counter()
+    raw = np.stack([np.random.randint(N, size=(S, n_candidate)) for _ in range(Bs)])
+    cand, tgt = orc.candidate_targets(sc, torch.from_numpy(raw))
+    t_draw = time.perf_counter() - t0
+    ncpu = os.cpu_count() or 1
+    torch.set_num_threads(min(32, ncpu))
+    kw = dict(candidates=cand, cand_targets=tgt)
+    (ol, orec, okld), grads = orc.loss_and_grads(sd, ocfg, sc, rc, uc, eps, BETA, **kw)
+    state, cur = {}, sd
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, g = orc.loss_and_grads(cur, ocfg, sc, rc, uc, eps, BETA, **kw)
+        cur = orc.adam_step(cur, g, state, LR)
+    dt = (time.perf_counter() - t0) / steps
+    with torch.no_grad():
+        hl, hrec, hkld = model.loss(s, r, u, BETA, eps=eps.to(dev), candidates=(cand.to(dev), tgt.to(dev)))
+    rel = lambda a, b: abs(a - b) / max(abs(b), 1e-30)
+    base = {"value": Bs / (dt + t_draw), "unit": "slates/s", "cores": torch.get_num_threads(), "host_cores": ncpu, "cpu_model": cpu_model(),
+            "kind": "port", "as_specified": Bs == cfg["B"],
+            "sample": f"oracle/pivotcvae_oracle.py train step in candidate mode (gathered rows [{Bs}, {S}, {n_candidate}, {D}] + bmm + CE + "
+                      f"KL + backward + Adam: {dt:.3f} s/step) + the candidate draw the reference's way ({t_draw:.3f} s per batch), "
+                      f"B={Bs} slates of the same workload, {steps} steps"}
+    parity = {"loss_rel_err": rel(hl.item(), ol), "recLoss_rel_err": rel(hrec.item(), orec), "KLD_rel_err": rel(hkld.item(), okld),
+              "tolerance": 1e-4, "sample": f"B={Bs}, same eps, same candidate sets, HIP fused candidate kernel vs CPU oracle"}
+    parity["within_tolerance"] = max(parity["loss_rel_err"], parity["recLoss_rel_err"], parity["KLD_rel_err"]) <= 1e-4
+    return base, parity
+
+
 def cpu_baseline_and_parity(model, st, cfg, dtype):
     """Oracle train step on the host cores on a bounded sample + HIP-vs-oracle ELBO on that same sample."""
     from oracle import pivotcvae_oracle as orc
@@ -1057,6 +1101,8 @@ def main():
     if single and not args.no_variants and not args.no_extras and cfg.get("model", "pivotcvae_gt_pi") == "pivotcvae_gt_pi" \
             and args.n_neg is None and not cand_mode and N >= 100_000:
         out["pivot_rules"] = pivot_rules_block(cfg, device, args.dtype, args.mlp, out["ms_per_step"])
+    if single and not args.no_cpu_baseline and cand_mode and cfg.get("model", "pivotcvae_gt_pi") in ("pivotcvae_gt_pi", "listcvae"):
+        out["cpu_baseline"], out["parity"] = cpu_baseline_candidates(model, st, cfg, args.n_candidate)
     if single and not args.no_cpu_baseline and cfg.get("model", "pivotcvae_gt_pi") in ("pivotcvae_gt_pi", "listcvae") and not cand_mode:
         base, parity = cpu_baseline_and_parity(model, st, cfg, args.dtype)
         out["cpu_baseline"] = base
