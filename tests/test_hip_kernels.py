@@ -1223,3 +1223,52 @@ def test_catalog_ce_sparse_random_shapes_fuzz(ops):
             np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6, err_msg=msg)
             np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6 + 2e-6 * float(np.abs(wl).max()), err_msg=msg)
             np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6, err_msg=msg)
+
+
+def test_candidate_ce_and_sampler_random_shapes_fuzz(ops):
+    """ten random (R, S-less rows, N, D, Cn, seed, row offset, precision) per sequence through the fused candidate kernel - sets drawn
+    in-kernel == the documented stream (host restatement + the oracle's first-hit rule), loss / lse / gradient == the oracle's
+    bmm + CE + autograd in fp64 (on the bf16-rounded table in bf16 mode), the materialised route, a shard - and through the rejection
+    sampler (ids == the host restatement on decision-safe rows).  PCVAE_FUZZ_SEEDS="1,2,.." runs other sequences as well."""
+    import random
+    from pivotcvae_amd._hip import PREC_BF16, PREC_F32
+    for sd in [int(v) for v in os.environ.get("PCVAE_FUZZ_SEEDS", "2718").split(",")]:
+        rng = random.Random(sd)
+        for case in range(10):
+            D = rng.choice([8, 16, 20, 32, 64, 128, 256])
+            N = rng.choice([rng.randint(1, 40), rng.randint(41, 3000), rng.randint(3001, 70000)])
+            R = rng.randint(1, 40)
+            Cn = rng.choice([1, rng.randint(2, 64), rng.randint(65, 1200), rng.randint(2049, 4200)])
+            seed, off = rng.randint(0, 2 ** 40), rng.randint(0, 2 ** 33)
+            bf16 = D in (64, 128, 256) and rng.random() < 0.4
+            prec = PREC_BF16 if bf16 else PREC_F32
+            msg = f"seed={sd} case={case} R={R} N={N} D={D} Cn={Cn} bf16={bf16}"
+            rx, E = rnd(R, D, seed=sd + case, scale=3.0), unit_rows(N, D, seed=sd + 100 + case)
+            feat = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(sd + 200 + case))
+            table = ops.CatalogTable(E.to(DEV))
+            raw = torch.from_numpy(philox_ref.candidate_raw(R, Cn, N, seed, off)).view(R, 1, Cn)
+            wc, wt = orc.candidate_targets(feat.view(R, 1), raw)
+            wc, wt = wc.view(R, Cn), wt.view(R)
+            nll, lse, dx, tcol = ops.candidate_ce_raw(rx.to(DEV), table, Cn, feat.to(DEV), seed, off, want_target=True, prec=prec)
+            assert torch.equal(tcol.cpu(), wt), msg
+            Eo = E.to(torch.bfloat16).float() if bf16 else E
+            wn, wl, wd = orc.candidate_ce(rx, Eo, wc, wt)
+            tol = max(2e-6, 1e-7 * Cn ** 0.5)
+            np.testing.assert_allclose(lse.cpu().double().numpy(), wl.numpy(), rtol=2e-6, atol=2e-6, err_msg=msg)
+            np.testing.assert_allclose(nll.cpu().double().numpy(), wn.numpy(), rtol=2e-6, atol=3e-6 + 2e-6 * float(wl.abs().max()), err_msg=msg)
+            assert (dx.cpu().double() - wd).abs().max() <= tol * max(1.0, float(wd.abs().max())), msg
+            g = ops.candidate_ce_raw(rx.to(DEV), table, cand=wc.to(DEV), cand_target=wt.to(DEV), prec=prec)
+            assert torch.equal(g[0], nll) and torch.equal(g[2], dx), msg
+            if not bf16:
+                p = ops.candidate_scores(rx.to(DEV), E.to(DEV), wc.to(DEV))
+                want_p = torch.bmm(E[wc].double(), rx.double().reshape(R, D, 1)).reshape(R, Cn)
+                assert (p.cpu().double() - want_p).abs().max() <= 3e-6 * max(1.0, float(want_p.abs().max())), msg
+            h = R // 2
+            if h:
+                part = ops.candidate_ce_raw(rx[h:].contiguous().to(DEV), table, Cn, feat[h:].contiguous().to(DEV), seed, off + h, prec=prec)
+                assert torch.equal(part[0], nll[h:]) and torch.equal(part[2], dx[h:]), msg
+            idx = ops.catalog_sample(rx.to(DEV), table, seed=seed, row_offset=off).cpu().numpy()
+            want, _k, safe = philox_ref.sample_reject(rx.numpy(), E.numpy(), seed, off)
+            ok = safe & (want >= 0)
+            np.testing.assert_array_equal(idx[ok], want[ok], err_msg=msg)
+            assert ((idx >= 0) & (idx < N)).all(), msg
