@@ -121,6 +121,8 @@ class Trainer:
     def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None,
                  capture_graph=False, world_size=None, rank=0, resident_batch=False, n_candidate=None):
         import torch.distributed as dist
+        if n_neg is not None and n_candidate is not None:
+            raise ValueError("n_neg (mask-train) and n_candidate (candidate sets) are the two branches of get_gen_loss: pass one")
         self.model, self.beta, self.n_neg = model, float(beta), n_neg
         # the reference's DEFAULT mode (no --mask_train): candidate sets of n_candidate columns per slot, drawn in the fused
         # kernel from a stream keyed by (step, GLOBAL slot) - independent of the world size, like the masks and eps
