@@ -1,5 +1,6 @@
 // Host-side error text + ABI version for libpcvae_hip.so.
 #include "common.h"
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <utility>
@@ -44,30 +45,37 @@ int lds_optin(const void* kernel, int bytes) {
 namespace {
 struct TimedLaunch { int tag; hipEvent_t e0, e1; };
 std::vector<TimedLaunch>& timed() { static std::vector<TimedLaunch> v; return v; }
-bool g_timer_on = false;
+std::mutex& timer_mu() { static std::mutex m; return m; }   // the list is process-wide: launches of any thread append under it
+std::atomic<bool> g_timer_on{false};
 }
-bool timer_on() { return g_timer_on; }
+bool timer_on() { return g_timer_on.load(std::memory_order_relaxed); }
 void timer_events(int tag, hipEvent_t* start, hipEvent_t* stop) {
     TimedLaunch t{tag, nullptr, nullptr};
     hipEventCreate(&t.e0);
     hipEventCreate(&t.e1);
-    timed().push_back(t);
+    {
+        std::lock_guard<std::mutex> lock(timer_mu());
+        timed().push_back(t);
+    }
     *start = t.e0;
     *stop = t.e1;
 }
 }  // namespace pcvae
 
-// enable = 1: start collecting (forgets earlier launches); 0: stop.  Not thread-safe: a measurement tool's switch, not a product path.
+// enable = 1: start collecting (forgets earlier launches); 0: stop.  The switch and the list are process-wide (every thread's
+// instrumented launches are timed while it is on); both are safe to use from several threads.
 extern "C" int pcvae_kernel_timer(int enable) {
     using namespace pcvae;
+    std::lock_guard<std::mutex> lock(timer_mu());
     for (auto& t : timed()) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
     timed().clear();
-    g_timer_on = enable != 0;
+    g_timer_on.store(enable != 0, std::memory_order_relaxed);
     return PCVAE_OK;
 }
 // -> number of timed launches so far; fills ms[i] / tags[i] for the first `cap` of them (synchronises on their stop events)
 extern "C" int pcvae_kernel_timer_read(float* ms, int* tags, int cap) {
     using namespace pcvae;
+    std::lock_guard<std::mutex> lock(timer_mu());
     int n = 0;
     for (auto& t : timed()) {
         if (n < cap && ms && tags) {
