@@ -62,6 +62,22 @@ for name, kern, key, alg, what in JOBS:
                          "traffic_over_algorithmic": (fetch + write) / alg,
                          "note": "FETCH_SIZE / WRITE_SIZE count the L2s' memory-side requests: Infinity-Cache hits are included",
                          "collected_with": "tools/profile_r05.sh: rocprofv3 --pmc <counter> --kernel-trace, one pass per counter"}
+    sq = {}
+    for n in ("SQ1", "SQ2"):
+        pth = os.path.join(src, f"{name}_pmc_{n}.csv")
+        if os.path.exists(pth):
+            for r in csv.DictReader(open(pth)):
+                if kern.split("<")[0] in r["kernel"]:
+                    sq[r["counter"]] = float(r["mean_per_dispatch"])
+    if "SQ_WAVE_CYCLES" in sq:
+        wc = sq["SQ_WAVE_CYCLES"]
+        t["_r05_" + name]["SQ"] = sq
+        t["_r05_" + name]["derived"] = {
+            "wave_cycles_issuing": sq["SQ_ACTIVE_INST_ANY"] / wc, "wave_cycles_issue_stalled": sq["SQ_WAIT_INST_ANY"] / wc,
+            "wave_cycles_parked_waitcnt_or_barrier": sq["SQ_WAIT_ANY"] / wc,
+            **({"clock_GHz_under_load": sq["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6), "waves": sq.get("SQ_WAVES"),
+                "valu_instructions_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]} if "GRBM_GUI_ACTIVE" in sq else {})}
+        print(name, json.dumps(t["_r05_" + name]["derived"]))
     print(name, "%.3f ms" % ms, "memory side %.2f GB = %.2f x algorithmic, %.0f GB/s" % ((fetch + write) / 1e9, (fetch + write) / alg,
                                                                                        (fetch + write) / ms / 1e6))
 for stale, fresh in (("_round1", "_r05_bf16_config4"), ("_source", "_r05_bf16x3_config4")):
