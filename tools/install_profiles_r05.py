@@ -45,6 +45,8 @@ JOBS = [
      "REQUESTED bytes: 50 candidate rows + the target row per slate slot, rx, dx, nll, lse"),
     ("bf16_config4", "catalog_ce_bf16_pipe_kernel<128, 4>", "config4_bf16_gpus1", 256e6 + R4 * 128 * 4 + 2 * 2 * R4 * 130 * 4,
      "bf16 table once + rx + the ranges' partials written and read"),
+    ("bf16_config3", "catalog_ce_bf16_pipe_kernel<64, 4>", "config3_bf16_gpus1", 12.8e6 + 40960 * 64 * 4 + 3 * 40960 * 66 * 4,
+     "bf16 table once + rx + the 3 ranges' partials"),
     ("bf16x3_config4", "catalog_ce_x3_pipe_kernel<128, 2, 2>", "config4_bf16x3_gpus1", 512e6 + R4 * 128 * 4 + 2 * 2 * R4 * 130 * 4,
      "table image [N, 256] bf16 once + rx + the ranges' partials written and read"),
 ]
@@ -72,11 +74,18 @@ for name, kern, key, alg, what in JOBS:
     if "SQ_WAVE_CYCLES" in sq:
         wc = sq["SQ_WAVE_CYCLES"]
         t["_r05_" + name]["SQ"] = sq
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in sq:   # an MFMA kernel: pipe utilisation as in round 4's entries
+            cyc = sq["GRBM_GUI_ACTIVE"] / 8
+            flops = 4.0 * 40960 * 1e5 * 64 if name == "bf16_config3" else None
+            t["_r05_" + name]["mfma"] = {"gpu_cycles_per_launch": cyc, "clock_GHz_under_load": cyc / (ms * 1e6),
+                                         "mfma_pipe_utilisation": sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * cyc),
+                                         "lds_bank_conflict_cycles": sq.get("SQ_LDS_BANK_CONFLICT"),
+                                         "frac_of_dense_bf16_peak": (flops / (ms * 1e-3) / 2500e12) if flops else None}
         t["_r05_" + name]["derived"] = {
             "wave_cycles_issuing": sq["SQ_ACTIVE_INST_ANY"] / wc, "wave_cycles_issue_stalled": sq["SQ_WAIT_INST_ANY"] / wc,
             "wave_cycles_parked_waitcnt_or_barrier": sq["SQ_WAIT_ANY"] / wc,
             **({"clock_GHz_under_load": sq["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e6), "waves": sq.get("SQ_WAVES"),
-                "valu_instructions_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]} if "GRBM_GUI_ACTIVE" in sq else {})}
+                "valu_instructions_per_wave": sq["SQ_INSTS_VALU"] / sq["SQ_WAVES"]} if "SQ_WAVES" in sq else {})}
         print(name, json.dumps(t["_r05_" + name]["derived"]))
     print(name, "%.3f ms" % ms, "memory side %.2f GB = %.2f x algorithmic, %.0f GB/s" % ((fetch + write) / 1e9, (fetch + write) / alg,
                                                                                        (fetch + write) / ms / 1e6))

@@ -3,6 +3,7 @@
 #   part A: config 4 - the default line (headline + variants incl. candidates_nneg1000 / _nneg50 + pivot_rules); the reference's
 #           DEFAULT training mode as its own line (--n_candidate 1000 / 50): kernel stats + FETCH_SIZE / WRITE_SIZE passes of
 #           candidate_ce_kernel<128, true>; the sampled-rule step (pivotcvae_spt_pi) kernel stats
+#   part E: config 3's kernel on the 3-range plan, four PMC passes
 #   part D: SQ counters of the candidate kernel
 #   part C: config 3 on the round-5 plan; candidate mode on bf16 rows at configs 3 / 5; config 3's full line
 #   part B: the gather evidence on this tree (tools/profile_gather.sh); bf16 / bf16x3 FETCH / WRITE passes at config 4 (traffic.json's
@@ -41,6 +42,13 @@ if [ "$PART" = "A" ]; then
     pmc cand${cn}_config4 WRITE_SIZE "WRITE_SIZE" --n_candidate $cn --steps 3 --warmup 1 $LEAN
   done
   stats spt_config4 --model pivotcvae_spt_pi --steps 3 --warmup 1 $LEAN
+elif [ "$PART" = "E" ]; then
+  # config 3 on the 3-range plan: the four PMC passes of catalog_ce_bf16_pipe_kernel<64, 4>
+  stats bf16_config3 --config 3 --steps 20 --warmup 5 --no-graph $LEAN
+  pmc bf16_config3 SQ1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --config 3 --steps 3 --warmup 1 --no-graph $LEAN
+  pmc bf16_config3 SQ2 "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" --config 3 --steps 3 --warmup 1 --no-graph $LEAN
+  pmc bf16_config3 FETCH_SIZE "FETCH_SIZE" --config 3 --steps 3 --warmup 1 --no-graph $LEAN
+  pmc bf16_config3 WRITE_SIZE "WRITE_SIZE" --config 3 --steps 3 --warmup 1 --no-graph $LEAN
 elif [ "$PART" = "D" ]; then
   # what the candidate kernel's waves do: SQ counters (issuing / issue-stalled / parked at waits), two passes
   pmc cand1000_config4 SQ1 "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" --n_candidate 1000 --steps 3 --warmup 1 --no-graph $LEAN
