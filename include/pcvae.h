@@ -26,7 +26,8 @@
 extern "C" {
 #endif
 
-#define PCVAE_ABI_VERSION 1
+#define PCVAE_ABI_VERSION 2   /* 2 (round 5): pcvae_catalog_ce_sparse_scaled takes the table's precision and a device-word seed;
+                                 pcvae_candidate_ce, pcvae_catalog_sample_at, pcvae_set_words, pcvae_gather_rows_variant are new */
 
 #define PCVAE_OK 0
 #define PCVAE_EINVAL (-1)   /* bad argument / unsupported shape */

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PCVAE_LIB: load an alternative build of the same ABI (kernel A/B experiments, tools/bench_catalog.py)
 LIB_PATH = os.environ.get("PCVAE_LIB") or os.path.join(_HERE, "lib", "libpcvae_hip.so")
 
+ABI_VERSION = 2   # include/pcvae.h: PCVAE_ABI_VERSION
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_SCREENED, PREC_BF16X6 = 0, 1, 2, 3, 4
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
@@ -117,8 +118,9 @@ def lib():
             fn = getattr(handle, name)  # AttributeError here = header/library mismatch
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, _I)
-        if handle.pcvae_abi_version() != 1:
-            raise RuntimeError("libpcvae_hip.so ABI version mismatch")
+        if handle.pcvae_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libpcvae_hip.so ABI version {handle.pcvae_abi_version()} != {ABI_VERSION}: rebuild it "
+                               "(python -m pivotcvae_amd.build)")
         _lib = handle
     return _lib
 
