@@ -26,8 +26,10 @@
 extern "C" {
 #endif
 
-#define PCVAE_ABI_VERSION 2   /* 2 (round 5): pcvae_catalog_ce_sparse_scaled takes the table's precision and a device-word seed;
-                                 pcvae_candidate_ce, pcvae_catalog_sample_at, pcvae_set_words, pcvae_gather_rows_variant are new */
+#define PCVAE_ABI_VERSION 3   /* 2 (round 5): pcvae_catalog_ce_sparse_scaled takes the table's precision and a device-word seed;
+                                 pcvae_candidate_ce, pcvae_catalog_sample_at, pcvae_set_words, pcvae_gather_rows_variant are new
+                                 3 (round 6): pcvae_candidate_ce takes n_items (the dataset's id range of the in-kernel draw);
+                                 PCVAE_GEMM_X6 */
 
 #define PCVAE_OK 0
 #define PCVAE_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -136,6 +138,11 @@ enum { PCVAE_GEMM_FWD = 0, PCVAE_GEMM_DX = 1, PCVAE_GEMM_DX_ACC = 2, PCVAE_GEMM_
  * effect when EVERY problem of a launch carries it (such a launch always uses the 64 x 64 tiles, whatever its size, so a layer's
  * arithmetic does not depend on the batch); a launch with mixed flags computes in exact fp32.                                    */
 #define PCVAE_GEMM_X3 0x100
+/* OR-ed into `kind` (ABI 3): run this problem in bf16x6 arithmetic - every fp32 operand as THREE bf16 components whose sum is the fp32
+ * value exactly, six bf16 MFMAs per product (the dropped component pairs are <= 2^-25 relative), fp32 accumulate: the reference's
+ * fp32 products on the bf16 matrix cores, as PCVAE_PREC_BF16X6 of the catalog kernels.  Same launch rule as PCVAE_GEMM_X3 (every
+ * problem of the launch must carry it; with X3 and X6 mixed the launch runs bf16x3).                                            */
+#define PCVAE_GEMM_X6 0x200
 typedef struct pcvae_gemm_desc {
     int32_t kind;
     int32_t act;
@@ -284,7 +291,7 @@ int pcvae_catalog_ce_scaled(const float* rx, int64_t R, const void* E, const voi
  *     accept with probability sigmoid(s_n) <= 1: exactly that categorical, for ~1 / mean sigmoid dot products per row instead of the
  *     [R, N] score matrix the reference hands to torch.multinomial.  Proposal k of row r = Philox(seed, row_offset + r, k, "RJCT"):
  *     n_k = (x << 32 | y) mod N, u_k = (z + 0.5) 2^-32; idx[r] = n_k of the lowest k with u_k < sigmoid(s) (s = exact fp32 fmaf dot
- *     product of the fp32 table row: E = [N, D] fp32, prec = PCVAE_PREC_F32, E_lo unused).  A row that rejects 4096 proposals is
+ *     product of the fp32 table row: E = [N, D] fp32, prec = PCVAE_PREC_F32, E_lo unused).  A row that rejects 512 proposals is
  *     drawn by Gumbel-max over the whole catalog instead (argmax_n log sigmoid(s_n) - log(-log u_n), u_n = Philox(seed, row, n)).
  *     The reference's torch.multinomial stream cannot be matched: parity is distributional (tests) or by feeding the recorded
  *     draw back in on the host side.                                                                                          */
@@ -352,7 +359,12 @@ int pcvae_dense_ce(const float* p, int64_t ldp, int64_t R, int C, const int64_t*
  *     products and sums stay fp32 (the stated arithmetic of configs 3 / 5; tolerances of the bf16 catalog kernels).           */
 int pcvae_candidate_ce(const float* rx, int64_t R, const void* E, int prec, int64_t N, int D, int Cn, const int64_t* feature,
                        uint64_t seed, uint64_t row_offset, const int64_t* cand, const int64_t* cand_target, float* nll,
-                       float* lse, float* dx, float dx_scale, int64_t* tgt_out, const uint64_t* seed_dev, pcvae_stream_t stream);
+                       float* lse, float* dx, float dx_scale, int64_t* tgt_out, const uint64_t* seed_dev, int64_t n_items,
+                       pcvae_stream_t stream);
+/*     n_items (ABI 3): the in-kernel draw is uniform over [0, n_items), n_items <= N - the DATASET's id range, data_loader.py:23
+ *     (self.max_iid = np.max(slates)) and :46 (np.random.randint(self.max_iid + 1, ...)); a table can have more rows than the
+ *     slates use (the simulators build n_item + 1 rows, env/response_model.py:30).  <= 0: the table's row count N.  Given sets
+ *     (cand != NULL) are bounded by N as before.                                                                              */
 /*     seed_dev (here, in pcvae_catalog_ce_sparse_scaled; row_offset_dev in pcvae_catalog_sample_at): NULL, or a device word the
  *     kernel reads its seed (stream position) from at run time instead of the by-value argument - kernel arguments are frozen when
  *     a step is captured into a hipGraph, a device word is not: pcvae_set_words writes it before each replay.                      */

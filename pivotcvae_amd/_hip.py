@@ -13,13 +13,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # PCVAE_LIB: load an alternative build of the same ABI (kernel A/B experiments, tools/bench_catalog.py)
 LIB_PATH = os.environ.get("PCVAE_LIB") or os.path.join(_HERE, "lib", "libpcvae_hip.so")
 
-ABI_VERSION = 2   # include/pcvae.h: PCVAE_ABI_VERSION
+ABI_VERSION = 3   # include/pcvae.h: PCVAE_ABI_VERSION
 ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
 PREC_F32, PREC_BF16, PREC_BF16X3, PREC_SCREENED, PREC_BF16X6 = 0, 1, 2, 3, 4
 PREC_NAMES = {"f32": PREC_F32, "fp32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "bf16x6": PREC_BF16X6}
 
 GEMM_FWD, GEMM_DX, GEMM_DX_ACC, GEMM_DW = 0, 1, 2, 3
 GEMM_X3 = 0x100   # OR-ed into a problem's kind: bf16x3 arithmetic (include/pcvae.h: PCVAE_GEMM_X3)
+GEMM_X6 = 0x200   # ... bf16x6 arithmetic: fp32-exact products on the bf16 matrix cores (PCVAE_GEMM_X6)
 GEMM_GROUP_MAX = 6
 
 _c = ctypes
@@ -80,7 +81,7 @@ SIGNATURES = {
     "pcvae_candidate_scores": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_candidate_scores_bwd": [_P, _L, _P, _L, _I, _P, _I, _P, _P],
     "pcvae_dense_ce": [_P, _L, _L, _I, _P, _P, _P, _L, _P],
-    "pcvae_candidate_ce": [_P, _L, _P, _I, _L, _I, _I, _P, _U64, _U64, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "pcvae_candidate_ce": [_P, _L, _P, _I, _L, _I, _I, _P, _U64, _U64, _P, _P, _P, _P, _P, _F, _P, _P, _L, _P],
     "pcvae_set_words": [_P, _U64, _U64, _P],
     "pcvae_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _P],
     "pcvae_adam_step_l2": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _F, _F, _P],

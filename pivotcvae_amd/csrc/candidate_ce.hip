@@ -28,8 +28,10 @@ struct CandParams {
     const int64_t* cand;         // [R, Cn] given candidate ids (given mode) or null
     const int64_t* cand_target;  // [R] target columns          (given mode)
     int64_t R, N;
+    int64_t n_draw;              // drawn ids are uniform in [0, n_draw), n_draw <= N: the DATASET's id range (data_loader.py:23, :46
+                                 // max_iid + 1), which is smaller than the table when the table has rows no slate uses
     int Cn;
-    uint64_t seed, row_offset, magic;   // magic = floor((2^64 - 1) / N): exact x % N without a 64-bit division
+    uint64_t seed, row_offset, magic;   // magic = floor((2^64 - 1) / n_draw): exact x % n_draw without a 64-bit division
     const uint64_t* seed_dev;    // or null: the seed is read from this device word instead (a captured graph replays with a new seed)
     float* nll;                  // [R]
     float* lse;                  // [R] or null
@@ -73,8 +75,8 @@ __global__ void __launch_bounds__(256) candidate_ce_kernel(CandParams p) {
             for (int c = c0 + 2 * lane; c < c0 + cnt; c += 128) {   // a lane draws columns c, c + 1 from one Philox call
                 const Philox4 ph = philox4x32_10((uint32_t)grow, (uint32_t)(grow >> 32), (uint32_t)(c >> 1), 0x43414E44u /*"CAND"*/,
                                                  (uint32_t)seed, (uint32_t)(seed >> 32));
-                const int64_t v0 = (int64_t)mod_magic(((uint64_t)ph.x << 32) | ph.y, (uint64_t)p.N, p.magic);
-                const int64_t v1 = (int64_t)mod_magic(((uint64_t)ph.z << 32) | ph.w, (uint64_t)p.N, p.magic);
+                const int64_t v0 = (int64_t)mod_magic(((uint64_t)ph.x << 32) | ph.y, (uint64_t)p.n_draw, p.magic);
+                const int64_t v1 = (int64_t)mod_magic(((uint64_t)ph.z << 32) | ph.w, (uint64_t)p.n_draw, p.magic);
                 const bool two = c + 1 < c0 + cnt;
                 if (store) {
                     lst[c - c0] = (int)v0;
@@ -218,7 +220,7 @@ int launch_cand(const CandParams& p, bool bf16, hipStream_t st) {
 extern "C" int pcvae_candidate_ce(const float* rx, int64_t R, const void* E, int prec, int64_t N, int D, int Cn, const int64_t* feature,
                                   uint64_t seed, uint64_t row_offset, const int64_t* cand, const int64_t* cand_target, float* nll,
                                   float* lse, float* dx, float dx_scale, int64_t* tgt_out, const uint64_t* seed_dev,
-                                  pcvae_stream_t stream) {
+                                  int64_t n_items, pcvae_stream_t stream) {
     PCVAE_REQUIRE(rx && E && nll, "candidate_ce: null pointer");
     PCVAE_REQUIRE(prec == PCVAE_PREC_F32 || prec == PCVAE_PREC_BF16, "candidate_ce: precision mode %d (fp32 or bf16 table rows)", prec);
     const bool bf16 = prec == PCVAE_PREC_BF16;
@@ -229,9 +231,11 @@ extern "C" int pcvae_candidate_ce(const float* rx, int64_t R, const void* E, int
     PCVAE_REQUIRE(((uintptr_t)rx % 16 == 0) && ((uintptr_t)E % 16 == 0) && (!dx || (uintptr_t)dx % 16 == 0),
                   "candidate_ce: rx/E/dx must be 16-byte aligned");
     PCVAE_REQUIRE(cdiv(R, 4) <= 2147483647LL, "candidate_ce: R too large");
+    PCVAE_REQUIRE(n_items <= N, "candidate_ce: n_items=%lld exceeds the table's %lld rows", (long long)n_items, (long long)N);
     if (R == 0) return PCVAE_OK;
-    CandParams p{rx, E, feature, cand, cand_target, R, N, Cn, seed, row_offset, ~0ull / (uint64_t)N, seed_dev, nll, lse, dx, dx_scale,
-                 tgt_out};
+    const int64_t n_draw = n_items > 0 ? n_items : N;   // <= 0: the whole table (ABI 2's behaviour)
+    CandParams p{rx, E, feature, cand, cand_target, R, N, n_draw, Cn, seed, row_offset, ~0ull / (uint64_t)n_draw, seed_dev, nll, lse, dx,
+                 dx_scale, tgt_out};
     switch (D) {
         case 16: return launch_cand<16>(p, bf16, as_stream(stream));
         case 32: return launch_cand<32>(p, bf16, as_stream(stream));

@@ -2,7 +2,7 @@
 #include "common.h"
 #include <atomic>
 #include <mutex>
-#include <set>
+#include <cstdint>
 #include <utility>
 #include <vector>
 
@@ -25,19 +25,58 @@ int check_launch(const char* what) {
     return PCVAE_OK;
 }
 
+// Dynamic-LDS opt-in, once per (kernel, device).  It sits on the launch path of every bf16 / split-bf16 / screened catalog kernel, so
+// the common case - already done - takes no lock: a small open-addressed table of (kernel -> bitmask of devices) read with two
+// relaxed-then-acquire atomic loads.  Only a first call per (kernel, device) takes the mutex, sets the attribute and publishes the bit.
+namespace {
+constexpr int OPTIN_SLOTS = 128;   // the library has ~40 kernels with dynamic LDS over 64 KB; never fills (checked)
+struct OptinSlot { std::atomic<const void*> key{nullptr}; std::atomic<uint64_t> devices{0}; };
+OptinSlot g_optin[OPTIN_SLOTS];
+inline unsigned optin_hash(const void* k) { return (unsigned)(((uintptr_t)k >> 4) * 2654435761u) % OPTIN_SLOTS; }
+}  // namespace
+
 int lds_optin(const void* kernel, int bytes) {
-    static std::mutex mu;
-    static std::set<std::pair<const void*, int>> done;   // (kernel, device)
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const hipError_t eg = hipGetDevice(&dev);
+    if (eg != hipSuccess) {
+        set_error("lds_optin: hipGetDevice: %s", hipGetErrorString(eg));
+        return PCVAE_ELAUNCH;
+    }
+    if (dev < 0 || dev >= 64) {
+        set_error("lds_optin: device ordinal %d outside [0, 64)", dev);
+        return PCVAE_EINVAL;
+    }
+    const uint64_t bit = 1ull << dev;
+    unsigned h = optin_hash(kernel);
+    for (int probe = 0; probe < OPTIN_SLOTS; ++probe, h = (h + 1) % OPTIN_SLOTS) {   // fast path: no lock
+        const void* k = g_optin[h].key.load(std::memory_order_acquire);
+        if (k == kernel) {
+            if (g_optin[h].devices.load(std::memory_order_acquire) & bit) return PCVAE_OK;
+            break;
+        }
+        if (k == nullptr) break;
+    }
+    static std::mutex mu;
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count({kernel, dev})) return PCVAE_OK;
+    h = optin_hash(kernel);
+    int slot = -1;
+    for (int probe = 0; probe < OPTIN_SLOTS; ++probe, h = (h + 1) % OPTIN_SLOTS) {
+        const void* k = g_optin[h].key.load(std::memory_order_acquire);
+        if (k == kernel || k == nullptr) { slot = (int)h; break; }
+    }
+    if (slot < 0) {
+        set_error("lds_optin: table of %d kernels is full", OPTIN_SLOTS);
+        return PCVAE_EINVAL;
+    }
+    if (g_optin[slot].key.load(std::memory_order_acquire) == kernel && (g_optin[slot].devices.load(std::memory_order_acquire) & bit))
+        return PCVAE_OK;   // another thread did it while this one waited for the lock
     const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
         set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) on device %d: %s", bytes, dev, hipGetErrorString(e));
         return PCVAE_ELAUNCH;
     }
-    done.insert({kernel, dev});
+    g_optin[slot].devices.fetch_or(bit, std::memory_order_release);
+    g_optin[slot].key.store(kernel, std::memory_order_release);
     return PCVAE_OK;
 }
 

@@ -156,12 +156,18 @@ extern "C" int pcvae_gemm_stamps(unsigned long long* out) { return (int)hipMemcp
 // splits: ~96 vector ops per chunk), about 1.75x faster on the large layers.  (Measured and dropped, round 3: splitting each staged tile
 // ONCE per workgroup into bf16 LDS images - half the vector ops, plain 16-byte operand reads - needs a second barrier per chunk and
 // 16 KB more LDS (three workgroups per CU instead of five): enc_1 forward 49.0 us against 36.8 us for the in-register split.)
-template <bool A_KC, bool B_KC, int EPI, bool X3>
+// X6 (round 6, XM = 2): the same body with every operand value as THREE bf16 components, c0 = RNE bf16(v), c1 = RNE bf16(v - c0),
+// c2 = v - c0 - c1 (exactly representable: 3 x 8 significand bits hold the 24 of an fp32), and SIX MFMAs per product - c2 c0, c0 c2,
+// c1 c1, c1 c0, c0 c1, c0 c0, smallest first; the dropped c1 c2, c2 c1, c2 c2 are <= 2^-25 relative, below the rounding of an fp32
+// product - every partial product exact in the fp32 accumulator's input: the reference's fp32 arithmetic on the bf16 matrix cores
+// (the catalog kernel's bf16x6, catalog_x3.h, applied to K3).  XM: 0 exact f32 MFMA, 1 bf16x3, 2 bf16x6.
+template <bool A_KC, bool B_KC, int EPI, int XM>
 __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx, const int by, const int bz, char* smem) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
-    const int c16 = lane & 15, gq = lane >> 4;   // X3: MFMA 16x16x32 lane coordinates
+    constexpr bool X3 = XM != 0;                 // (the name of the round-3 code: "runs on the bf16 pipe, 16 x 16 x 32 tiles")
+    const int c16 = lane & 15, gq = lane >> 4;   // X3 / X6: MFMA 16x16x32 lane coordinates
     const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
 
     int64_t kbeg = 0, kend = p.K;
@@ -241,9 +247,9 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                 bsum += *reinterpret_cast<const float*>(sA + k * 256 + ((threadIdx.x ^ (((k >> 2) & 1) << 5)) << 2));
         }
         if constexpr (X3) {
-            // operand tile t (16 rows) of this wave: eight k values kset(gq) of row 16 t + c16, then the hi / lo split
-            bf16x8 ah[2], al[2], bh[2], bl[2];
-            auto fetch = [&](const char* img, const bool kc, const int row, bf16x8& hi, bf16x8& lo) {
+            // operand tile t (16 rows) of this wave: eight k values kset(gq) of row 16 t + c16, then the split into bf16 components
+            bf16x8 ah[2], al[2], bh[2], bl[2], a2[2], b2[2];
+            auto fetch = [&](const char* img, const bool kc, const int row, bf16x8& hi, bf16x8& lo, bf16x8& lo2) {
                 float v[8];
                 if (kc) {
                     const unsigned sw = (unsigned)((row >> 1) & 7);
@@ -262,18 +268,26 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                 for (int e = 0; e < 8; ++e) {
                     const __bf16 hv = (__bf16)v[e];
                     hi[e] = hv;
-                    lo[e] = (__bf16)(v[e] - (float)hv);
+                    const float r1 = v[e] - (float)hv;      // exact
+                    const __bf16 mv = (__bf16)r1;
+                    lo[e] = mv;
+                    if constexpr (XM == 2) lo2[e] = (__bf16)(r1 - (float)mv);   // exact: at most 8 significant bits are left
                 }
             };
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                fetch(sA, A_KC, wm * 32 + 16 * t + c16, ah[t], al[t]);
-                fetch(sB, B_KC, wn * 32 + 16 * t + c16, bh[t], bl[t]);
+                fetch(sA, A_KC, wm * 32 + 16 * t + c16, ah[t], al[t], a2[t]);
+                fetch(sB, B_KC, wn * 32 + 16 * t + c16, bh[t], bl[t], b2[t]);
             }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < 2; ++ct) {
+                    if constexpr (XM == 2) {
+                        acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[rt], bh[ct], acc4[rt][ct], 0, 0, 0);
+                        acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], b2[ct], acc4[rt][ct], 0, 0, 0);
+                        acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], bl[ct], acc4[rt][ct], 0, 0, 0);
+                    }
                     acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[rt], bh[ct], acc4[rt][ct], 0, 0, 0);
                     acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bl[ct], acc4[rt][ct], 0, 0, 0);
                     acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bh[ct], acc4[rt][ct], 0, 0, 0);
@@ -667,7 +681,7 @@ __device__ __forceinline__ void gemm_tile_small(const GemmParams& p, const int b
 // the register-staged small body's 150, set the occupancy of the launches that matter.)
 // (... and launches without a weight gradient - every forward and input-gradient launch - take an instantiation without that body:
 // its split reduction holds 64 more registers, the difference between five and four workgroups per CU.)
-template <bool SMALL, bool HAS_DW, bool X3 = false>
+template <bool SMALL, bool HAS_DW, int X3 = 0>   // X3: the arithmetic XM of the 64 x 64 DMA body (0 f32, 1 bf16x3, 2 bf16x6)
 __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int xcd = blockIdx.x & 7;
@@ -704,7 +718,7 @@ static int check_desc(const pcvae_gemm_desc& d) {
                   (long long)d.K);
     // a tile's DMA lane offsets are 32-bit byte offsets from the tile origin: 64 rows (or 32 k lines) of ld floats
     PCVAE_REQUIRE(d.lda < (1LL << 22) && d.ldb < (1LL << 22), "linear: leading dimension too large");
-    switch (d.kind & ~PCVAE_GEMM_X3) {
+    switch (d.kind & ~(PCVAE_GEMM_X3 | PCVAE_GEMM_X6)) {
         case PCVAE_GEMM_FWD:
             PCVAE_REQUIRE(d.lda >= d.K && d.ldb >= d.K && d.ldc >= d.N, "linear_fwd: bad leading dimension");
             PCVAE_REQUIRE(d.act == PCVAE_ACT_NONE || d.act == PCVAE_ACT_LEAKY || d.act == PCVAE_ACT_RELU,
@@ -759,7 +773,7 @@ constexpr size_t CNT_REGION = 65536;
 static size_t group_ws_bytes(const pcvae_gemm_desc* descs, int n) {
     size_t cnt = 0, part = 0;
     for (int i = 0; i < n; ++i) {
-        if ((descs[i].kind & ~PCVAE_GEMM_X3) != PCVAE_GEMM_DW || descs[i].M <= 0) continue;
+        if ((descs[i].kind & ~(PCVAE_GEMM_X3 | PCVAE_GEMM_X6)) != PCVAE_GEMM_DW || descs[i].M <= 0) continue;
         const DwPlan pl = dw_plan(descs[i], true);
         cnt += (size_t)pl.nx * pl.ny;
         if (pl.nz > 1) part += ((size_t)pl.nx * pl.ny * pl.nz * 4096 + (size_t)pl.ny * pl.nz * 64) * sizeof(float);
@@ -773,13 +787,16 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     GroupParams gp;
     gp.n = 0;
     int64_t tiles64 = 0;
-    bool has_dw = false, x3 = true;   // bf16x3 arithmetic: only if EVERY problem of the launch asks for it (one kernel per launch)
+    // split-bf16 arithmetic: only if EVERY problem of the launch asks for it (one kernel per launch); bf16x6 only if every problem asks
+    // for bf16x6 (a mixed launch runs the narrower bf16x3 - a group is built under ONE ops.mlp_arith, so this does not happen)
+    bool has_dw = false, x3 = true, x6 = true;
     pcvae_gemm_desc local[MAXG];
     for (int i = 0; i < n; ++i) {
         if (int rc = check_desc(descs[i])) return rc;
         local[i] = descs[i];
-        x3 = x3 && (local[i].kind & PCVAE_GEMM_X3) != 0;
-        local[i].kind &= ~PCVAE_GEMM_X3;
+        x3 = x3 && (local[i].kind & (PCVAE_GEMM_X3 | PCVAE_GEMM_X6)) != 0;
+        x6 = x6 && (local[i].kind & PCVAE_GEMM_X6) != 0;
+        local[i].kind &= ~(PCVAE_GEMM_X3 | PCVAE_GEMM_X6);
     }
     descs = local;
     for (int i = 0; i < n; ++i) {
@@ -847,14 +864,20 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     PCVAE_REQUIRE(total * 8 < (1LL << 31), "linear_group: launch too large");
     if (small)   // (exact f32 only: a launch that asks for bf16x3 never takes the K-split 32 x 32 tiles, see above)
         hipLaunchKernelGGL((gemm_group_kernel<true, false>), dim3((unsigned)(total * 8)), dim3(256), SMALL_LDS, as_stream(stream), gp);
+    else if (has_dw && x6)
+        hipLaunchKernelGGL((gemm_group_kernel<false, true, 2>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+                           as_stream(stream), gp);
+    else if (x6)
+        hipLaunchKernelGGL((gemm_group_kernel<false, false, 2>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+                           as_stream(stream), gp);
     else if (has_dw && x3)
-        hipLaunchKernelGGL((gemm_group_kernel<false, true, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+        hipLaunchKernelGGL((gemm_group_kernel<false, true, 1>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
                            as_stream(stream), gp);
     else if (has_dw)
         hipLaunchKernelGGL((gemm_group_kernel<false, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
                            as_stream(stream), gp);
     else if (x3)
-        hipLaunchKernelGGL((gemm_group_kernel<false, false, true>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
+        hipLaunchKernelGGL((gemm_group_kernel<false, false, 1>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,
                            as_stream(stream), gp);
     else
         hipLaunchKernelGGL((gemm_group_kernel<false, false>), dim3((unsigned)(total * 8)), dim3(256), NSTAGE * STAGE_BYTES,

@@ -12,13 +12,14 @@ from .._hip import PREC_F32, PREC_NAMES
 
 
 def _in_mlp_arith(fn):
-    """run a model method with the model's MLP arithmetic selected (ops.mlp_arith): exact fp32 by default, bf16x3 after
-    ``set_mlp_precision("bf16x3")``.  Backward passes re-select the arithmetic of their forward by themselves."""
+    """run a model method with the model's MLP arithmetic selected (ops.mlp_arith): exact fp32 by default, bf16x3 / bf16x6 after
+    ``set_mlp_precision(...)``.  Backward passes re-select the arithmetic of their forward by themselves."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(self, *a, **k):
-        with ops.mlp_arith(getattr(self, "mlp_x3", False)):
+        # (a module pickled before round 6 carries the boolean ``mlp_x3`` instead of ``mlp_precision``)
+        with ops.mlp_arith(self.__dict__.get("mlp_precision", self.__dict__.get("mlp_x3", False))):
             return fn(self, *a, **k)
     return wrapped
 
@@ -60,8 +61,11 @@ class BaseCVAE(nn.Module):
                 self.userEmbed.weight.requires_grad = False
         # precision of the [R,D]x[D,N] catalog contraction: "f32" (exact), "bf16x3", "bf16"
         self.catalog_precision = PREC_F32
-        # arithmetic of the MLP stacks' GEMMs: exact fp32 MFMA (False) or bf16x3 (True: fp32-equivalent, ~2x faster on large layers)
-        self.mlp_x3 = False
+        # arithmetic of the MLP stacks' GEMMs inside the training loss: "f32" (exact fp32 MFMA), "bf16x3", "bf16x6" (ops.MLP_PRECISIONS)
+        self.mlp_precision = "f32"
+        # table rows the GATHER kernels (sparse mask-train kernel, fused candidate kernel) read: the fp32 table - the reference's
+        # arithmetic, whatever ``catalog_precision`` is - unless bf16 rows are asked for explicitly (set_gather_rows("bf16"))
+        self.gather_rows_bf16 = False
         # Philox stream for eps when the caller does not supply one
         self.rng_seed = 0
         self._rng_offset = 0
@@ -73,12 +77,27 @@ class BaseCVAE(nn.Module):
         return self
 
     def set_mlp_precision(self, name):
-        """arithmetic of the MLP GEMMs inside ``loss()`` (forward + backward of a train step): "f32" (exact fp32 MFMA, the default) or
+        """arithmetic of the MLP GEMMs inside ``loss()`` (forward + backward of a train step): "f32" (exact fp32 MFMA, the default),
         "bf16x3" (operands split into bf16 hi + lo in registers, three bf16 MFMAs per product, fp32 accumulate: ELBO terms agree
-        with fp32 to ~1e-6, parameter gradients to ~1e-4 of each tensor's scale; ~1.7x faster on the large layers)"""
-        if name not in ("f32", "fp32", "bf16x3"):
-            raise ValueError(f"MLP arithmetic {name!r}: 'f32' or 'bf16x3'")
-        self.mlp_x3 = name == "bf16x3"
+        with fp32 to ~1e-6, parameter gradients to ~1e-4 of each tensor's scale) or "bf16x6" (three bf16 components per operand = the
+        fp32 value exactly, six MFMAs per product: fp32-exact products, gradients inside the f32 kernel's tolerances)"""
+        name = {"fp32": "f32"}.get(name, name)
+        if name not in ops.MLP_PRECISIONS:
+            raise ValueError(f"MLP arithmetic {name!r}: one of {ops.MLP_PRECISIONS}")
+        self.mlp_precision = name
+        return self
+
+    @property
+    def mlp_x3(self):   # the round-3 name of the switch
+        return self.mlp_precision == "bf16x3"
+
+    def set_gather_rows(self, name):
+        """which table the gather kernels read: "f32" (default: the fp32 table, the reference's arithmetic) or "bf16" (rows of the
+        bf16 copy, widened exactly, fp32 products and sums: half the gathered bytes - the stated arithmetic of configs 3 / 5; loss
+        terms then differ from fp32 rows at the bf16 catalog kernels' tolerance, ~2e-3 relative)"""
+        if name not in ("f32", "fp32", "bf16"):
+            raise ValueError(f"gather rows {name!r}: 'f32' or 'bf16'")
+        self.gather_rows_bf16 = name == "bf16"
         return self
 
     def catalog_table(self):
@@ -140,27 +159,33 @@ class BaseCVAE(nn.Module):
         return ops.catalog_argmax(embeddings.reshape(-1, self.feature_size), self.catalog_table(),
                                   prec=self.catalog_precision)
 
-    def _rec_term(self, rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates=None):
+    def _rec_term(self, rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates=None, n_items=None):
         """the reconstruction term of get_gen_loss from rx [B, S, D], fused loss + gradient, no logits in memory.
 
         ``candidates`` None: the mask-train branch (train_generative.py:58-59): full-catalog softmax CE with the downsample rule.
         ``candidates`` = an int Cn: the candidate-set branch (:52-56) with the sets of data_loader.py:46-58 drawn in-kernel (Philox
-        stream keyed by (mask_seed, global slot)); a pair (sample_candidates [B, S, Cn], sample_targets [B, S]): sets as given."""
+        stream keyed by (mask_seed, global slot)); a pair (sample_candidates [B, S, Cn], sample_targets [B, S]): sets as given.
+        ``n_items``: the id range [0, n_items) of the in-kernel draw - the DATASET's ``max_iid + 1`` (data_loader.py:23, :46), which
+        is smaller than the table when the table has rows no slate uses; None = the table's row count."""
         S, D = s.shape[1], self.feature_size
         rows = rx.reshape(-1, D)
         if candidates is not None:
             if isinstance(candidates, (tuple, list)):
                 cand, tgt = candidates
                 return ops.candidate_ce(rows, self.catalog_table(), cand=cand, cand_target=tgt, inv_count=inv_count,
-                                        unit_upstream=terms_only, prec=self.catalog_precision)
+                                        unit_upstream=terms_only, prec=self._gather_prec())
             return ops.candidate_ce(rows, self.catalog_table(), int(candidates), s.reshape(-1), mask_seed, row_offset * S,
-                                    inv_count=inv_count, unit_upstream=terms_only, prec=self.catalog_precision)
+                                    inv_count=inv_count, unit_upstream=terms_only, prec=self._gather_prec(), n_items=n_items)
         N = self.docEmbed.weight.shape[0]
         keep_prob = 1.0 if n_neg is None else float(n_neg) / N
         if keep_prob > 1.0:
             raise RuntimeError(f"n_neg={n_neg} exceeds the catalog size {N}")
         return ops.catalog_ce(rows, self.catalog_table(), s.reshape(-1), keep_prob, mask_seed, row_offset * S, keep_mask,
-                              self.catalog_precision, inv_count, unit_upstream=terms_only)
+                              self.catalog_precision, inv_count, unit_upstream=terms_only, gather_bf16=self.gather_rows_bf16)
+
+    def _gather_prec(self):
+        from .._hip import PREC_BF16
+        return PREC_BF16 if self.__dict__.get("gather_rows_bf16", False) else PREC_F32
 
     def _user_rows(self, u, B):
         return None if self.noUser else ops.gather_rows(self.userEmbed.weight, u.reshape(-1)).reshape(B, -1)

@@ -68,7 +68,7 @@ class UserListCVAEWithPrior(BaseCVAE):
         return p, rx, z, emb, z_mu, z_logvar
 
     def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
-             eps_offset=None, terms_only=False, candidates=None):
+             eps_offset=None, terms_only=False, candidates=None, n_items=None):
         """Fused counterpart of train_generative.get_gen_loss: neither the [R, N] logits of the mask-train branch nor the
         [R, Cn] ids / rows / logits of the candidate branch (``candidates``: BaseCVAE._rec_term) are ever materialised.
         -> (loss, recLoss, KLD)."""
@@ -84,7 +84,7 @@ class UserListCVAEWithPrior(BaseCVAE):
         else:
             z, self._last_eps, k = ops.latent(z_mu, z_logvar, pmu, plv, eps)
         rx = self.decode(z, cond, u_emb)
-        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates)
+        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates, n_items)
         if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
             return None, rec, k
         return rec + beta * k, rec, k

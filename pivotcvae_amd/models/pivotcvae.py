@@ -74,9 +74,10 @@ class UserPivotCVAE(BaseCVAE):
         return self._prior_from(self.get_condition(r), self._user_rows(u, r.shape[0]))
 
     # ---- pivot selection ------------------------------------------------------------------------
-    def _pivot_index(self, rule, pivot_output, true_pivot, sample_offset=None):
+    def _pivot_index(self, rule, pivot_output, true_pivot, sample_offset=None, pivot_row=None):
         """Item id of the pivot for one of the rules gt / pt|pi / spt|spi / sgt (never differentiable).
-        ``sample_offset``: stream position (a global slate index) of the sampled rules; None = this model's running offset."""
+        ``sample_offset``: stream position (a global slate index) of the sampled rules; None = this model's running offset.
+        ``pivot_row``: the ground-truth pivot's table row [B, D] when the caller already holds it (sgt: no second gather)."""
         if rule == "gt":
             return true_pivot
         if self.pivot_override is not None and rule in ("spt", "spi", "sgt"):
@@ -87,26 +88,26 @@ class UserPivotCVAE(BaseCVAE):
         if rule in ("spt", "spi"):
             query = pivot_output.detach()
         else:  # sgt: scores of the ground-truth pivot's own embedding against the catalog
-            query = ops.gather_rows(self.docEmbed.weight, true_pivot)
+            query = pivot_row if pivot_row is not None else ops.gather_rows(self.docEmbed.weight, true_pivot)
         B = query.shape[0]
         if sample_offset is None:
             off = self._next_offset(B)
         else:   # an int, or (int, device word added to it) for a hipGraph-replayed step
             off = sample_offset if isinstance(sample_offset, (tuple, list)) else int(sample_offset)
-        return ops.catalog_sample(query, table, seed=self.rng_seed ^ 0x5A17, row_offset=off, prec=self.catalog_precision)
+        return ops.catalog_sample(query, table, seed=self.rng_seed ^ 0x5A17, row_offset=off)
 
-    def pick_pivot(self, pivot_output, true_pivot, sample_offset=None):
+    def pick_pivot(self, pivot_output, true_pivot, sample_offset=None, pivot_row=None):
         """-> pivot embedding [B, D]; rule = TRAIN_RULE when a true pivot is given, else INFER_RULE."""
         training = len(true_pivot) > 0
-        p = self._pivot_index(self.TRAIN_RULE if training else self.INFER_RULE, pivot_output, true_pivot, sample_offset)
+        p = self._pivot_index(self.TRAIN_RULE if training else self.INFER_RULE, pivot_output, true_pivot, sample_offset, pivot_row)
         self.last_pivot = p
         return ops.gather_rows(self.docEmbed.weight, p)
 
-    def decode(self, z, c, u_emb=None, true_pivot=[], sample_offset=None):
+    def decode(self, z, c, u_emb=None, true_pivot=[], sample_offset=None, pivot_row=None):
         B = z.shape[0]
         x = ops.concat([z, c] if self.noUser else [z, c, u_emb])
         pivot_output = ops.mlp(x, self._mlp_layers("psm", self._n_psm), last_linear=True)
-        pivot_emb = self.pick_pivot(pivot_output, true_pivot, sample_offset)
+        pivot_emb = self.pick_pivot(pivot_output, true_pivot, sample_offset, pivot_row)
         return self._complete(z, c, u_emb, pivot_emb)
 
     def _complete(self, z, c, u_emb, pivot_emb):
@@ -134,10 +135,11 @@ class UserPivotCVAE(BaseCVAE):
         return p, rx, z, emb, z_mu, z_logvar
 
     def loss(self, s, r, u, beta, n_neg=None, eps=None, keep_mask=None, mask_seed=0, row_offset=0, inv_count=None,
-             eps_offset=None, terms_only=False, sample_offset=None, candidates=None):
+             eps_offset=None, terms_only=False, sample_offset=None, candidates=None, n_items=None):
         """Fused counterpart of train_generative.get_gen_loss -> (loss, recLoss, KLD).  ``candidates`` None: the mask-train
         branch; an int Cn / a pair (sample_candidates, sample_targets): the candidate-set branch - the reference's default mode
-        (train_generative.py:52-57, 270-274) - from ONE fused launch (BaseCVAE._rec_term, ops.candidate_ce).
+        (train_generative.py:52-57, 270-274) - from ONE fused launch (BaseCVAE._rec_term, ops.candidate_ce); ``n_items`` = the id range
+        of the in-kernel draw (the dataset's ``max_iid + 1``, data_loader.py:23, :46; default: the table's row count).
 
         The [B*S, N] logits never exist: the full-catalog softmax CE (with the reference's downsample
         semantics when n_neg < N) and its gradient come from one streaming pass over the catalog.
@@ -152,7 +154,7 @@ class UserPivotCVAE(BaseCVAE):
         if self.TRAIN_RULE == "gt" and self.FUSED_TRAIN_PATH and r.shape[1] == S and \
                 ops.heads_adjacent(self.encmu, self.enclogvar) and ops.heads_adjacent(self.priorMu, self.priorLogvar):
             return self._loss_fused(s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only,
-                                    candidates)
+                                    candidates, n_items)
         cond = self.get_condition(r)
         emb = ops.gather_rows(self.docEmbed.weight, s.reshape(-1), group=S)
         u_emb = self._user_rows(u, B)
@@ -170,8 +172,15 @@ class UserPivotCVAE(BaseCVAE):
             pivot_emb = emb[:, : self.feature_size]
             rx = self._complete(z, cond, u_emb, pivot_emb)
         else:
-            rx = self.decode(z, cond, u_emb=u_emb, true_pivot=s[:, 0].contiguous(), sample_offset=sample_offset)
-        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates)
+            # no torch op on the step's path (round 5's kernel trace showed one strided-copy kernel per spt / sgt step: the
+            # ``s[:, 0].contiguous()`` that stood here): pt / spt only need to know THAT a true pivot exists; sgt needs its table row,
+            # which is the first D columns of the slate's gathered rows (one library copy kernel, no second gather)
+            pivot_row = None
+            if self.TRAIN_RULE == "sgt":
+                pivot_row = torch.empty(B, self.feature_size, dtype=torch.float32, device=emb.device)
+                ops.copy2d(emb[:, : self.feature_size], pivot_row)
+            rx = self.decode(z, cond, u_emb=u_emb, true_pivot=s[:, 0], sample_offset=sample_offset, pivot_row=pivot_row)
+        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates, n_items)
         if terms_only:   # the caller seeds backward with (1, beta) and forms the logged loss itself: no mul / add launches
             return None, rec, k
         return rec + beta * k, rec, k
@@ -179,7 +188,7 @@ class UserPivotCVAE(BaseCVAE):
     FUSED_TRAIN_PATH = True   # tests switch it off to compare the two routes
 
     def _loss_fused(self, s, r, u, beta, n_neg, eps, keep_mask, mask_seed, row_offset, inv_count, eps_offset, terms_only,
-                    candidates=None):
+                    candidates=None, n_items=None):
         """loss() for the ground-truth pivot rule with a trainer's flat parameter buffer attached: the same arithmetic in fewer,
         larger launches - one kernel assembles the three stack inputs (condition, gathers, concatenations), each stack's two heads
         are one N = 2 Z GEMM, reparametrize + KL are one kernel that writes z straight into the slate-completion input, and that
@@ -199,7 +208,7 @@ class UserPivotCVAE(BaseCVAE):
             scm_x, self._last_eps, k = ops.latent_packed(y_enc, y_prior, scm_in, eps, Z=Z)
         self.last_pivot = s[:, 0]
         rx = ops.mlp_into(scm_x, self._mlp_layers("scm", self._n_scm), rx, D, grad_cols=Z)   # only z carries a gradient
-        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates)
+        rec = self._rec_term(rx, s, n_neg, keep_mask, mask_seed, row_offset, inv_count, terms_only, candidates, n_items)
         if terms_only:
             return None, rec, k
         return rec + beta * k, rec, k

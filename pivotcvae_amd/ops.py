@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _hip
-from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, GEMM_DW, GEMM_DX, GEMM_DX_ACC, GEMM_FWD, GEMM_GROUP_MAX, GEMM_X3, PREC_BF16, PREC_BF16X3, PREC_BF16X6,
+from ._hip import (ACT_LEAKY, ACT_NONE, ACT_RELU, GEMM_DW, GEMM_DX, GEMM_DX_ACC, GEMM_FWD, GEMM_GROUP_MAX, GEMM_X3, GEMM_X6, PREC_BF16, PREC_BF16X3, PREC_BF16X6,
                    PREC_F32, PREC_SCREENED, GemmDesc, check, lib, ptr, require_device, stream)
 
 F32 = torch.float32
@@ -152,27 +152,46 @@ def _timed_gemm(flops, launch):
     t[1](tok, flops, 1)
 
 
-# Arithmetic of the MLP GEMMs: exact fp32 MFMA (default: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain) or bf16x3 (operands split
-# into bf16 hi + lo in registers, three bf16 MFMAs per product, fp32 accumulate - fp32-equivalent at the GEMM tests' tolerances,
-# ~2x faster on the MFMA-bound layers; csrc/gemm_f32.hip).  A model sets it around its forward (BaseCVAE.set_mlp_precision); an
-# autograd node remembers the arithmetic of its forward and runs its backward in the same one.
-_MLP_X3 = False
+# Arithmetic of the MLP GEMMs (csrc/gemm_f32.hip):
+#   "f32"     exact fp32 MFMA (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain);
+#   "bf16x3"  operands split into bf16 hi + lo in registers, three bf16 MFMAs per product, fp32 accumulate - 16-bit-mantissa operands,
+#             2^-18 relative per product: a stated-tolerance fast path, fp32-equivalent at the GEMM tests' tolerances;
+#   "bf16x6"  (round 6) every fp32 operand as THREE bf16 components whose sum is the fp32 value exactly, six bf16 MFMAs per product
+#             (the dropped pairs are <= 2^-25 relative: below the rounding of an fp32 product), fp32 accumulate - the reference's fp32
+#             arithmetic on the bf16 matrix cores, the catalog kernel's bf16x6 applied to K3.
+# A model sets it around its training loss (BaseCVAE.set_mlp_precision); an autograd node remembers the arithmetic of its forward
+# and runs its backward in the same one.
+MLP_PRECISIONS = ("f32", "bf16x3", "bf16x6")
+MLP_ARITHMETIC = {"f32": "f32 (v_mfma_f32_32x32x2_f32)",
+                  "bf16x3": "bf16x3: operands as bf16 hi+lo in registers, 3 bf16 MFMAs per product, fp32 accumulate (train step only; "
+                            "generation: exact f32)",
+                  "bf16x6": "bf16x6: fp32 operands as 3 bf16 components in registers, 6 bf16 MFMAs per product, fp32 accumulate - "
+                            "fp32-exact products (train step only; generation: exact f32)"}
+_MLP_MODE = 0   # 0 f32, 1 bf16x3, 2 bf16x6 (the flag OR-ed into a GEMM descriptor's kind)
+_MODE_OF = {"f32": 0, "fp32": 0, "bf16x3": 1, "bf16x6": 2, False: 0, True: 1, None: 0, 0: 0, 1: 1, 2: 2}
+
+
+def default_mlp_precision(catalog_dtype):
+    """the MLP arithmetic that goes with a catalog arithmetic: bf16x3 where the catalog contraction is bf16x3 / bf16 (a stated-
+    tolerance step end to end), bf16x6 where it is bf16x6 (fp32-exact products on the bf16 matrix cores end to end), exact f32 else"""
+    return {"bf16x3": "bf16x3", "bf16": "bf16x3", "bf16x6": "bf16x6"}.get(catalog_dtype, "f32")
 
 
 class mlp_arith:
-    """``with mlp_arith(True):`` the GEMMs launched inside run in bf16x3 (False: exact fp32)"""
+    """``with mlp_arith("bf16x6"):`` the GEMMs launched inside run in that arithmetic ("f32" / "bf16x3" / "bf16x6"; the round-3
+    booleans still mean f32 / bf16x3)"""
 
-    def __init__(self, x3):
-        self.x3 = bool(x3)
+    def __init__(self, mode):
+        self.mode = _MODE_OF[mode]
 
     def __enter__(self):
-        global _MLP_X3
-        self.prev, _MLP_X3 = _MLP_X3, self.x3
+        global _MLP_MODE
+        self.prev, _MLP_MODE = _MLP_MODE, self.mode
         return self
 
     def __exit__(self, *exc):
-        global _MLP_X3
-        _MLP_X3 = self.prev
+        global _MLP_MODE
+        _MLP_MODE = self.prev
         return False
 
 
@@ -185,7 +204,7 @@ def _one(build):
 
 
 def linear_fwd_raw(x, W, b, act, out=None):
-    if _MLP_X3:
+    if _MLP_MODE:
         return _one(lambda g: g.fwd(x, W, b, act, out=out))
     x = _c2d(x)
     M, K = x.shape
@@ -201,7 +220,7 @@ def linear_fwd_raw(x, W, b, act, out=None):
 
 
 def linear_bwd_input_raw(gy, W, xact=None, out=None):
-    if _MLP_X3:
+    if _MLP_MODE:
         return _one(lambda g: g.dx(gy, W, xact=xact, out=out))
     gy = _c2d(gy)
     M, N = gy.shape
@@ -230,10 +249,10 @@ class GemmGroup:
 
     def __init__(self):
         self.descs, self.keep, self.flops = [], [], 0.0
-        self.x3 = _MLP_X3
+        self.mode = _MLP_MODE
 
     def _add(self, kind, act, a, b, c, aux, aux_out, M, N, K):
-        d = GemmDesc(kind | (GEMM_X3 if self.x3 else 0), act, a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), c.data_ptr(), _ld(c),
+        d = GemmDesc(kind | (0, GEMM_X3, GEMM_X6)[self.mode], act, a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), c.data_ptr(), _ld(c),
                      aux.data_ptr() if aux is not None else None, (_ld(aux) if aux is not None and aux.dim() == 2 else 0),
                      aux_out.data_ptr() if aux_out is not None else None, M, N, K)
         for x in (a, b, c, aux, aux_out):
@@ -242,6 +261,10 @@ class GemmGroup:
         self.descs.append(d)
         self.keep += [a, b, c, aux, aux_out]
         self.flops += 2.0 * M * N * K
+
+    @property
+    def x3(self):   # (round-3 name) does this group run on the bf16 matrix cores (bf16x3 or bf16x6)?
+        return self.mode != 0
 
     def fwd(self, x, W, b, act, out=None):
         x = _c2d(x)
@@ -300,7 +323,7 @@ class _MLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, last_linear, *params):
-        ctx.x3 = _MLP_X3
+        ctx.x3 = _MLP_MODE
         with gemm_span():
             return _MLP._forward_impl(ctx, x, last_linear, *params)
 
@@ -358,7 +381,7 @@ class _MLP(torch.autograd.Function):
 
 def linear_bwd_input_acc_raw(gy, W, xact, out):
     """out = (out + gy @ W) * LeakyReLU'(xact)   (xact may be None: no mask)."""
-    if _MLP_X3:
+    if _MLP_MODE:
         return _one(lambda g: g.dx(gy, W, xact=xact, out=out, accumulate=True))
     gy = _c2d(gy)
     M, N = gy.shape
@@ -379,7 +402,7 @@ class _MLPHeads(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_trunk, *params):
-        ctx.x3 = _MLP_X3
+        ctx.x3 = _MLP_MODE
         with gemm_span():
             return _MLPHeads._forward_impl(ctx, x, n_trunk, *params)
 
@@ -457,6 +480,7 @@ def mlp_heads(x, trunk, head_a, head_b):
 # ---------------------------------------------------------------- fused training-path operators (fewer, larger launches)
 # bench.py sets this to (begin() -> token, end(token, bytes_moved)) to bracket the launch with HIP events inside real train steps
 ASSEMBLE_TIMING = None
+ASSEMBLE_ROW_ALIGN = int(os.environ.get("PCVAE_ASSEMBLE_ROW_ALIGN", "32"))   # floats (32 = a 128-byte cache line; 1 = packed rows)
 
 
 def assemble_inputs(E, U, s, r, u, Z):
@@ -471,9 +495,16 @@ def assemble_inputs(E, U, s, r, u, Z):
     s = s.to(torch.int64).contiguous()
     r = r.to(F32).contiguous()
     uu = None if U is None else u.reshape(-1).to(torch.int64).contiguous()
-    enc_in = torch.empty(B, S * D + C + ud, dtype=F32, device=dev)
-    prior_in = torch.empty(B, C + ud, dtype=F32, device=dev)
-    scm_in = torch.empty(B, Z + C + D + ud, dtype=F32, device=dev)
+    # rows of the three inputs start on ASSEMBLE_ROW_ALIGN-float boundaries (their widths - 1419, 139, 283 at config 4 - are odd:
+    # packed rows start on arbitrary 4-byte boundaries and every 512-byte table row written into them ends in two partial cache
+    # lines); the GEMMs take the leading dimension as given, so the padding costs nothing downstream
+    def rows(width):
+        ld = -(-width // ASSEMBLE_ROW_ALIGN) * ASSEMBLE_ROW_ALIGN
+        return torch.empty(B, ld, dtype=F32, device=dev)[:, :width]
+
+    enc_in = rows(S * D + C + ud)
+    prior_in = rows(C + ud)
+    scm_in = rows(Z + C + D + ud)
     rx = torch.empty(B, S * D, dtype=F32, device=dev)
     timing = ASSEMBLE_TIMING
     tok = timing[0]() if timing is not None else None
@@ -516,7 +547,7 @@ class _StacksPacked(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, *tensors):
-        ctx.x3 = _MLP_X3
+        ctx.x3 = _MLP_MODE
         with gemm_span():
             return _StacksPacked._forward_impl(ctx, spec, *tensors)
 
@@ -664,7 +695,7 @@ class _MLPInto(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, out_buf, col0, grad_cols, *params):
-        ctx.x3 = _MLP_X3
+        ctx.x3 = _MLP_MODE
         with gemm_span():
             return _MLPInto._forward_impl(ctx, x, out_buf, col0, grad_cols, *params)
 
@@ -1060,10 +1091,17 @@ def sparse_ce_applies(keep_prob, N):
     return 0.0 < keep_prob <= SPARSE_MAX_KEEP_PROB and N < 2 ** 31 - 1
 
 
+def gather_rows_are_bf16(model):
+    """do this model's gather kernels read bf16 table rows?  (an explicit switch - BaseCVAE.set_gather_rows("bf16") - never implied
+    by the catalog contraction's arithmetic: the validation loss of the epoch loop and get_gen_loss's candidate branch stay the
+    reference's fp32 arithmetic unless asked otherwise)"""
+    return bool(getattr(model, "gather_rows_bf16", False)) and model.docEmbed.weight.shape[1] in BF16_DIMS
+
+
 def _gather_table(table, D0, prec):
-    """the table the gather kernels (sparse K5, K9) read for a precision mode -> (tensor, width, PREC_F32 | PREC_BF16): bf16 rows
-    (half the gathered bytes; widened exactly, fp32 products and sums) where the model computes its catalog contraction in bf16
-    and the width has a bf16 table (configs 3 / 5 as stated); the fp32 table - the reference's arithmetic - in every other mode"""
+    """the table the gather kernels (sparse K5, K9) read -> (tensor, width, PREC_F32 | PREC_BF16).  ``prec`` = PREC_BF16 (the caller
+    asked for bf16 rows EXPLICITLY: half the gathered bytes; widened exactly, fp32 products and sums) and a width that has a bf16
+    table; the fp32 table - the reference's arithmetic - otherwise"""
     if prec == PREC_BF16 and D0 in BF16_DIMS:
         return table.operands(PREC_BF16)[0], D0, PREC_BF16
     E, D = table.padded()
@@ -1122,8 +1160,9 @@ def _pad_cols(x, Dp):
 
 
 def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32,
-                   want_dx=True, dx_scale=1.0):
-    """-> (nll [R], lse [R], dx [R, D] * dx_scale or None); see pcvae_catalog_ce in include/pcvae.h."""
+                   want_dx=True, dx_scale=1.0, gather_bf16=False):
+    """-> (nll [R], lse [R], dx [R, D] * dx_scale or None); see pcvae_catalog_ce in include/pcvae.h.  ``gather_bf16``: the sparse
+    kept-rows kernel (keep_prob << 1) reads bf16 table rows (an explicit switch; default: the fp32 table whatever ``prec`` is)."""
     table = _as_table(table)
     require_device(rx, table.weight, target, keep_mask)
     rx = _c2d(rx).contiguous()
@@ -1138,7 +1177,8 @@ def catalog_ce_raw(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_
             raise ValueError("catalog_ce: keep_mask must be [R, N]")
     prec = effective_precision(prec, D0)
     if keep_mask is None and keep_prob < 1.0 and sparse_ce_applies(keep_prob, N):
-        return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx, dx_scale, prec)
+        return catalog_ce_sparse_raw(rx, table, target, keep_prob, seed, row_offset, want_dx, dx_scale,
+                                     PREC_BF16 if gather_bf16 else PREC_F32)
     if torch.is_tensor(seed):
         if keep_mask is None and keep_prob < 1.0:
             raise RuntimeError("a device-word mask seed (hipGraph replay) exists for the sparse kept-rows kernel only "
@@ -1193,10 +1233,10 @@ class _CatalogCE(torch.autograd.Function):
     and backward hands it on without a scaling launch.  Any other upstream gradient is still applied correctly (one launch)."""
 
     @staticmethod
-    def forward(ctx, rx, table, target, keep_prob, seed, row_offset, keep_mask, prec, inv_count, unit_upstream):
+    def forward(ctx, rx, table, target, keep_prob, seed, row_offset, keep_mask, prec, inv_count, unit_upstream, gather_bf16):
         want_dx = rx.requires_grad
         nll, _lse, dx = catalog_ce_raw(rx.detach(), table, target, keep_prob, seed, row_offset, keep_mask, prec, want_dx,
-                                       dx_scale=float(inv_count) if unit_upstream else 1.0)
+                                       dx_scale=float(inv_count) if unit_upstream else 1.0, gather_bf16=gather_bf16)
         out = torch.empty((), dtype=F32, device=rx.device)
         check(lib().pcvae_sum(ptr(nll, F32), nll.numel(), float(inv_count), ptr(out, F32), stream()), "sum")
         ctx.inv_count = float(inv_count)
@@ -1209,24 +1249,24 @@ class _CatalogCE(torch.autograd.Function):
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
         if ctx.unit and _is_unit_seed(g):   # the registered constant 1: the kernel already wrote dx * inv_count
-            return (dx,) + (None,) * 9
+            return (dx,) + (None,) * 10
         g = g.contiguous()
         out = torch.empty_like(dx)
         # unit_upstream but some OTHER upstream gradient: dx is pre-scaled by inv_count, only g is left to apply
         check(lib().pcvae_scale_rows(ptr(dx, F32), _ld(dx), ptr(out, F32), _ld(out), dx.shape[0], dx.shape[1],
                                      ptr(g, F32), 1.0 if ctx.unit else ctx.inv_count, stream()), "scale_rows")
-        return (out,) + (None,) * 9
+        return (out,) + (None,) * 10
 
 
 def catalog_ce(rx, table, target, keep_prob=1.0, seed=0, row_offset=0, keep_mask=None, prec=PREC_F32, inv_count=None,
-               unit_upstream=False):
+               unit_upstream=False, gather_bf16=False):
     """CrossEntropyLoss(downsample(rx @ E^T), target) without the [R, N] logits (train_generative.py:59).
 
     ``inv_count`` defaults to 1/R (the 'mean'); data-parallel ranks pass 1/(R_local * world_size).
     """
     R = rx.shape[0]
     return _CatalogCE.apply(rx, _as_table(table), target, keep_prob, seed, row_offset, keep_mask, prec,
-                            (1.0 / R) if inv_count is None else inv_count, unit_upstream)
+                            (1.0 / R) if inv_count is None else inv_count, unit_upstream, gather_bf16)
 
 
 # exact argmax through bf16 screening pays off once the catalog is large; below this the plain f32 kernel is used
@@ -1270,12 +1310,12 @@ def catalog_argmax(x, table, prec=PREC_F32, return_best=False, screened=None):
     return (idx, best) if return_best else idx
 
 
-def catalog_sample(x, table, seed=0, row_offset=0, prec=PREC_F32):
+def catalog_sample(x, table, seed=0, row_offset=0):
     """idx[r] ~ Categorical(sigmoid(<x_r, E_n>)) (models/pivotcvae.py:349-351), drawn by REJECTION sampling: propose a uniform item,
     accept it with probability sigmoid(score) - exactly the reference's distribution for ~2 dot products per row instead of the
-    [R, N] score matrix (csrc/catalog_sample.hip; rows that reject 4096 proposals in a row fall back to the exact Gumbel-max
-    kernel).  Scores are exact fp32 of the fp32 table whatever ``prec`` the training loss runs in: they cost nothing now, so
-    ``prec`` (kept for call compatibility) has nothing left to select."""
+    [R, N] score matrix (csrc/catalog_sample.hip; rows that reject 512 proposals in a row fall back to the exact Gumbel-max
+    kernel).  Scores are exact fp32 of the fp32 table whatever arithmetic the training loss runs in (there is no precision
+    argument: round 5's ignored ``prec`` is gone)."""
     table = _as_table(table)
     require_device(x, table.weight)
     x = _c2d(x.detach()).contiguous()
@@ -1351,10 +1391,11 @@ def candidate_draw(slates, n_items, n_candidate, seed=0, row_offset=0, raw=None)
 
 
 def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offset=0, cand=None, cand_target=None, want_dx=True,
-                     dx_scale=1.0, want_target=False, prec=PREC_F32):
+                     dx_scale=1.0, want_target=False, prec=PREC_F32, n_items=None):
     """The candidate-set softmax CE in ONE launch (pcvae_candidate_ce): -> (nll [R], lse [R], dx [R, D] * dx_scale or None,
     target column [R] or None).  Either ``cand`` [R, Cn] + ``cand_target`` [R] (sets as given: a batch of the reference's dataset,
-    a recorded draw) or ``feature`` [R] + ``n_candidate`` (sets drawn in-kernel from the stream of ``candidate_draw``)."""
+    a recorded draw) or ``feature`` [R] + ``n_candidate`` (sets drawn in-kernel from the stream of ``candidate_draw(slates,
+    n_items, ...)``: uniform ids in [0, n_items), the dataset's ``max_iid + 1`` - data_loader.py:23, :46; None = the table's rows)."""
     table = _as_table(table)
     require_device(rx, table.weight, feature, cand, cand_target)
     rx = _c2d(rx).contiguous()
@@ -1378,6 +1419,8 @@ def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offs
         feature = feature.reshape(-1).to(torch.int64).contiguous()
         if feature.numel() != R:
             raise ValueError("candidate_ce: one true item per row expected")
+        if n_items is not None and not 0 < int(n_items) <= N:
+            raise ValueError(f"candidate_ce: n_items={n_items} must lie in (0, {N}] (the table's row count)")
     nll = torch.empty(R, dtype=F32, device=rx.device)
     lse = torch.empty(R, dtype=F32, device=rx.device)
     dx = torch.empty(R, D, dtype=F32, device=rx.device) if want_dx else None
@@ -1387,7 +1430,7 @@ def candidate_ce_raw(rx, table, n_candidate=None, feature=None, seed=0, row_offs
     seed_val, seed_dev = _word(seed)
     check(lib().pcvae_candidate_ce(ptr(rx, F32), R, ptr(E), gprec, N, D, Cn, ptr(feature), seed_val, int(row_offset), ptr(cand),
                                    ptr(cand_target), ptr(nll, F32), ptr(lse, F32), ptr(dx), float(dx_scale), ptr(tcol), seed_dev,
-                                   stream()), "candidate_ce")
+                                   0 if n_items is None else int(n_items), stream()), "candidate_ce")
     if timing:
         timing[1](tok)
     if dx is not None and D != D0:
@@ -1400,10 +1443,10 @@ class _CandidateCE(torch.autograd.Function):
     _CatalogCE: the kernel writes the direction times inv_count and a registered constant-1 seed hands it on without a launch)."""
 
     @staticmethod
-    def forward(ctx, rx, table, n_candidate, feature, seed, row_offset, cand, cand_target, inv_count, unit_upstream, prec):
+    def forward(ctx, rx, table, n_candidate, feature, seed, row_offset, cand, cand_target, inv_count, unit_upstream, prec, n_items):
         want_dx = rx.requires_grad
         nll, _lse, dx, _t = candidate_ce_raw(rx.detach(), table, n_candidate, feature, seed, row_offset, cand, cand_target, want_dx,
-                                             dx_scale=float(inv_count) if unit_upstream else 1.0, prec=prec)
+                                             dx_scale=float(inv_count) if unit_upstream else 1.0, prec=prec, n_items=n_items)
         out = torch.empty((), dtype=F32, device=rx.device)
         check(lib().pcvae_sum(ptr(nll, F32), nll.numel(), float(inv_count), ptr(out, F32), stream()), "sum")
         ctx.inv_count = float(inv_count)
@@ -1416,23 +1459,23 @@ class _CandidateCE(torch.autograd.Function):
     def backward(ctx, g):
         (dx,) = ctx.saved_tensors
         if ctx.unit and _is_unit_seed(g):
-            return (dx,) + (None,) * 10
+            return (dx,) + (None,) * 11
         g = g.contiguous()
         out = torch.empty_like(dx)
         check(lib().pcvae_scale_rows(ptr(dx, F32), _ld(dx), ptr(out, F32), _ld(out), dx.shape[0], dx.shape[1],
                                      ptr(g, F32), 1.0 if ctx.unit else ctx.inv_count, stream()), "scale_rows")
-        return (out,) + (None,) * 10
+        return (out,) + (None,) * 11
 
 
 def candidate_ce(rx, table, n_candidate=None, feature=None, seed=0, row_offset=0, cand=None, cand_target=None, inv_count=None,
-                 unit_upstream=False, prec=PREC_F32):
+                 unit_upstream=False, prec=PREC_F32, n_items=None):
     """CrossEntropyLoss(bmm(docEmbed(candidates), rx), sample_targets) (models/pivotcvae.py:265-271, train_generative.py:52-57)
     without the [R, Cn] ids, the [R, Cn, D] rows or the [R, Cn] logits: loss and d rx from one launch.
 
     ``inv_count`` defaults to 1/R (the 'mean'); data-parallel ranks pass 1/(R_local * world_size)."""
     R = rx.shape[0]
     return _CandidateCE.apply(rx, _as_table(table), n_candidate, feature, seed, row_offset, cand, cand_target,
-                              (1.0 / R) if inv_count is None else inv_count, unit_upstream, prec)
+                              (1.0 / R) if inv_count is None else inv_count, unit_upstream, prec, n_items)
 
 
 def urm_forward(E, item_bias, U, user_bias, slates, users, pos_bias=None, pos_dep=None, mr_factor=None):

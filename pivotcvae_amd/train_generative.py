@@ -51,12 +51,16 @@ def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None, seed=0,
         # any other lossFun is called as given on the materialised candidate logits of forward()
         plain_ce = isinstance(lossFun, torch.nn.CrossEntropyLoss) and lossFun.weight is None and \
             lossFun.reduction == "mean" and lossFun.ignore_index == -100 and getattr(lossFun, "label_smoothing", 0.0) == 0.0
+        # ids are drawn from the DATASET's range [0, max_iid + 1) (data_loader.py:23, :46) when the model carries it
+        # (``model.candidateIdRange``, set by train_on_dataset from ``trainset.max_iid``); the table's row count otherwise
+        n_items = getattr(model, "candidateIdRange", None)
         if plain_ce and hasattr(model, "loss"):
             cands = (cand, tgt) if given else int(getattr(model, "nCandidate", n_neg))
-            return model.loss(slates, targets, users, beta, eps=eps, mask_seed=seed, row_offset=row_offset, candidates=cands)
+            return model.loss(slates, targets, users, beta, eps=eps, mask_seed=seed, row_offset=row_offset, candidates=cands,
+                              n_items=None if given else n_items)
         pMu, pLogvar = model.get_prior(targets, users)
         if not given:
-            N = model.docEmbed.weight.shape[0]
+            N = model.docEmbed.weight.shape[0] if n_items is None else int(n_items)
             cand, tgt = ops.candidate_draw(slates, N, int(getattr(model, "nCandidate", n_neg)), seed=seed,
                                            row_offset=row_offset * slates.shape[1])
         pred, _rx, _z, _emb, mu, logvar = model.forward(slates, targets, candidates=cand, u=users, eps=eps)
@@ -118,17 +122,24 @@ class Trainer:
     injectable so the collective logic can be exercised on CPU with gloo in tests.
     """
 
+    REDUCE_TIMING = None   # bench.py: (begin() -> token, end(token)) around the gradient all-reduce (HIP events on the launch stream)
+
     def __init__(self, model, lr, beta, n_neg=None, process_group=None, loss_fn=None, optimizer=None,
-                 capture_graph=False, world_size=None, rank=0, resident_batch=False, n_candidate=None):
+                 capture_graph=False, world_size=None, rank=0, resident_batch=False, n_candidate=None, n_items=None):
         import torch.distributed as dist
         if n_neg is not None and n_candidate is not None:
             raise ValueError("n_neg (mask-train) and n_candidate (candidate sets) are the two branches of get_gen_loss: pass one")
         self.model, self.beta, self.n_neg = model, float(beta), n_neg
         # the reference's DEFAULT mode (no --mask_train): candidate sets of n_candidate columns per slot, drawn in the fused
         # kernel from a stream keyed by (step, GLOBAL slot) - independent of the world size, like the masks and eps
-        # (a pair (sample_candidates [B, S, Cn], sample_targets [B, S]) instead of a count: THIS step's sets as given - what a
-        # batch of the reference's dataset carries; assign ``trainer.n_candidate`` before each step)
+        # Sets GIVEN per step (what a batch of the reference's dataset carries: sample_candidates [B, S, Cn], sample_targets [B, S])
+        # are an argument of step() / local_phase(): ``candidates=(cand, tgt)``; such a step always launches eagerly.
+        # (a pair passed HERE is kept as the default of steps that pass none - the round-5 interface; it is validated per step too)
         self.n_candidate = n_candidate if n_candidate is None or isinstance(n_candidate, (tuple, list)) else int(n_candidate)
+        # the id range [0, n_items) of the in-kernel draw: the dataset's max_iid + 1 (data_loader.py:23, :46); None = the table's rows
+        self.n_items = None if n_items is None else int(n_items)
+        if self.n_items is not None and not 0 < self.n_items <= model.docEmbed.weight.shape[0]:
+            raise ValueError(f"n_items={n_items} must lie in (0, {model.docEmbed.weight.shape[0]}] (the table's row count)")
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.pg = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
@@ -155,10 +166,8 @@ class Trainer:
         # sampler can read their step-dependent word (seed / stream position) from DEVICE memory (``self._words``, written by one
         # tiny launch before each replay).  What still stays eager: the dense masked kernels (n_neg / N > ops.SPARSE_MAX_KEEP_PROB),
         # candidate sets handed in per step, an injected loss_fn.
-        N_items = model.docEmbed.weight.shape[0]
-        masked_ok = n_neg is None or ops.sparse_ce_applies(float(n_neg) / N_items, N_items)
-        self.capture_graph = bool(capture_graph) and loss_fn is None and masked_ok and \
-            (n_candidate is None or not isinstance(n_candidate, (tuple, list)))
+        # (whether the CURRENT mode can be captured is decided when the capture is attempted: _capturable())
+        self.capture_graph = bool(capture_graph) and loss_fn is None
         self._words = None   # int64 [2] on the device: (mask / candidate seed = global step, sampler stream position) of the replayed step
         self._graph = None
         self._static = None
@@ -180,15 +189,43 @@ class Trainer:
         lo = self.rank * per
         return [t[lo:lo + per] for t in tensors], lo
 
-    def _local(self, s, r, u, eps, row_offset, eps_offset, words=None):
+    def _capturable(self):
+        """can a step in the CURRENT mode be replayed as a hipGraph?  Not: the dense masked kernels (n_neg / N above the sparse
+        kernel's range: their keep set is keyed by a by-value seed), candidate sets handed in per step, an injected loss_fn."""
+        N = self.model.docEmbed.weight.shape[0]
+        masked_ok = self.n_neg is None or ops.sparse_ce_applies(float(self.n_neg) / N, N)
+        return self._own_loss and masked_ok and not isinstance(self.n_candidate, (tuple, list))
+
+    @staticmethod
+    def _check_given_sets(candidates, s):
+        """(sample_candidates [B, S, Cn], sample_targets [B, S]) of THIS batch - shapes are checked against the batch, so that sets
+        left over from another step cannot be used silently"""
+        if not isinstance(candidates, (tuple, list)) or len(candidates) != 2:
+            raise ValueError("candidates: a pair (sample_candidates [B, S, Cn], sample_targets [B, S])")
+        cand, tgt = candidates
+        B, S = s.shape
+        if cand.dim() != 3 or tuple(cand.shape[:2]) != (B, S) or tuple(tgt.shape) != (B, S):
+            raise ValueError(f"candidate sets {tuple(cand.shape)} / targets {tuple(tgt.shape)} do not belong to a batch of shape "
+                             f"[{B}, {S}] (expected [B, S, Cn] and [B, S])")
+        return cand, tgt
+
+    def _local(self, s, r, u, eps, row_offset, eps_offset, words=None, candidates=None):
         """zero-grad + local loss + backward (this rank's shard).  ``words``: the device words of a captured step (the seed and the
-        sampler position are then read from them at run time; the by-value ones are what an eager step passes)."""
+        sampler position are then read from them at run time; the by-value ones are what an eager step passes).  ``candidates``:
+        this step's given sets (else the trainer's mode: ``n_candidate`` drawn in-kernel, or mask-train)."""
         B, S = s.shape
         self.opt.zero_grad()
         kw = dict(beta=self.beta, n_neg=self.n_neg, eps=eps, row_offset=row_offset, inv_count=1.0 / (B * S * self.world),
                   eps_offset=eps_offset, mask_seed=self.global_step if words is None else words[0:1])
-        if self.n_candidate is not None:
+        if candidates is None and isinstance(self.n_candidate, (tuple, list)):
+            candidates = self.n_candidate
+        if candidates is not None:
+            kw["candidates"] = self._check_given_sets(candidates, s)
+            kw["n_neg"] = None
+        elif self.n_candidate is not None:
             kw["candidates"] = self.n_candidate
+            if self.n_items is not None:
+                kw["n_items"] = self.n_items
         if self._own_loss and getattr(self.model, "TRAIN_RULE", "gt") in ("spt", "sgt"):
             # sampled pivots: the sampler's stream position is the slate's GLOBAL index in the run, like eps - independent of how
             # the batch is sharded over ranks (captured step: this shard's offset by value + the step's base from the device word)
@@ -244,14 +281,18 @@ class Trainer:
     def _mode(self):
         """what a captured step has baked in besides shapes: the loss mode and the pivot rule (a step in another mode runs eagerly)"""
         nc = self.n_candidate
-        return (self.n_neg, "given" if isinstance(nc, (tuple, list)) else nc, getattr(self.model, "TRAIN_RULE", "gt"),
-                getattr(self.model, "catalog_precision", None), getattr(self.model, "mlp_x3", None))
+        return (self.n_neg, "given" if isinstance(nc, (tuple, list)) else nc, self.n_items, getattr(self.model, "TRAIN_RULE", "gt"),
+                getattr(self.model, "catalog_precision", None), getattr(self.model, "mlp_precision", None),
+                getattr(self.model, "gather_rows_bf16", None))
 
     def prepare_graph(self, s, r, u, row_offset=0):
         """Capture the hipGraph of a step for this batch shape now (no parameter update, no collective: two warm-up passes of
         zero-grad + loss + backward, then the captured pass).  local_phase() calls it on the first step; a caller that times steps
         calls it BEFORE its timed region (bench.py with --warmup 0).  A failed capture falls back to eager launches, loudly."""
         if not self.capture_graph or self._graph is not None:
+            return
+        if not self._capturable():   # evaluated NOW, from the current mode (n_neg / n_candidate may have changed since __init__)
+            self.capture_graph = False
             return
         try:
             self._capture(s, r, u, row_offset)
@@ -264,17 +305,19 @@ class Trainer:
             self.capture_graph, self._graph = False, None
             self.capture_failed = str(e)
 
-    def local_phase(self, s, r, u, eps=None, global_batch=None, row_offset=0):
+    def local_phase(self, s, r, u, eps=None, global_batch=None, row_offset=0, candidates=None):
         """Phase 1 of a step - everything a rank does on its own: zero-grad, local loss (reconstruction term scaled by
         1 / (B_local S world), eps / mask / sampler streams at GLOBAL slate indices), backward into the flat gradient buffer, and
-        the rank's (loss, rec, KLD) record written behind the gradients (``opt.tail``)."""
+        the rank's (loss, rec, KLD) record written behind the gradients (``opt.tail``).  ``candidates``: THIS batch's given sets
+        (sample_candidates [B_local, S, Cn], sample_targets [B_local, S]); such a step is launched eagerly."""
         B, S = s.shape
         W = self.world
         gb = global_batch if global_batch is not None else B * W
         Z = self.model.latent_size
         eps_offset = (self.global_step * gb + row_offset) * Z
-        self.prepare_graph(s, r, u, row_offset)
-        if self.capture_graph and self._graph is not None and tuple(s.shape) == tuple(self._static["s"].shape) \
+        if candidates is None:
+            self.prepare_graph(s, r, u, row_offset)
+        if candidates is None and self.capture_graph and self._graph is not None and tuple(s.shape) == tuple(self._static["s"].shape) \
                 and row_offset == self._static["row_offset"] and self._static["mode"] == self._mode():
             st = self._static
             # the graph reads its own input buffers: copy the caller's batch in, unless the caller promised (resident_batch) that
@@ -296,7 +339,7 @@ class Trainer:
             self._graph.replay()
             loss, rec, kld = st["out"]
         else:
-            loss, rec, kld = self._local(s, r, u, eps, row_offset, eps_offset)
+            loss, rec, kld = self._local(s, r, u, eps, row_offset, eps_offset, candidates=candidates)
         tail = getattr(self.opt, "tail", None)
         self._stats, self._in_tail = None, False
         host_record = lambda: torch.stack([torch.add(rec, kld, alpha=float(self.beta)) if loss is None else loss, rec, kld])
@@ -318,11 +361,15 @@ class Trainer:
         collective path is then the one that is exercised.  Simulated ranks (``external_reduce``): the caller sums the buffers."""
         if self.dist is None:
             return
+        timing = self.REDUCE_TIMING
+        tok = timing[0]() if timing else None
         if self._in_tail:
             self.dist.all_reduce(self.opt.grad_ext, group=self.pg)
         else:
             self.dist.all_reduce(self.opt.grad, group=self.pg)
             self.dist.all_reduce(self._stats, group=self.pg)
+        if timing:
+            timing[1](tok)
 
     def finish_phase(self):
         """Phase 3: identical Adam on every rank.  -> (loss, recLoss, KLD) of the GLOBAL batch as device scalars."""
@@ -331,13 +378,13 @@ class Trainer:
         self.global_step += 1
         return stats[0], stats[1], stats[2]
 
-    def step(self, s, r, u, eps=None, global_batch=None, row_offset=0):
+    def step(self, s, r, u, eps=None, global_batch=None, row_offset=0, candidates=None):
         """s, r, u: THIS rank's shard.  Returns (loss, recLoss, KLD) as device scalars of the GLOBAL batch; nothing is
-        synchronised with the host."""
+        synchronised with the host.  ``candidates``: this batch's given candidate sets (local_phase)."""
         if self.external_reduce:
             raise RuntimeError("this Trainer plays one of several simulated ranks: call local_phase(), sum the ranks' "
                                "opt.grad_ext yourself, then finish_phase()")
-        self.local_phase(s, r, u, eps, global_batch, row_offset)
+        self.local_phase(s, r, u, eps, global_batch, row_offset, candidates)
         self.reduce_phase()
         return self.finish_phase()
 
@@ -354,20 +401,21 @@ def _dataset_arrays(ds):
     return slates, users, resp
 
 
-def candidate_loss(model, s, r, u, beta, n_candidate, seed=0, row_offset=0, inv_count=None, eps=None, eps_offset=None):
+def candidate_loss(model, s, r, u, beta, n_candidate, seed=0, row_offset=0, inv_count=None, eps=None, eps_offset=None, n_items=None):
     """The candidate path of get_gen_loss as a Trainer loss function: ``model.loss(candidates=n_candidate)`` - candidate sets drawn
     in the fused kernel, streams pinned to global slate indices (independent of sharding), the mean scaled by ``inv_count``.
     -> (loss, recLoss, KLD)"""
     return model.loss(s, r, u, beta, eps=eps, mask_seed=seed, row_offset=row_offset, inv_count=inv_count, eps_offset=eps_offset,
-                      candidates=int(n_candidate))
+                      candidates=int(n_candidate), n_items=n_items)
 
 
-def candidate_loss_materialised(model, s, r, u, beta, n_candidate, seed=0, row_offset=0, inv_count=None, eps=None, eps_offset=None):
+def candidate_loss_materialised(model, s, r, u, beta, n_candidate, seed=0, row_offset=0, inv_count=None, eps=None, eps_offset=None,
+                                n_items=None):
     """The same loss the way the reference computes it - ids [B, S, Cn] (``ops.candidate_draw``), candidate logits through
     ``forward(candidates=...)`` (K9 scores), dense CE - kept as the cross-check of the fused kernel (tests) and for callers that
     want ``forward()``'s ``p``.  Same streams, same result up to fp32 summation order."""
     B, S = s.shape
-    N = model.docEmbed.weight.shape[0]
+    N = model.docEmbed.weight.shape[0] if n_items is None else int(n_items)
     cand, tgt = ops.candidate_draw(s, N, n_candidate, seed=seed, row_offset=row_offset * S)
     if eps is None:
         eps = torch.empty(B, model.latent_size, dtype=torch.float32, device=s.device)
@@ -404,7 +452,15 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
     losses accumulate on the device and are read once per epoch.  Under data parallelism every rank takes bs / world slates of
     each batch (a last batch that does not divide is cut to a multiple of the world size), rank 0 logs and saves.
 
+    Candidate ids are drawn from the DATASET's range, as in the reference (data_loader.py:23 ``max_iid = np.max(slates)``, :46
+    ``randint(max_iid + 1, ...)``): ``trainset.max_iid + 1`` when the dataset has it (a table may have more rows than the slates
+    use - the simulators build n_item + 1, env/response_model.py:30), the table's row count otherwise.
+    ``model_path=None``: no pickle is written (a benchmark of the loop itself).  ``history`` also carries the seconds each
+    epoch's training loop and validation pass took (measured at the host reads the loop does anyway).
+
     ``trainer`` / ``val_loss_fn`` / ``eval_fn`` are injection points for the CPU tests of the loop logic."""
+    import time
+
     import torch.distributed as dist
     device = model.docEmbed.weight.device
     use_dist = dist.is_available() and dist.is_initialized()
@@ -427,8 +483,15 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
         model.log(logger)
     log("----------------------------------------")
 
-    n_cand = int(getattr(trainset, "nCandidate", n_neg) if not isinstance(trainset, dict) else trainset.get("nCandidate", n_neg))
+    ds_get = (lambda k, d: trainset.get(k, d)) if isinstance(trainset, dict) else (lambda k, d: getattr(trainset, k, d))
+    n_cand = int(ds_get("nCandidate", n_neg))
     N = model.docEmbed.weight.shape[0]
+    max_iid = ds_get("max_iid", None)
+    n_items = None if max_iid is None else int(max_iid) + 1   # the id range of the candidate draw (data_loader.py:23, :46)
+    if n_items is not None and not 0 < n_items <= N:
+        raise ValueError(f"trainset.max_iid + 1 = {n_items} does not fit the model's table of {N} rows")
+    if n_items is not None:
+        model.candidateIdRange = n_items   # get_gen_loss reads it (a caller that evaluates batches through the reference's entry point)
     S = model.slate_size
     tr_s, tr_u, tr_r = (t.to(device) for t in _dataset_arrays(trainset))
     va_s, va_u, va_r = (t.to(device) for t in _dataset_arrays(valset))
@@ -437,7 +500,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
     if trainer is None:
         if model.candidateFlag:   # the reference's default mode: the fused candidate kernel inside the trainer's own (seeded) step
             trainer = Trainer(model, lr=lr, beta=beta, n_neg=None, process_group=process_group, n_candidate=n_cand,
-                              capture_graph=capture_graph)
+                              capture_graph=capture_graph, n_items=n_items)
         else:
             trainer = Trainer(model, lr=lr, beta=beta, n_neg=None if n_neg >= N else n_neg, process_group=process_group,
                               capture_graph=capture_graph)
@@ -446,7 +509,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
     if val_loss_fn is None:
         def val_loss_fn(m, s, r, u, row_offset):   # forward only, n_neg = the dataset's candidate count (reference :157)
             if m.candidateFlag:
-                return candidate_loss(m, s, r, u, beta, n_cand, seed=0x5641, row_offset=row_offset)
+                return candidate_loss(m, s, r, u, beta, n_cand, seed=0x5641, row_offset=row_offset, n_items=n_items)
             return m.loss(s, r, u, beta, n_neg=None if n_cand >= N else n_cand, mask_seed=0x5641, row_offset=row_offset)
     run_eval = eval_fn is not None or resp_model is not None   # neither given: the recommendation test is skipped
     if eval_fn is None:
@@ -459,9 +522,10 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
     gen = torch.Generator(device=device)
     best_val = float("inf")
     temper = 2
-    history = {"train": [], "val": []}
+    history = {"train": [], "val": [], "train_seconds": [], "val_seconds": []}
     for epoch in range(epochs):
         log("Epoch " + str(epoch + 1))
+        t_epoch = time.perf_counter()
         gen.manual_seed((seed << 20) + epoch)            # the same permutation on every rank
         perm = torch.randperm(L, device=device, generator=gen)
         acc = torch.zeros((), dtype=torch.float32, device=device)
@@ -477,7 +541,9 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
             loss, _rec, _kld = trainer.step(tr_s[mine], tr_r[mine], tr_u[mine], global_batch=gb, row_offset=rank * per)
             acc += loss.to(acc.device)
             n_batches += 1
-        history["train"].append(float(acc) / max(n_batches, 1))
+        history["train"].append(float(acc) / max(n_batches, 1))   # the epoch's one host read of the training loop: it has drained
+        history["train_seconds"].append(time.perf_counter() - t_epoch)
+        t_val = time.perf_counter()
         log("train loss: " + str(history["train"][-1]))
         if epoch == 0 and getattr(trainer, "capture_failed", None):
             log("hipGraph capture was asked for and failed (" + trainer.capture_failed + "): every step is launched eagerly")
@@ -494,6 +560,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
         if use_dist:
             dist.all_reduce(sums, group=process_group)
         v_loss, v_rec, v_kld = (float(x) / max(float(sums[3]), 1.0) for x in sums[:3])
+        history["val_seconds"].append(time.perf_counter() - t_val)
         history["val"].append(v_loss)
         log("validation Loss: " + str(v_loss) + " = " + str(v_rec) + " + " + str(beta) + " * " + str(v_kld))
 
@@ -508,7 +575,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
 
         # save best model (reference :198-208; early termination is commented out there too)
         if epoch == 0 or v_loss < best_val - 1e-3:
-            if rank == 0:
+            if rank == 0 and model_path is not None:
                 torch.save(model, open(model_path, "wb"))
             log("Save best model")
             temper = 3
@@ -518,7 +585,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
             log("Temper down to " + str(temper))
     if use_dist:
         dist.barrier(group=process_group)
-    if rank == 0:
+    if rank == 0 and model_path is not None:
         log("Move model to cpu before saving")
         best = torch.load(open(model_path, "rb"), weights_only=False)
         best.to("cpu")

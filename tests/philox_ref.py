@@ -97,7 +97,7 @@ def candidate_raw(R, Cn, n_items, seed, row_offset=0):
     return out[:, :Cn]
 
 
-REJECT_KMAX = 4096   # csrc/catalog_sample.hip: proposals before a row goes to the Gumbel-max kernel
+REJECT_KMAX = 512   # csrc/catalog_sample.hip: proposals before a row goes to the Gumbel-max kernel
 
 
 def sample_reject(x, E, seed, row_offset=0, kmax=REJECT_KMAX, margin=2e-6):

@@ -704,6 +704,36 @@ def test_catalog_sample_falls_back_to_gumbel_max_when_every_proposal_is_rejected
     np.testing.assert_array_equal(ops.catalog_sample(x.to(DEV), table, seed=11).cpu().numpy(), idx)
 
 
+def test_catalog_sample_low_mean_sigmoid_mixes_both_samplers_exactly(ops):
+    """the worst case of the rejection sampler - scores mostly far below zero (mean sigmoid ~ 4e-3: an un-normalised
+    table, a large-norm PSM output) - is bounded by the proposal cap (512: 32 rounds at D = 128, not round 5's 256): ~10 % of such
+    rows reject every proposal and are drawn by the Gumbel-max kernel, the rest by rejection, and the MIXTURE is still
+    Categorical(sigmoid(scores)); the host restatement flags exactly the rows that went to the fallback."""
+    N, D, R = 48, 16, 30000
+    g = torch.Generator().manual_seed(3)
+    base = torch.zeros(D)
+    base[0] = 1.0
+    E = orc.normalize_rows(base + 0.4 * (torch.rand(N, D, generator=g) - 0.5))     # every item near the first axis
+    q = -5.6 * base + 1.0 * (torch.rand(D, generator=g) - 0.5)
+    q[0] = -5.6
+    x = q.expand(R, D).contiguous()
+    sc = q.double() @ E.double().t()
+    sig = torch.sigmoid(sc)
+    assert 1e-3 < float(sig.mean()) < 1e-2
+    idx = ops.catalog_sample(x.to(DEV), ops.CatalogTable(E.to(DEV)), seed=21).cpu().numpy()
+    want, k, safe = philox_ref.sample_reject(x.numpy(), E.numpy(), 21)
+    fell = want < 0
+    assert 0.03 < fell.mean() < 0.3 and k[~fell].max() >= 256       # both samplers at work, late proposals exercised
+    ok = safe & ~fell
+    np.testing.assert_array_equal(idx[ok], want[ok])
+    probs = (sig / sig.sum()).numpy()
+    assert probs.max() / probs.min() > 1.5
+    freq = np.bincount(idx, minlength=N) / R
+    assert np.abs(freq - probs).max() < 5 * np.sqrt(probs.max() / R)
+    freq_fb = np.bincount(idx[fell], minlength=N) / fell.sum()             # the fallback rows on their own follow the same law
+    assert np.abs(freq_fb - probs).max() < 5 * np.sqrt(probs.max() / fell.sum())
+
+
 def test_catalog_sample_distribution(ops):
     """Categorical(sigmoid(scores)) (rejection sampling): empirical frequencies match the probabilities."""
     N, D, R = 40, 16, 20000
@@ -805,6 +835,43 @@ def test_candidate_ce_fused_draws_the_documented_stream(ops, R, S, N, D, Cn, see
     assert not torch.equal(ops.candidate_ce_raw(rx.to(DEV), table, Cn, sl.to(DEV).reshape(-1), seed + 1, off)[1], lse)
 
 
+@pytest.mark.parametrize("R,S,N,n_items,D,Cn,seed,off", [(40, 5, 1001, 700, 32, 200, 7, 0), (16, 10, 30011, 30000, 128, 1000, 3, 11),
+                                                         (9, 2, 100003, 1, 64, 33, 5, 1 << 33), (12, 3, 5000, 4097, 16, 2100, 9, 2)])
+def test_candidate_ce_fused_draws_from_the_dataset_id_range(ops, R, S, N, n_items, D, Cn, seed, off):
+    """VERDICT r5 missing #3 - data_loader.py:23 (max_iid = np.max(slates)) and :46 (randint(max_iid + 1, ...)): the candidate ids
+    come from the DATASET's range [0, max_iid + 1), not from the table's row count (the simulators build n_item + 1 rows,
+    env/response_model.py:30).  With n_items < N the in-kernel sets are the documented stream taken mod n_items (host restatement:
+    philox_ref.candidate_raw(.., n_items, ..)), no id >= n_items is ever proposed, results are bitwise those of the given-sets
+    mode on those ids and meet the oracle; pcvae_candidate_draw(n_items) draws the same sets; n_items > N is refused."""
+    gen = torch.Generator().manual_seed(seed)
+    sl = torch.randint(0, n_items, (R, S), generator=gen)      # the dataset's slates only use ids below max_iid + 1
+    rx, E = rnd(R * S, D, seed=1, scale=3.0), unit_rows(N, D, seed=2)
+    table = ops.CatalogTable(E.to(DEV))
+    want_raw = torch.from_numpy(philox_ref.candidate_raw(R * S, Cn, n_items, seed, off)).view(R, S, Cn)
+    assert int(want_raw.max()) < n_items
+    wc, wt = orc.candidate_targets(sl, want_raw)
+    nll, lse, dx, tcol = ops.candidate_ce_raw(rx.to(DEV), table, Cn, sl.to(DEV).reshape(-1), seed, off, want_target=True,
+                                              n_items=n_items)
+    assert torch.equal(tcol.cpu(), wt.reshape(-1))
+    n2, l2, d2, _ = ops.candidate_ce_raw(rx.to(DEV), table, cand=wc.to(DEV), cand_target=wt.to(DEV))
+    assert torch.equal(nll, n2) and torch.equal(lse, l2) and torch.equal(dx, d2)
+    cd, td = ops.candidate_draw(sl.to(DEV), n_items, Cn, seed=seed, row_offset=off)
+    assert torch.equal(cd.cpu(), wc) and torch.equal(td.cpu(), wt)
+    want_nll, _, want_dx = orc.candidate_ce(rx, E, wc, wt)
+    np.testing.assert_allclose(nll.cpu().double().numpy(), want_nll.numpy(), rtol=2e-6, atol=2e-6)
+    assert (dx.cpu().double() - want_dx).abs().max() <= max(2e-6, 1e-7 * Cn ** 0.5) * max(1.0, float(want_dx.abs().max()))
+    if n_items > 1:   # the table-wide draw is a different set (ABI 2's behaviour = n_items None)
+        full = ops.candidate_ce_raw(rx.to(DEV), table, Cn, sl.to(DEV).reshape(-1), seed, off)
+        assert not torch.equal(full[1], lse)
+    with pytest.raises(ValueError):
+        ops.candidate_ce_raw(rx.to(DEV), table, Cn, sl.to(DEV).reshape(-1), seed, off, n_items=N + 1)
+    # the autograd op and the model-level entry carry it too
+    rd = rx.to(DEV).requires_grad_(True)
+    loss = ops.candidate_ce(rd, table, Cn, sl.to(DEV).reshape(-1), seed, off, n_items=n_items)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), want_nll.mean().item(), rtol=2e-6)
+
+
 @pytest.mark.parametrize("R,N,D,Cn", [(66, 3000, 64, 257), (130, 5000, 128, 1000), (9, 300, 256, 70), (5, 50, 128, 4500)])
 def test_gather_kernels_on_bf16_rows(ops, R, N, D, Cn):
     """prec = bf16 (the stated arithmetic of configs 3 / 5): the fused candidate kernel and the sparse mask kernel gather rows of the
@@ -839,9 +906,13 @@ def test_gather_kernels_on_bf16_rows(ops, R, N, D, Cn):
     np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6, atol=2e-6)
     np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6, atol=3e-6)
     np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5, atol=2e-6)
-    # ... and catalog_ce routes a bf16 model's masked call there
-    r2 = ops.catalog_ce_raw(rx.to(DEV), table, tg.to(DEV), keep_prob=p, seed=77, row_offset=9, prec=PREC_BF16)
+    # ... and catalog_ce routes a masked call there ONLY when bf16 rows are asked for explicitly (round 6: a bf16 catalog
+    # arithmetic alone leaves the gather kernels on the fp32 table - the reference's arithmetic)
+    r2 = ops.catalog_ce_raw(rx.to(DEV), table, tg.to(DEV), keep_prob=p, seed=77, row_offset=9, prec=PREC_BF16, gather_bf16=True)
     assert torch.equal(r2[0], nll) and torch.equal(r2[2], dx)
+    r3 = ops.catalog_ce_raw(rx.to(DEV), table, tg.to(DEV), keep_prob=p, seed=77, row_offset=9, prec=PREC_BF16)
+    f3 = ops.catalog_ce_sparse_raw(rx.to(DEV), table, tg.to(DEV), p, seed=77, row_offset=9)
+    assert torch.equal(r3[0], f3[0]) and torch.equal(r3[2], f3[2]) and not torch.equal(r3[0], nll)
 
 
 def test_candidate_ce_fused_bad_ids_poison_their_row_only(ops):
@@ -868,8 +939,13 @@ def test_candidate_ce_fused_bad_ids_poison_their_row_only(ops):
     assert torch.isnan(d[0].cpu()[3]) and torch.isnan(d[2].cpu()[3]).all() and torch.isfinite(d[0].cpu()[good & (torch.arange(R) != 3)]).all()
     from pivotcvae_amd import _hip
     rc = _hip.lib().pcvae_candidate_ce(_hip.ptr(rx.to(DEV)), R, _hip.ptr(table.weight), _hip.PREC_F32, N, D, Cn, None, 0, 0, None, None,
-                                       _hip.ptr(torch.empty(R, device=DEV)), None, None, 1.0, None, None, _hip.stream())
+                                       _hip.ptr(torch.empty(R, device=DEV)), None, None, 1.0, None, None, 0, _hip.stream())
     assert rc == -1 and b"candidate_ce" in _hip.lib().pcvae_last_error()
+    # (ABI 3) an id range larger than the table is refused on the host, before any launch
+    feat_d = feat.clamp(max=N - 1).to(DEV)
+    rc = _hip.lib().pcvae_candidate_ce(_hip.ptr(rx.to(DEV)), R, _hip.ptr(table.weight), _hip.PREC_F32, N, D, Cn, _hip.ptr(feat_d), 0, 0,
+                                       None, None, _hip.ptr(torch.empty(R, device=DEV)), None, None, 1.0, None, None, N + 1, _hip.stream())
+    assert rc == -1 and b"n_items" in _hip.lib().pcvae_last_error()
 
 
 # ------------------------------------------------------------------------- argument validation
@@ -1101,8 +1177,9 @@ def test_split_hand_off_stress_two_thousand_grouped_launches(ops):
     assert launches >= 2000 and max_splits == 64
 
 
+@pytest.mark.parametrize("arith,atol0,err_vs_scale", [("bf16x3", 6e-5, 2e-5), ("bf16x6", 2e-5, 2e-6)])
 @pytest.mark.parametrize("tiles", ["default", "dma_tiles_only"])
-def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
+def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch, arith, atol0, err_vs_scale):
     """Round 3: the MLP GEMMs in bf16x3 (ops.mlp_arith(True): operands split into bf16 hi + lo in registers, three bf16 MFMAs per
     product, fp32 accumulate) - forward, input gradient (plain / accumulating / LeakyReLU-masked), weight + bias gradient, alone
     and grouped, ragged everything, against fp64.  Tolerance: rtol 1e-4 as for the exact-f32 kernel; the absolute term is 3x the
@@ -1111,7 +1188,10 @@ def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
     uniform(-1, 1) operands, i.e. 1.5e-5 of the tensor's scale (the catalog bf16x3 kernel's gradient is held to 2e-5 of scale).
     A launch that asks for bf16x3 takes the 64 x 64 tiles (= the bf16x3 body) at any size (round 4: the arithmetic of a layer
     does not depend on the batch), so both parametrisations run the same kernels here; PCVAE_GEMM_SMALL_BELOW=0 stays as the pin
-    the exact-f32 reference launches of this test use."""
+    the exact-f32 reference launches of this test use.
+    Round 6, arith = "bf16x6" (ops.mlp_arith("bf16x6"): three bf16 components per operand = the fp32 value exactly, six MFMAs per
+    product): the same sweep at the EXACT-F32 kernel's own tolerance (atol 2e-5 sqrt(n / 64)), and on the large layer an error
+    against fp64 within the f32 kernel's bound (2e-6 of scale) - fp32-exact products on the bf16 matrix cores."""
     import random
     if tiles == "dma_tiles_only":
         monkeypatch.setenv("PCVAE_GEMM_SMALL_BELOW", "0")
@@ -1120,14 +1200,14 @@ def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
     for _ in range(24):
         shapes.append((rng.choice([1, 31, 64, 65, 200, 1000, 1300, 2100]), rng.choice([1, 16, 33, 64, 65, 130, 256]),
                        rng.choice([1, 7, 32, 33, 64, 97, 283, 300])))
-    with ops.mlp_arith(True):
+    with ops.mlp_arith(arith):
         for case, (M, N, K) in enumerate(shapes):
             padx, pady = rng.choice([0, 1, 3]), rng.choice([0, 5])
             xb, Wb = rnd(M, K + padx, seed=1100 + case), rnd(N, K, seed=1200 + case, scale=0.3)
             b, g = rnd(N, seed=1300 + case), rnd(M, N + pady, seed=1400 + case)
             xd, Wd, bd, gd = xb.to(DEV)[:, padx:], Wb.to(DEV), b.to(DEV), g.to(DEV)[:, :N]
             x64, W64, g64 = xb[:, padx:].double(), Wb.double(), g[:, :N].double()
-            tol = dict(rtol=1e-4, atol=6e-5 * max(1.0, (max(K, N, M) / 64.0) ** 0.5))
+            tol = dict(rtol=1e-4, atol=atol0 * max(1.0, (max(K, N, M) / 64.0) ** 0.5))
             y64 = x64 @ W64.t() + b.double()
             want_y = torch.nn.functional.leaky_relu(y64, 0.01).float()
             y = ops.linear_fwd_raw(xd, Wd, bd, 1)
@@ -1142,7 +1222,7 @@ def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
             outs = []
             for rep in range(2):
                 grp = ops.GemmGroup()
-                assert grp.x3
+                assert grp.x3 and grp.mode == {"bf16x3": 1, "bf16x6": 2}[arith]
                 dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
                 ybuf = torch.full((M, N + 3), 9.0, device=DEV)
                 grp.dw(gd, xd, dW, db)
@@ -1159,12 +1239,14 @@ def test_linear_bf16x3_arithmetic_random_ragged_shapes(ops, tiles, monkeypatch):
     M, N, K = 4096, 256, 1419
     xd, Wd = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=0.1).to(DEV)
     y32 = ops.linear_fwd_raw(xd, Wd, None, 0)
-    with ops.mlp_arith(True):
+    with ops.mlp_arith(arith):
         y3 = ops.linear_fwd_raw(xd, Wd, None, 0)
+    with ops.mlp_arith("bf16x3" if arith == "bf16x6" else "bf16x6"):
+        y_other = ops.linear_fwd_raw(xd, Wd, None, 0)
     y64 = xd.double() @ Wd.double().t()
     e32, e3 = (y32.double() - y64).abs().max().item(), (y3.double() - y64).abs().max().item()
     scale = y64.abs().max().item()
-    assert not torch.equal(y32, y3) and e32 < 2e-6 * scale and e3 < 2e-5 * scale, (e32, e3, scale)
+    assert not torch.equal(y32, y3) and not torch.equal(y3, y_other) and e32 < 2e-6 * scale and e3 < err_vs_scale * scale, (e32, e3, scale)
 
 
 def _f32_catalog_sequence(ops, seed, cases=20):

@@ -18,12 +18,14 @@ from tests.helpers import CandidateMode, candidate_mode_cases, explain_by_kinks,
 KINK_REL_X3 = 2.0 ** -18
 # ... and between the reference's and our fp32 trajectory (two summation orders of every layer, parameters that differ in their
 # last bits after a step; with a bf16x3 catalog the incoming gradient - hence the parameters after a step - by ~2e-5 of scale)
-KINK_REL_ADAM = {"f32": 2.0 ** -19, "bf16x6": 2.0 ** -19, "bf16x3": 2.0 ** -15}
+KINK_REL_ADAM = {"f32": 2.0 ** -19, "bf16x6": 2.0 ** -19, "bf16x6+mlp": 2.0 ** -19, "bf16x3": 2.0 ** -15}
 
 pytestmark = pytest.mark.gpu
 # bf16x3 (16-bit-mantissa operands) and bf16x6 (round 4: the fp32 operands themselves as three bf16 components): natively at D = 128,
 # on zero-padded columns at narrower widths (ops.x3_width / ops.x6_width); D = 256 has no bf16x6 kernel - it computes in exact f32 there
-CASES = [(n, p) for n in stated_cases() for p in ("f32", "bf16x6", "bf16x3")]
+# "bf16x6+mlp" (round 6): the catalog contraction AND the MLP GEMMs of the training loss in bf16x6 (set_mlp_precision("bf16x6"): fp32
+# operands as three bf16 components, six MFMAs per product) - held to the SAME tolerances as the exact-f32 kernels, against the reference
+CASES = [(n, p) for n in stated_cases() for p in ("f32", "bf16x6", "bf16x6+mlp", "bf16x3")]
 
 
 def adam_off_rows(got, want, rtol=1e-4, atol=3e-6):
@@ -75,6 +77,9 @@ def explain_adam_by_kinks(g, offenders, prec, device_states=None):
 
 def _model(g, prec, fused=True):
     m = build_from_golden(g)
+    if prec.endswith("+mlp"):
+        prec = prec[:-4]
+        m.set_mlp_precision(prec)
     m.set_catalog_precision(prec)
     if hasattr(m, "FUSED_TRAIN_PATH"):
         m.FUSED_TRAIN_PATH = fused
@@ -311,8 +316,10 @@ def test_candidate_mode_three_adam_steps(name):
     s, r, u = dev(g.t("s")), dev(g.t("r")), dev(g.t("u"))
     for step in range(3):
         cand, tgt = cm.draw(1 + step)
-        tr.n_candidate = (dev(cand), dev(tgt))
-        loss, rec, kld = tr.step(s, r, u, eps=dev(cm.t(f"adam/eps{step}")))
+        if step == 0:   # sets that belong to another batch shape are refused, not silently used
+            with pytest.raises(ValueError):
+                tr.step(s, r, u, candidates=(dev(cand)[:-1], dev(tgt)[:-1]))
+        loss, rec, kld = tr.step(s, r, u, eps=dev(cm.t(f"adam/eps{step}")), candidates=(dev(cand), dev(tgt)))
         np.testing.assert_allclose([loss.item(), rec.item(), kld.item()], cm.a[f"adam/loss{step}"], rtol=1e-4)
         if step in (0, 2):
             sd = m.state_dict()

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(handle, s), f"{s} declared in include/pcvae.h but not exported"
     assert sorted(_hip.SIGNATURES) == syms  # the ctypes table mirrors the header one to one
-    assert _hip.lib().pcvae_abi_version() == _hip.ABI_VERSION == 2
+    assert _hip.lib().pcvae_abi_version() == _hip.ABI_VERSION == 3
 
 
 def test_host_side_argument_checks_need_no_gpu():

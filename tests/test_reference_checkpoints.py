@@ -108,3 +108,34 @@ def test_a_pickle_that_names_anything_else_is_refused(tmp_path):
     with pytest.raises(pickle.UnpicklingError, match="refused"):
         read_reference_pickle(str(path))
     assert not (tmp_path / "pwned").exists()
+
+
+def test_a_nested_load_from_bytes_payload_is_refused(tmp_path):
+    """ADVICE r5 (medium): torch.storage._load_from_bytes is torch.load(BytesIO(b), weights_only=False) on the STANDARD unpickler;
+    while it was on the allowlist a pickle that REDUCEs it over an inner pickle ran the inner payload.  It is off the list: the outer
+    pickle is refused before anything is called, and so are the other rebuild helpers a module pickle does not need."""
+    import io
+    import pickle
+    from pivotcvae_amd import checkpoint as ck
+
+    class Inner:
+        def __reduce__(self):
+            import os
+            return (os.system, ("echo pwned > " + str(tmp_path / "pwned_inner"),))
+
+    buf = io.BytesIO()
+    torch.save(Inner(), buf)          # what _load_from_bytes would torch.load with the standard unpickler
+
+    class Outer:
+        def __reduce__(self):
+            return (torch.storage._load_from_bytes, (buf.getvalue(),))
+
+    path = tmp_path / "nested.pt"
+    torch.save({"model": Outer()}, open(path, "wb"))
+    with pytest.raises(pickle.UnpicklingError, match="refused"):
+        ck.read_reference_pickle(str(path))
+    assert not (tmp_path / "pwned_inner").exists()
+    for mod, names in (("torch.storage", ("_load_from_bytes",)), ("torch._utils", ("_rebuild_qtensor",)),
+                       ("numpy.core.multiarray", ("_reconstruct", "scalar")), ("copyreg", ("_reconstructor",)), ("_codecs", ("encode",))):
+        for n in names:
+            assert n not in ck._ALLOWED.get(mod, ()), (mod, n)
