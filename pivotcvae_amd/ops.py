@@ -480,7 +480,7 @@ def mlp_heads(x, trunk, head_a, head_b):
 # ---------------------------------------------------------------- fused training-path operators (fewer, larger launches)
 # bench.py sets this to (begin() -> token, end(token, bytes_moved)) to bracket the launch with HIP events inside real train steps
 ASSEMBLE_TIMING = None
-ASSEMBLE_ROW_ALIGN = int(os.environ.get("PCVAE_ASSEMBLE_ROW_ALIGN", "32"))   # floats (32 = a 128-byte cache line; 1 = packed rows)
+ASSEMBLE_ROW_ALIGN = 1   # floats; 1 = packed rows (the product).  The alignment probe sets it (see assemble_inputs)
 
 
 def assemble_inputs(E, U, s, r, u, Z):
@@ -495,10 +495,13 @@ def assemble_inputs(E, U, s, r, u, Z):
     s = s.to(torch.int64).contiguous()
     r = r.to(F32).contiguous()
     uu = None if U is None else u.reshape(-1).to(torch.int64).contiguous()
-    # rows of the three inputs start on ASSEMBLE_ROW_ALIGN-float boundaries (their widths - 1419, 139, 283 at config 4 - are odd:
-    # packed rows start on arbitrary 4-byte boundaries and every 512-byte table row written into them ends in two partial cache
-    # lines); the GEMMs take the leading dimension as given, so the padding costs nothing downstream
+    # Rows are PACKED (ld = width: 1419 / 139 / 283 floats at config 4, so rows start on arbitrary 4-byte boundaries).  Round 6
+    # measured rows padded to 4 / 16 / 32 / 64 floats instead (tools/assemble_align_probe.py, profiles/r06_assemble_row_align_probe.txt):
+    # 26.5 - 27.5 us against 26.7 us packed - partial cache lines are not what bounds this kernel.  ASSEMBLE_ROW_ALIGN > 1 is the
+    # probe's knob only (the padded buffers are views, which _LatentPacked's in-place write of z cannot take).
     def rows(width):
+        if ASSEMBLE_ROW_ALIGN <= 1:
+            return torch.empty(B, width, dtype=F32, device=dev)
         ld = -(-width // ASSEMBLE_ROW_ALIGN) * ASSEMBLE_ROW_ALIGN
         return torch.empty(B, ld, dtype=F32, device=dev)[:, :width]
 
