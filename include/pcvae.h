@@ -387,8 +387,8 @@ int pcvae_adam_step_l2(float* p, const float* g, float* m, float* v, int64_t n, 
  * instrumented launches (tags below) go out through hipExtLaunchKernelGGL with a start / stop event pair; read returns the number
  * of timed launches and fills their durations (ms) and tags in launch order.  No reference counterpart (the reference times with
  * time.time(), train_generative.py:113).
- * This is the library's ONE piece of process-global state: the switch applies to the instrumented launches of every thread and
- * the durations are kept in one process-wide list (locked: safe from several threads) - off by default.                        */
+ * The switch and the list are PER THREAD (round 6; they were process-wide): a thread times, and reads back, its own instrumented
+ * launches only - off by default.                                                                                               */
 #define PCVAE_TIMER_GATHER 1        /* gather_rows_coal_kernel (D = 64 / 128 / 256) or gather_rows_vec4_kernel (pcvae_gather_rows) */
 #define PCVAE_TIMER_ASSEMBLE 2      /* assemble_inputs_vec_kernel   (pcvae_assemble_inputs)  */
 #define PCVAE_TIMER_CANDIDATE_CE 3  /* candidate_ce_kernel          (pcvae_candidate_ce)     */

@@ -2188,12 +2188,14 @@ int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const
     // pass A over a prefix of the catalog is enough to seed the threshold: with N/16 items the expected number of
     // later items above the prefix maximum is ~16 per row (plus the lane-local running maximum in pass B), each
     // costing one D-term fmaf chain - far cheaper than a second full bf16 pass.
-    // (Round 6: from N = 65536 up.  Until round 5 catalogs under 262144 items ran pass A over the WHOLE catalog - config 3's
+    // (Round 6: a prefix from N = 65536 up.  Until round 5 catalogs under 262144 items ran pass A over the WHOLE catalog - config 3's
     // generate step, N = 10^5, paid two full bf16 passes: 448 + 594 us of a 1.36 ms batch in the kernel trace,
-    // profiles/r06_config3_generate_kernel_stats_before.csv.  The expected candidates per row, ~N / Ns = 16, do not depend on N.
-    // PCVAE_SCREEN_PREFIX_MIN_ITEMS moves the switch for A/B measurements.)
+    // profiles/r06_config3_generate_kernel_stats_before.csv.  The candidates per row, ~N / Ns, cost pass B rescoring time, and
+    // relatively more so on a SHORT catalog pass: below 262144 items the prefix is N / 4 (sweep: profiles/r06_screen_prefix_sweep.txt).
+    // PCVAE_SCREEN_PREFIX_MIN_ITEMS / PCVAE_SCREEN_PREFIX_DIV move the switch / the short catalogs' divisor for A/B measurements.)
     static const int64_t prefix_min = [] { const char* e = getenv("PCVAE_SCREEN_PREFIX_MIN_ITEMS"); return e ? atoll(e) : 65536LL; }();
-    const int64_t Ns = N >= prefix_min ? (N / 16) / 128 * 128 : N;
+    static const int64_t prefix_div = [] { const char* e = getenv("PCVAE_SCREEN_PREFIX_DIV"); return e && atoll(e) > 0 ? atoll(e) : 4LL; }();
+    const int64_t Ns = N >= 262144 ? (N / 16) / 128 * 128 : N >= prefix_min ? (N / prefix_div) / 128 * 128 : N;
     // the screen kernels always run 256-row workgroups: plan them as the D = 128 case
     const CatalogPlan pa = catalog_plan(R, Ns, 128, PCVAE_PREC_BF16), pb = catalog_plan(R, N, 128, PCVAE_PREC_BF16);
     ScreenParams p{};

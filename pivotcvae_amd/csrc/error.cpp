@@ -81,42 +81,46 @@ int lds_optin(const void* kernel, int bytes) {
 }
 
 // ---- kernel timer ------------------------------------------------------------------------------------------------------------
+// Measurement only.  Round 6: the switch and the list are PER THREAD (they were process-wide, locked): a thread that turns the timer
+// on times its own instrumented launches and nobody else's, reads back its own list, and the library keeps no process-global
+// mutable state besides the once-per-(kernel, device) LDS opt-in table above.
 namespace {
 struct TimedLaunch { int tag; hipEvent_t e0, e1; };
-std::vector<TimedLaunch>& timed() { static std::vector<TimedLaunch> v; return v; }
-std::mutex& timer_mu() { static std::mutex m; return m; }   // the list is process-wide: launches of any thread append under it
-std::atomic<bool> g_timer_on{false};
+struct ThreadTimer {
+    bool on = false;
+    std::vector<TimedLaunch> launches;
+    void clear() {
+        for (auto& t : launches) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+        launches.clear();
+    }
+    ~ThreadTimer() { clear(); }
+};
+ThreadTimer& thread_timer() { static thread_local ThreadTimer t; return t; }
 }
-bool timer_on() { return g_timer_on.load(std::memory_order_relaxed); }
+bool timer_on() { return thread_timer().on; }
 void timer_events(int tag, hipEvent_t* start, hipEvent_t* stop) {
     TimedLaunch t{tag, nullptr, nullptr};
     hipEventCreate(&t.e0);
     hipEventCreate(&t.e1);
-    {
-        std::lock_guard<std::mutex> lock(timer_mu());
-        timed().push_back(t);
-    }
+    thread_timer().launches.push_back(t);
     *start = t.e0;
     *stop = t.e1;
 }
 }  // namespace pcvae
 
-// enable = 1: start collecting (forgets earlier launches); 0: stop.  The switch and the list are process-wide (every thread's
-// instrumented launches are timed while it is on); both are safe to use from several threads.
+// enable = 1: start collecting the CALLING THREAD's instrumented launches (forgets its earlier ones); 0: stop.
 extern "C" int pcvae_kernel_timer(int enable) {
-    using namespace pcvae;
-    std::lock_guard<std::mutex> lock(timer_mu());
-    for (auto& t : timed()) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
-    timed().clear();
-    g_timer_on.store(enable != 0, std::memory_order_relaxed);
+    auto& tt = pcvae::thread_timer();
+    tt.clear();
+    tt.on = enable != 0;
     return PCVAE_OK;
 }
-// -> number of timed launches so far; fills ms[i] / tags[i] for the first `cap` of them (synchronises on their stop events)
+// -> number of launches the calling thread timed so far; fills ms[i] / tags[i] for the first `cap` of them (synchronises on their
+// stop events)
 extern "C" int pcvae_kernel_timer_read(float* ms, int* tags, int cap) {
     using namespace pcvae;
-    std::lock_guard<std::mutex> lock(timer_mu());
     int n = 0;
-    for (auto& t : timed()) {
+    for (auto& t : thread_timer().launches) {
         if (n < cap && ms && tags) {
             if (hipEventSynchronize(t.e1) != hipSuccess || hipEventElapsedTime(&ms[n], t.e0, t.e1) != hipSuccess) {
                 set_error("kernel_timer_read: event %d unreadable", n);

@@ -5,6 +5,7 @@
 #   part H: the headline kernel on this tree: kernel stats + four PMC passes (SQ1, SQ2, FETCH_SIZE, WRITE_SIZE)
 #   part C: candidate mode (Cn = 1000 / 50) lines + kernel stats per MLP arithmetic (what the MLP GEMMs cost in the light steps)
 #   part G: config 3: the full line (generate after the prefix-screening change) + the generate chain's kernel stats
+#   part M: the launches of ONE candidate-mode step (Cn = 50) in order, per MLP arithmetic: which GEMM launch costs what
 #   part S: the train step's gather kernel: alignment probe + same-box reference points + write-request counters
 PART=${1:-A}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -57,6 +58,14 @@ elif [ "$PART" = "C" ]; then
 elif [ "$PART" = "G" ]; then
   line config3 --config 3 --steps 20 --warmup 5
   stats config3_generate $ROOT/tools/gen_trace_run.py 3
+elif [ "$PART" = "M" ]; then
+  for mlp in f32 bf16x3 bf16x6; do
+    rm -rf $OUT/tr_m
+    timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tr_m -- python3 $ROOT/tools/step_trace_run.py 4 8192 bf16x6 8 $mlp 50 > $OUT/tr_m_$mlp.log 2>&1 &&
+      python3 $ROOT/tools/step_trace_list.py $(find $OUT/tr_m -name "*kernel_trace.csv") > $OUT/cand50_config4_mlp_${mlp}_step_launches.txt
+    rm -rf $OUT/tr_m
+    echo "[M] $mlp done $(date +%T)" | tee -a $OUT/progress.log
+  done
 elif [ "$PART" = "S" ]; then
   python3 $ROOT/tools/assemble_align_probe.py > $OUT/assemble_row_align_probe.txt 2>&1
   (rocprofv3-avail list 2>/dev/null || rocprofv3 --list-avail 2>/dev/null) | grep -io "TCC_[A-Z0-9_]*WR[A-Z0-9_]*\|TCC_[A-Z0-9_]*STALL[A-Z0-9_]*" | sort -u > $OUT/avail_tcc_write_counters.txt
