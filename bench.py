@@ -704,6 +704,10 @@ def main():
         args.mlp = ops.default_mlp_precision(args.dtype)
     model, st = build_model(cfg, device, args.dtype)
     model.set_mlp_precision(args.mlp)
+    if args.dtype == "bf16":
+        # configs 3 / 5 are STATED in bf16 (BASELINE.json): their gather kernels (candidate sets, n_neg << N, validation) read rows of
+        # the bf16 table too.  An explicit switch - a bf16 catalog arithmetic alone leaves them on the fp32 table (round 6)
+        model.set_gather_rows("bf16")
     # hipGraph replay pays off when the step is launch-bound (per-rank batch <= 4096 slates: ~50 launches of 5-30 us);
     # at a full single-GPU batch of config 4 the catalog kernel is > 95 % of the step and eager launches keep the HIP events
     # that time it inside the timed region

@@ -6,6 +6,8 @@
 #   part C: candidate mode (Cn = 1000 / 50) lines + kernel stats per MLP arithmetic (what the MLP GEMMs cost in the light steps)
 #   part G: config 3: the full line (generate after the prefix-screening change) + the generate chain's kernel stats
 #   part M: the launches of ONE candidate-mode step (Cn = 50) in order, per MLP arithmetic: which GEMM launch costs what
+#   part O: the other BASELINE configs on this tree: config 1 / 2 lines (as specified), config 5 (N = 10M, K = 20, D = 256, bf16) line and
+#           its candidate mode (bf16 rows: the stated arithmetic)
 #   part S: the train step's gather kernel: alignment probe + same-box reference points + write-request counters
 PART=${1:-A}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -58,6 +60,12 @@ elif [ "$PART" = "C" ]; then
 elif [ "$PART" = "G" ]; then
   line config3 --config 3 --steps 20 --warmup 5
   stats config3_generate $ROOT/tools/gen_trace_run.py 3
+elif [ "$PART" = "O" ]; then
+  line config1 --config 1 --steps 50 --warmup 10
+  line config2 --config 2 --steps 50 --warmup 10
+  line config5 --config 5 --steps 5 --warmup 2
+  line cand1000_config5 --config 5 --n_candidate 1000 --steps 20 --warmup 5 --no-extras --no-variants
+  line cand1000_config3 --config 3 --n_candidate 1000 --steps 50 --warmup 10 --no-extras --no-variants
 elif [ "$PART" = "M" ]; then
   for mlp in f32 bf16x3 bf16x6; do
     rm -rf $OUT/tr_m
