@@ -14,8 +14,6 @@ file the driver runs is the headline path, and out of the ONE JSON line so that 
 
 `run(ctx)` returns them as one dict; bench.py writes it (with the verbose headline) to `bench_extras.json` and copies a few
 two-number summaries into the line.  A block that raises is recorded as {"error": ...} - it never costs the headline."""
-import json
-import os
 import time
 import traceback
 

@@ -1324,14 +1324,18 @@ def test_candidate_ce_and_sampler_random_shapes_fuzz(ops):
             seed, off = rng.randint(0, 2 ** 40), rng.randint(0, 2 ** 33)
             bf16 = D in (64, 128, 256) and rng.random() < 0.4
             prec = PREC_BF16 if bf16 else PREC_F32
-            msg = f"seed={sd} case={case} R={R} N={N} D={D} Cn={Cn} bf16={bf16}"
+            # (round 6) the draw's id range: the table's rows (None) or a dataset range n_items <= N (data_loader.py:23, :46)
+            n_items = rng.choice([None, None, N, rng.randint(1, N)])
+            n_draw = N if n_items is None else n_items
+            msg = f"seed={sd} case={case} R={R} N={N} D={D} Cn={Cn} bf16={bf16} n_items={n_items}"
             rx, E = rnd(R, D, seed=sd + case, scale=3.0), unit_rows(N, D, seed=sd + 100 + case)
-            feat = torch.randint(0, N, (R,), generator=torch.Generator().manual_seed(sd + 200 + case))
+            feat = torch.randint(0, n_draw, (R,), generator=torch.Generator().manual_seed(sd + 200 + case))
             table = ops.CatalogTable(E.to(DEV))
-            raw = torch.from_numpy(philox_ref.candidate_raw(R, Cn, N, seed, off)).view(R, 1, Cn)
+            raw = torch.from_numpy(philox_ref.candidate_raw(R, Cn, n_draw, seed, off)).view(R, 1, Cn)
             wc, wt = orc.candidate_targets(feat.view(R, 1), raw)
             wc, wt = wc.view(R, Cn), wt.view(R)
-            nll, lse, dx, tcol = ops.candidate_ce_raw(rx.to(DEV), table, Cn, feat.to(DEV), seed, off, want_target=True, prec=prec)
+            nll, lse, dx, tcol = ops.candidate_ce_raw(rx.to(DEV), table, Cn, feat.to(DEV), seed, off, want_target=True, prec=prec,
+                                                      n_items=n_items)
             assert torch.equal(tcol.cpu(), wt), msg
             Eo = E.to(torch.bfloat16).float() if bf16 else E
             wn, wl, wd = orc.candidate_ce(rx, Eo, wc, wt)
@@ -1347,7 +1351,8 @@ def test_candidate_ce_and_sampler_random_shapes_fuzz(ops):
                 assert (p.cpu().double() - want_p).abs().max() <= 3e-6 * max(1.0, float(want_p.abs().max())), msg
             h = R // 2
             if h:
-                part = ops.candidate_ce_raw(rx[h:].contiguous().to(DEV), table, Cn, feat[h:].contiguous().to(DEV), seed, off + h, prec=prec)
+                part = ops.candidate_ce_raw(rx[h:].contiguous().to(DEV), table, Cn, feat[h:].contiguous().to(DEV), seed, off + h, prec=prec,
+                                            n_items=n_items)
                 assert torch.equal(part[0], nll[h:]) and torch.equal(part[2], dx[h:]), msg
             idx = ops.catalog_sample(rx.to(DEV), table, seed=seed, row_offset=off).cpu().numpy()
             want, _k, safe = philox_ref.sample_reject(rx.numpy(), E.numpy(), seed, off)
