@@ -88,8 +88,9 @@ class BaseCVAE(nn.Module):
         return self
 
     @property
-    def mlp_x3(self):   # the round-3 name of the switch
-        return self.mlp_precision == "bf16x3"
+    def mlp_x3(self):   # the round-3 name of the switch (a module pickled before round 6 still carries it in its __dict__)
+        d = self.__dict__
+        return d.get("mlp_precision", "bf16x3" if d.get("mlp_x3") else "f32") == "bf16x3"
 
     def set_gather_rows(self, name):
         """which table the gather kernels read: "f32" (default: the fp32 table, the reference's arithmetic) or "bf16" (rows of the

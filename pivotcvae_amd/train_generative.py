@@ -490,8 +490,8 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
     n_items = None if max_iid is None else int(max_iid) + 1   # the id range of the candidate draw (data_loader.py:23, :46)
     if n_items is not None and not 0 < n_items <= N:
         raise ValueError(f"trainset.max_iid + 1 = {n_items} does not fit the model's table of {N} rows")
-    if n_items is not None:
-        model.candidateIdRange = n_items   # get_gen_loss reads it (a caller that evaluates batches through the reference's entry point)
+    model.candidateIdRange = n_items   # get_gen_loss reads it (a caller that evaluates batches through the reference's entry point);
+    #                                      None - a dataset without max_iid - resets what an earlier dataset may have left
     S = model.slate_size
     tr_s, tr_u, tr_r = (t.to(device) for t in _dataset_arrays(trainset))
     va_s, va_u, va_r = (t.to(device) for t in _dataset_arrays(valset))
