@@ -74,6 +74,7 @@ struct GemmParams {
 struct GroupParams {
     GemmParams g[MAXG];
     int n;
+    int dma_x4;   // 16-byte LDS-DMA where the operands allow it (PCVAE_GEMM_DMA16, default on)
 };
 
 __device__ float g_zero_page[64];
@@ -111,6 +112,31 @@ __device__ __forceinline__ void dma8(const float* base, const int (&off)[PCS], u
                  "global_load_lds_dword %7, %8 offset:1792"
                  ::"v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7]),
                    "s"(base), "s"(lds_dst)
+                 : "memory", "m0");
+}
+
+// 16-byte LDS-DMA (round 6): the same LDS images filled by global_load_lds_dwordx4 - a lane brings one 16-byte chunk (4 consecutive k
+// of a k-contiguous row, or 4 consecutive rows of a k line), a wave 1 KB per instruction, so an operand's 8 KB chunk is 2 instructions
+// per wave instead of 8.  The image is unchanged (the swizzles above act on whole 16-byte chunks), so results are bitwise the
+// dword path's.  Source offset (floats, relative to the tile origin) of the 16 bytes that land at LDS position (piece pc of 1 KB, lane):
+template <bool KC>
+__device__ __forceinline__ int64_t dma_src4(int pc, int lane, int64_t ld, int rows_left) {
+    if (KC) {   // piece = 8 image rows of 32 k
+        const int row = 8 * pc + (lane >> 3), slot = lane & 7;
+        const int k = 4 * (slot ^ ((row >> 1) & 7));
+        const int rc = row < rows_left ? row : rows_left - 1;
+        return (int64_t)rc * ld + k;
+    } else {    // piece = 4 k lines of 64 rows (only used when all 64 rows exist: a chunk of 4 rows cannot be clamped row by row)
+        const int k = 4 * pc + (lane >> 4), slot = lane & 15;
+        const int row = 4 * (slot ^ (((k >> 2) & 1) << 3));
+        return (int64_t)k * ld + row;
+    }
+}
+__device__ __forceinline__ void dma2x4(const float* base, const int (&off)[2], unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %2\n\t"
+                 "global_load_lds_dwordx4 %1, %2 offset:1024"
+                 ::"v"(off[0]), "v"(off[1]), "s"(base), "s"(lds_dst)
                  : "memory", "m0");
 }
 
@@ -162,7 +188,7 @@ extern "C" int pcvae_gemm_stamps(unsigned long long* out) { return (int)hipMemcp
 // product - every partial product exact in the fp32 accumulator's input: the reference's fp32 arithmetic on the bf16 matrix cores
 // (the catalog kernel's bf16x6, catalog_x3.h, applied to K3).  XM: 0 exact f32 MFMA, 1 bf16x3, 2 bf16x6.
 template <bool A_KC, bool B_KC, int EPI, int XM>
-__device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx, const int by, const int bz, char* smem) {
+__device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx, const int by, const int bz, char* smem, const bool dma_x4) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
@@ -202,6 +228,15 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
         offA[i] = (int)(dma_src<A_KC>(wave * PCS + i, lane, p.lda, rowsA, &kk) * 4) + 2048 - 256 * i;
         offB[i] = (int)(dma_src<B_KC>(wave * PCS + i, lane, p.ldb, rowsB, &kk) * 4) + 2048 - 256 * i;
     }
+    // 16-byte DMA where the operand allows it (workgroup-uniform): k-contiguous operands always (a chunk lies inside one row, rows are
+    // clamped whole); row-contiguous operands only when all 64 rows of the tile exist.  Lane offsets: bytes, + 1024 - 1024 i.
+    const bool a4 = dma_x4 && (A_KC || rowsA == BM), b4 = dma_x4 && (B_KC || rowsB == BN);
+    int offA4[2], offB4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA4[i] = (int)(dma_src4<A_KC>(wave * 2 + i, lane, p.lda, rowsA) * 4) + 1024 - 1024 * i;
+        offB4[i] = (int)(dma_src4<B_KC>(wave * 2 + i, lane, p.ldb, rowsB) * 4) + 1024 - 1024 * i;
+    }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the ring
 
     auto issue = [&](int c) {   // chunk c -> stage c % NSTAGE (A image, then B image); uniform branch on the ragged last chunk
@@ -219,8 +254,10 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                 dma1_addr(pb, dstB + 256u * i);
             }
         } else {
-            dma8(reinterpret_cast<const float*>(reinterpret_cast<const char*>(A0 + (int64_t)c * stepA) - 2048), offA, dstA);
-            dma8(reinterpret_cast<const float*>(reinterpret_cast<const char*>(B0 + (int64_t)c * stepB) - 2048), offB, dstB);
+            if (a4) dma2x4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(A0 + (int64_t)c * stepA) - 1024), offA4, dstA);
+            else dma8(reinterpret_cast<const float*>(reinterpret_cast<const char*>(A0 + (int64_t)c * stepA) - 2048), offA, dstA);
+            if (b4) dma2x4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(B0 + (int64_t)c * stepB) - 1024), offB4, dstB);
+            else dma8(reinterpret_cast<const float*>(reinterpret_cast<const char*>(B0 + (int64_t)c * stepB) - 2048), offB, dstB);
         }
     };
 
@@ -698,9 +735,10 @@ __global__ void __launch_bounds__(256) gemm_group_kernel(const GroupParams gp) {
         if (p.kind == KIND_FWD_S) gemm_tile_small<true, true, EPI_FWD>(p, bx, by, smem);
         else gemm_tile_small<true, false, EPI_DX>(p, bx, by, smem);
     } else {
-        if (p.kind == KIND_FWD) gemm_tile_dma<true, true, EPI_FWD, X3>(p, bx, by, bz, smem);
-        else if (p.kind == KIND_DX || !HAS_DW) gemm_tile_dma<true, false, EPI_DX, X3>(p, bx, by, bz, smem);
-        else gemm_tile_dma<false, false, EPI_DW, X3>(p, bx, by, bz, smem);
+        const bool x4 = gp.dma_x4 != 0;
+        if (p.kind == KIND_FWD) gemm_tile_dma<true, true, EPI_FWD, X3>(p, bx, by, bz, smem, x4);
+        else if (p.kind == KIND_DX || !HAS_DW) gemm_tile_dma<true, false, EPI_DX, X3>(p, bx, by, bz, smem, x4);
+        else gemm_tile_dma<false, false, EPI_DW, X3>(p, bx, by, bz, smem, x4);
     }
 }
 
@@ -786,6 +824,8 @@ static int launch_group(const pcvae_gemm_desc* descs, int n, void* ws, size_t ws
     PCVAE_REQUIRE(descs && n >= 1 && n <= MAXG, "linear_group: 1..%d problems per launch", MAXG);
     GroupParams gp;
     gp.n = 0;
+    static const int dma16 = [] { const char* e = getenv("PCVAE_GEMM_DMA16"); return e ? atoi(e) : 1; }();
+    gp.dma_x4 = dma16;
     int64_t tiles64 = 0;
     // split-bf16 arithmetic: only if EVERY problem of the launch asks for it (one kernel per launch); bf16x6 only if every problem asks
     // for bf16x6 (a mixed launch runs the narrower bf16x3 - a group is built under ONE ops.mlp_arith, so this does not happen)
