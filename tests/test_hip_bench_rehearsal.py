@@ -83,3 +83,17 @@ def test_the_real_default_bench_prints_one_bounded_line_and_writes_the_extras(tm
         assert k in full and "error" not in full[k], (k, full.get(k))
     assert full["value"] == pytest.approx(d["value"], rel=1e-5)     # the file repeats the headline in full precision
     assert {"candidates_1000", "mask_train_n_neg_1000"} <= set(full["epoch"])
+
+
+@pytest.mark.timeout(900)
+def test_four_ranks_on_one_gpu_report_the_single_rank_elbo_in_candidate_mode():
+    """the driver's scaling run goes to 4 and 8 ranks: the same rehearsal with FOUR ranks on the one GPU (gloo collectives), in the
+    reference's default loss mode (candidate sets drawn in-kernel from streams keyed by GLOBAL slots): sharding by four, per-rank graph
+    capture, the `dist` block, and ELBO terms equal to the single-rank run's"""
+    one = run_bench(1, ["--n_candidate", "64"])
+    four = run_bench(4, ["--n_candidate", "64"])
+    assert four["n_gpus"] == 4 and four["config"]["per_gpu_batch"] == 256 and four["config"]["rccl_ranks"] == 4
+    assert four["config"]["launch"].startswith("hipGraph") and four["roofline"]["kernel"].startswith("candidate_ce_kernel")
+    assert four["dist"]["allreduce_ms"] > 0 and four["dist"]["kernel_ms_min"] <= four["dist"]["kernel_ms_max"]
+    np.testing.assert_allclose([four["elbo"][k] for k in ("loss", "recLoss", "KLD")], [one["elbo"][k] for k in ("loss", "recLoss", "KLD")],
+                               rtol=2e-5)
