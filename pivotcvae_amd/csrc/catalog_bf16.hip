@@ -2164,7 +2164,9 @@ static int launch_screened(ScreenParams p, const CatalogPlan& pa, const CatalogP
     if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 0>), lds_pipe)) return rc_optin;
     if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 1>), lds_pipe)) return rc_optin;
     const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
-    const int pipe_min = env_min ? atoi(env_min) : 512;
+    // (D = 64, round 6: from 128 tiles per range - the quarter-catalog prefix pass of config 3's generate step takes the pipelined
+    // kernel too: 1.09 -> 1.05 ms per batch, same ids)
+    const int pipe_min = env_min ? atoi(env_min) : (D == 64 ? 128 : 512);
     p.N = Ns; p.nrb = pa.nrb; p.nsplit = pa.nsplit; p.tiles_per_split = pa.tiles_per_split; p.ntiles = pa.ntiles;
     if (pa.tiles_per_split >= pipe_min)
         hipLaunchKernelGGL((catalog_screen_pipe_kernel<D, CT, 0>), dim3((unsigned)(cdiv(p.R, PG::ROWS) * pa.nsplit)), dim3(256),
