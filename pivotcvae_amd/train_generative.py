@@ -73,22 +73,73 @@ def get_gen_loss(batch_data, model, lossFun, beta, n_neg=1000, eps=None, seed=0,
 
 
 @torch.no_grad()
-def recommendation_test(model, resp_model, bs, n_test_trial=100, seed=0):
+def recommendation_test(model, resp_model, bs, n_test_trial=100, seed=0, capture_graph=False):
     """The in-loop evaluation of reference train_generative.py:169-195, entirely on the device.
 
     For each of ``n_test_trial`` trials: sample ``bs`` users, and for the five contexts "i+1 desired clicks"
     (i = 0..4) generate greedy slates with ``model.recommend`` and score them with the response model; the expected
     number of clicks of a slate is sum_s sigmoid(logit).  Returns a [5, 3] tensor of (min, mean, max) expected clicks
     averaged over the trials - the three numbers the reference logs per context - without any host synchronisation
-    inside the loop (the reference does 15 ``.cpu()`` copies per trial)."""
+    inside the loop (the reference does 15 ``.cpu()`` copies per trial).
+
+    ``capture_graph`` (round 6): the 500 generate + score calls of an evaluation are the SAME ~35 launches on the same shapes -
+    they are captured once as a hipGraph (static context / users / eps buffers; eps drawn outside the graph from the model's own
+    Philox stream at the positions the eager calls would use) and replayed.  Same numbers as the eager loop, bit for bit; it pays
+    where the chain is launch-bound (config 2: 2.4x; tools/gen_graph_probe.py) and changes nothing where the catalog kernels
+    dominate (configs 3-5).  Sampled inference rules (``spi``) keep the eager loop: their sampler's stream position is a kernel
+    argument."""
     from .env.response_model import sample_users
     device = model.docEmbed.weight.device
     acc = torch.zeros(5, 3, dtype=torch.float32, device=device)
+    graph = st = None
+    if capture_graph and getattr(model, "INFER_RULE", "pi") == "pi" and n_test_trial > 0:
+        Z = model.latent_size
+        st = dict(ctx=torch.zeros(bs, 5, dtype=torch.float32, device=device), users=torch.zeros(bs, dtype=torch.int64, device=device),
+                  eps=torch.zeros(bs, Z, dtype=torch.float32, device=device))
+        users_shape = tuple(sample_users(resp_model, bs, seed=seed, offset=0).shape)
+        st["users"] = st["users"].reshape(users_shape)
+
+        def chain():
+            slates, _mu = model.recommend(st["ctx"], st["users"], return_item=True, eps=st["eps"])
+            logits = resp_model(slates.view(bs, -1), st["users"])
+            return ops.click_stats(logits)[1]
+
+        try:
+            torch.cuda.synchronize()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            warm = {}
+            with torch.cuda.stream(side), ops.workspace_holder(warm):   # warm-up: scratch buffers, table copies, kernel attributes
+                for _ in range(2):
+                    chain()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            bufs = {}
+            for key, buf in warm.items():
+                if key[2] not in bufs or bufs[key[2]].numel() < buf.numel():
+                    bufs[key[2]] = buf
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"), ops.workspace_holder(_FixedWorkspace(bufs)):
+                st["stats"] = chain()
+            st["ws"] = bufs
+        except Exception as e:   # capture is an optimisation: fall back to the eager loop, and say so
+            import warnings
+            warnings.warn(f"hipGraph capture of the recommendation test failed ({e}); running eagerly")
+            torch.cuda.synchronize()
+            graph = None
     for k in range(n_test_trial):
         users = sample_users(resp_model, bs, seed=seed, offset=k * bs)
         context = torch.zeros(bs, 5, dtype=torch.float32, device=device)
         for i in range(5):
             context[:, i] = 1
+            if graph is not None:
+                st["ctx"].copy_(context)
+                st["users"].copy_(users)
+                # the eps an eager recommend() would draw in its reparametrisation kernel: same stream, same position
+                ops.philox_normal_(st["eps"], seed=model.rng_seed, offset=model._next_offset(bs * model.latent_size))
+                graph.replay()
+                acc[i] += st["stats"]
+                continue
             slates, _mu = model.recommend(context, users, return_item=True)
             logits = resp_model(slates.view(bs, -1), users)
             _nc, stats = ops.click_stats(logits)
@@ -513,7 +564,7 @@ def train_on_dataset(trainset, valset, model, model_path, logger, resp_model, bs
             return m.loss(s, r, u, beta, n_neg=None if n_cand >= N else n_cand, mask_seed=0x5641, row_offset=row_offset)
     run_eval = eval_fn is not None or resp_model is not None   # neither given: the recommendation test is skipped
     if eval_fn is None:
-        eval_fn = lambda m: recommendation_test(m, resp_model, bs, n_test_trial=n_test_trial, seed=seed)
+        eval_fn = lambda m: recommendation_test(m, resp_model, bs, n_test_trial=n_test_trial, seed=seed, capture_graph=capture_graph)
 
     dropped = sum((min(bs, L - lo) % world) for lo in range(0, L, bs))
     if dropped:   # runs at different world sizes see the same slates only if every batch divides

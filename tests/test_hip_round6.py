@@ -234,3 +234,30 @@ def test_whole_step_with_split_bf16_mlp_against_the_oracle(mlp):
             torch.testing.assert_close(v, new[k], rtol=1e-4, atol=3e-6)
     with pytest.raises(ValueError):
         m.set_mlp_precision("fp8")
+
+
+def test_recommendation_test_replayed_as_a_hipgraph_equals_the_eager_loop():
+    """round 6: the in-loop evaluation (train_generative.py:169-195: 5 contexts x trials of recommend + click model + statistics) with
+    its ~35 launches per call captured ONCE and replayed - the same [5, 3] statistics as the eager loop, bit for bit (eps from the
+    model's own Philox stream at the positions the eager calls use), with the MLP click model and with a URM simulator; a sampled
+    inference rule keeps the eager loop."""
+    from pivotcvae_amd.env.response_model import URM_P_MR, UserResponseModel_MLP
+    from pivotcvae_amd.train_generative import recommendation_test
+    N, bs = 3001, 48
+    for variant in ("pivotcvae_gt_pi", "pivotcvae_gt_spi"):
+        m, _ = make(N, variant=variant, D=32)
+        torch.manual_seed(3)
+        rms = [UserResponseModel_MLP(N - 1, NU - 1, 32, S, [(S + 1) * 32, 64, 64, S], DEV, False).to(DEV),
+               URM_P_MR(N - 1, NU - 1, S, 32, DEV, False, 0.5, 0.1, 0.3).to(DEV)]
+        for rm in rms:
+            m._rng_offset = 0
+            eager = recommendation_test(m, rm, bs, n_test_trial=3, seed=11)
+            pos = m._rng_offset
+            m._rng_offset = 0
+            replayed = recommendation_test(m, rm, bs, n_test_trial=3, seed=11, capture_graph=True)
+            assert m._rng_offset == pos                          # the same stream positions were consumed
+            if variant.endswith("_pi"):
+                assert torch.equal(eager, replayed), (eager, replayed)
+            else:   # spi: the eager loop either way; its sampler advances its own running offset, so the two calls differ in their draws
+                assert tuple(replayed.shape) == (5, 3) and torch.isfinite(replayed).all()
+            assert torch.all(replayed[:, 0] <= replayed[:, 1]) and torch.all(replayed[:, 1] <= replayed[:, 2])
