@@ -323,3 +323,58 @@ def _fresh_model(g):
     return pa.PIVOTCVAE_MODELS["pivotcvae_gt_pi"](torch.nn.Embedding.from_pretrained(g.t("raw_doc")),
                                                  torch.nn.Embedding.from_pretrained(g.t("raw_user")), m["S"], m["D"], m["Z"], m["S"] + 1,
                                                  st["enc"], st["psm"], st["scm"], st["prior"], False, "cpu")
+
+
+def test_round6_host_switches_need_no_gpu():
+    """round 6's host-side contracts on a CPU-constructed model: the MLP arithmetic switch (and its round-3 alias, also on a module
+    pickled before round 6), the explicit gather-rows switch, the trainer's validation of per-step candidate sets and of the draw's id
+    range, capture eligibility decided from the current mode"""
+    from pivotcvae_amd import ops
+    from pivotcvae_amd.train_generative import Trainer
+    e, u = _tables()
+    st = dict(enc=[102, 24, 24], psm=[26, 24, 24, 16], scm=[42, 24, 24, 64], prior=[22, 12, 12])
+    m = pa.UserPivotCVAE(e, u, 5, 16, 4, 6, st["enc"], st["psm"], st["scm"], st["prior"], False, "cpu")
+    assert m.mlp_precision == "f32" and m.mlp_x3 is False and m.gather_rows_bf16 is False
+    assert ops.MLP_PRECISIONS == ("f32", "bf16x3", "bf16x6") and set(ops.MLP_ARITHMETIC) == set(ops.MLP_PRECISIONS)
+    for name in ops.MLP_PRECISIONS:
+        assert m.set_mlp_precision(name) is m and m.mlp_precision == name and m.mlp_x3 == (name == "bf16x3")
+    assert m.set_mlp_precision("fp32").mlp_precision == "f32"
+    with pytest.raises(ValueError):
+        m.set_mlp_precision("fp8")
+    old = dict(m.__dict__)                      # a module pickled by round <= 5: the boolean, no mlp_precision
+    del m.__dict__["mlp_precision"]
+    m.__dict__["mlp_x3"] = True
+    assert m.mlp_x3 is True
+    m.__dict__.clear()
+    m.__dict__.update(old)
+    assert m.set_gather_rows("bf16").gather_rows_bf16 is True and m.set_gather_rows("f32").gather_rows_bf16 is False
+    assert not ops.gather_rows_are_bf16(m.set_gather_rows("bf16"))     # D = 16 has no bf16 table: nothing to select
+    with pytest.raises(ValueError):
+        m.set_gather_rows("fp8")
+    assert [ops.default_mlp_precision(d) for d in ("f32", "bf16", "bf16x3", "bf16x6")] == ["f32", "bf16x3", "bf16x3", "bf16x6"]
+    with ops.mlp_arith("bf16x6"):
+        assert ops.GemmGroup().mode == 2 and ops.GemmGroup().x3
+        with ops.mlp_arith(True):
+            assert ops.GemmGroup().mode == 1
+        with ops.mlp_arith(False):
+            assert ops.GemmGroup().mode == 0 and not ops.GemmGroup().x3
+    assert ops.GemmGroup().mode == 0
+    # the trainer (no step is taken: no kernel is launched)
+    N = e.weight.shape[0]
+    tr = Trainer(m, lr=1e-3, beta=0.001, n_candidate=7, n_items=N - 3, capture_graph=True)
+    assert tr.n_items == N - 3 and tr._capturable() and tr._mode()[2] == N - 3
+    for bad in (0, N + 1):
+        with pytest.raises(ValueError):
+            Trainer(m, lr=1e-3, beta=0.001, n_candidate=7, n_items=bad)
+    with pytest.raises(ValueError):
+        Trainer(m, lr=1e-3, beta=0.001, n_candidate=7, n_neg=5)
+    s = torch.zeros(6, 5, dtype=torch.long)
+    cand, tgt = torch.zeros(6, 5, 7, dtype=torch.long), torch.zeros(6, 5, dtype=torch.long)
+    assert Trainer._check_given_sets((cand, tgt), s)[0] is cand
+    for wrong in ((cand[:5], tgt[:5]), (cand[:, :4], tgt), (cand, tgt[:, :4]), (cand.reshape(30, 7), tgt), (cand,), cand):
+        with pytest.raises(ValueError):
+            Trainer._check_given_sets(wrong, s)
+    tr.n_candidate = (cand, tgt)
+    assert not tr._capturable() and tr._mode()[1] == "given"
+    tr2 = Trainer(m, lr=1e-3, beta=0.001, n_neg=N // 2, capture_graph=True)     # keep probability above the sparse kernel's range
+    assert tr2.capture_graph and not tr2._capturable()
