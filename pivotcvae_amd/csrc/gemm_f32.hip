@@ -301,6 +301,16 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                         v[e] = *reinterpret_cast<const float*>(img + k * 256 + ((row ^ (((k >> 2) & 1) << 5)) << 2));
                     }
                 }
+#ifdef GEMM_PROBE_NO_SPLIT   // probe builds only (tools/gemm_loop_probe.sh): the fragments without the split's vector work (results garbage)
+                {
+                    const unsigned* w = reinterpret_cast<const unsigned*>(v);
+                    unsigned* ph = reinterpret_cast<unsigned*>(&hi);
+                    unsigned* pl = reinterpret_cast<unsigned*>(&lo);
+                    unsigned* p2 = reinterpret_cast<unsigned*>(&lo2);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ph[e] = w[e]; pl[e] = w[e + 4]; p2[e] = w[e] ^ w[e + 4]; }
+                }
+#else
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const __bf16 hv = (__bf16)v[e];
@@ -310,12 +320,23 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                     lo[e] = mv;
                     if constexpr (XM == 2) lo2[e] = (__bf16)(r1 - (float)mv);   // exact: at most 8 significant bits are left
                 }
+#endif
             };
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 fetch(sA, A_KC, wm * 32 + 16 * t + c16, ah[t], al[t], a2[t]);
                 fetch(sB, B_KC, wn * 32 + 16 * t + c16, bh[t], bl[t], b2[t]);
             }
+#ifdef GEMM_PROBE_NO_MFMA    // probe builds only: the loop without its MFMAs (the fragments are folded into the accumulators by four adds)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                const f32x4 fa = *reinterpret_cast<const f32x4*>(&ah[t2]), fb = *reinterpret_cast<const f32x4*>(&bl[t2]);
+                const f32x4 fc = *reinterpret_cast<const f32x4*>(&al[t2]), fd = *reinterpret_cast<const f32x4*>(&bh[t2]);
+                acc4[t2][0] += fa + fb;
+                acc4[t2][1] += fc + fd;
+                if constexpr (XM == 2) acc4[t2][0] += *reinterpret_cast<const f32x4*>(&a2[t2]) + *reinterpret_cast<const f32x4*>(&b2[t2]);
+            }
+#else
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -329,6 +350,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                     acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bl[ct], acc4[rt][ct], 0, 0, 0);
                     acc4[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[rt], bh[ct], acc4[rt][ct], 0, 0, 0);
                 }
+#endif
         } else {
         float a[4][4], b[4][4];
 #pragma unroll
