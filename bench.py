@@ -471,9 +471,10 @@ def pivot_block(cfg, B_local, pivot_ms, step_ms, rule="pt"):
 
 
 def committed_traffic(key):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (PMC counters cannot be read from inside the run)"""
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (PMC counters cannot be read from inside the run);
+    None for a workload the passes were not collected on (--global_batch: another number of row blocks per launch)"""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(tpath):
+    if key is None or not os.path.exists(tpath):
         return None
     return json.load(open(tpath)).get(key)
 
@@ -732,18 +733,20 @@ def main():
     # the gather kernels read fp32 rows unless bf16 rows were asked for (configs 3 / 5: the stated arithmetic is bf16)
     bf16_rows = ops.gather_rows_are_bf16(model)
     rows_dtype = "bf16 rows, fp32 accumulate" if bf16_rows else "f32"
+    # the committed counter passes are of the configs as BASELINE states them: none for an overridden batch
+    tkey = lambda what: None if args.global_batch else f"config{args.config}_{what}_gpus{world}"
     if cand_mode:
         roof = candidate_roofline(R_local, N, D, args.n_candidate, kern_ms,
-                                  committed_traffic(f"config{args.config}_cand{args.n_candidate}_gpus{world}"), bf16_rows)
+                                  committed_traffic(tkey(f"cand{args.n_candidate}")), bf16_rows)
         sparse = True
     else:
         roof = roofline_block(kernel_name(R_local, N, D, args.dtype) if not sparse else "catalog_ce_sparse_kernel",
                               R_local, N, D, args.dtype, kern_ms, sparse_kept=(args.n_neg + 1) if sparse else None,
-                              traffic=committed_traffic(f"config{args.config}_nneg{args.n_neg}_gpus{world}") if sparse else None,
+                              traffic=committed_traffic(tkey(f"nneg{args.n_neg}")) if sparse else None,
                               bf16_rows=bf16_rows)
     if not sparse:
         roof["kernel_note"] = "the events also span its row-bound prologue and merge kernels, <1% together"
-        roof["traffic"] = committed_traffic(f"config{args.config}_{args.dtype}_gpus{world}")
+        roof["traffic"] = committed_traffic(tkey(args.dtype))
     roof["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc passes of this kernel, committed; not measured in this run)"
     roof["timed_over"] = (f"{args.steps} eager steps right after the timed graph-replayed steps (HIP events cannot be "
                           "recorded inside a hipGraph)") if graphed else "HIP events on the launch stream inside the timed steps"

@@ -530,7 +530,7 @@ def variants_block(ctx):
                                       "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
                                       "roofline": roofline_block("catalog_ce_sparse_kernel", R_local, N, D, "f32", v["kern_ms"],
                                                                  sparse_kept=1001,
-                                                                 traffic=committed_traffic(f"config{args.config}_nneg1000_gpus{world}"),
+                                                                 traffic=committed_traffic(None if args.global_batch else f"config{args.config}_nneg1000_gpus{world}"),
                                                                  bf16_rows=bf16_rows)}
         if args.n_neg is None and not cand_mode and N >= 100_000:
             # the reference's DEFAULT mode (train_generative.py:270-274: candidate sets unless --mask_train; my_utils.py:169
@@ -542,7 +542,7 @@ def variants_block(ctx):
                     "launch": v["launch"],
                     "elbo": {k: t.item() for k, t in zip(("loss", "recLoss", "KLD"), v["elbo"])},
                     "roofline": candidate_roofline(R_local, N, D, cn, v["kern_ms"],
-                                                   committed_traffic(f"config{args.config}_cand{cn}_gpus{world}"), bf16_rows)}
+                                                   committed_traffic(None if args.global_batch else f"config{args.config}_cand{cn}_gpus{world}"), bf16_rows)}
     finally:
         trainer.capture_graph = was_graph
     return variants
