@@ -39,8 +39,22 @@ using namespace pcvae;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
+
+// two fp32 values -> their bf16 roundings (RNE) in one register, element 0 in the low half (v_cvt_pk_bf16_f32); and back, exactly
+__device__ __forceinline__ unsigned pack_bf16x2(const f32x2 x) {
+    const bf16x2 h = __builtin_convertvector(x, bf16x2);
+    return *reinterpret_cast<const unsigned*>(&h);
+}
+__device__ __forceinline__ f32x2 widen_bf16x2(const unsigned w) {
+    f32x2 r;
+    r[0] = __uint_as_float(w << 16);
+    r[1] = __uint_as_float(w & 0xffff0000u);
+    return r;
+}
 
 constexpr int BM = 64, BN = 64;                                       // output tile of the DMA body
 constexpr int DK = 32, NSTAGE = 2, STAGE_BYTES = 2 * 64 * DK * 4, PCS = 8;   // PCS: 256-byte pieces per wave per operand per chunk
@@ -286,8 +300,7 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
         if constexpr (X3) {
             // operand tile t (16 rows) of this wave: eight k values kset(gq) of row 16 t + c16, then the split into bf16 components
             bf16x8 ah[2], al[2], bh[2], bl[2], a2[2], b2[2];
-            auto fetch = [&](const char* img, const bool kc, const int row, bf16x8& hi, bf16x8& lo, bf16x8& lo2) {
-                float v[8];
+            auto ld = [&](const char* img, const bool kc, const int row, float (&v)[8]) {
                 if (kc) {
                     const unsigned sw = (unsigned)((row >> 1) & 7);
                     const f32x4 q0 = *reinterpret_cast<const f32x4*>(img + row * 128 + ((((unsigned)gq) ^ sw) << 4));
@@ -301,6 +314,8 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                         v[e] = *reinterpret_cast<const float*>(img + k * 256 + ((row ^ (((k >> 2) & 1) << 5)) << 2));
                     }
                 }
+            };
+            auto sp = [&](const float (&v)[8], bf16x8& hi, bf16x8& lo, bf16x8& lo2) {
 #ifdef GEMM_PROBE_NO_SPLIT   // probe builds only (tools/gemm_loop_probe.sh): the fragments without the split's vector work (results garbage)
                 {
                     const unsigned* w = reinterpret_cast<const unsigned*>(v);
@@ -311,16 +326,29 @@ __device__ __forceinline__ void gemm_tile_dma(const GemmParams& p, const int bx,
                     for (int e = 0; e < 4; ++e) { ph[e] = w[e]; pl[e] = w[e + 4]; p2[e] = w[e] ^ w[e + 4]; }
                 }
 #else
+                // the split, two values at a time: v_cvt_pk_bf16_f32 rounds a PAIR (RNE) into one register - already the fragment's
+                // layout -, one shift and one mask widen it back, one v_pk_add_f32 takes the (exact) remainders: 4 vector
+                // instructions per pair and level.  Written on explicit 2-vectors: left to itself hipcc packed only every other pair
+                // and split the rest value by value (7 instructions per pair and level; ISA, round 6).  Same roundings, same bits.
+                unsigned* ph = reinterpret_cast<unsigned*>(&hi);
+                unsigned* pl = reinterpret_cast<unsigned*>(&lo);
+                unsigned* p2 = reinterpret_cast<unsigned*>(&lo2);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const __bf16 hv = (__bf16)v[e];
-                    hi[e] = hv;
-                    const float r1 = v[e] - (float)hv;      // exact
-                    const __bf16 mv = (__bf16)r1;
-                    lo[e] = mv;
-                    if constexpr (XM == 2) lo2[e] = (__bf16)(r1 - (float)mv);   // exact: at most 8 significant bits are left
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 x = {v[2 * e], v[2 * e + 1]};
+                    const unsigned w0 = pack_bf16x2(x);
+                    ph[e] = w0;
+                    const f32x2 r1 = x - widen_bf16x2(w0);    // exact
+                    const unsigned w1 = pack_bf16x2(r1);
+                    pl[e] = w1;
+                    if constexpr (XM == 2) p2[e] = pack_bf16x2(r1 - widen_bf16x2(w1));   // exact: at most 8 significant bits are left
                 }
 #endif
+            };
+            auto fetch = [&](const char* img, const bool kc, const int row, bf16x8& hi, bf16x8& lo, bf16x8& lo2) {
+                float v[8];
+                ld(img, kc, row, v);
+                sp(v, hi, lo, lo2);
             };
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
