@@ -1749,6 +1749,7 @@ struct ScreenAcc { f32x4 acc[2][CT]; };
 template <int CT>
 struct ScreenState {        // per lane: rows 16 ct + c of the wave
     float m[CT], thr[CT], eps2[CT];
+    float tmp;           // the looks' temporary, alive over the whole range (see vmax8_into)
     int64_t row[CT];
     uint64_t mk[CT];     // steady-state slots of pass B: lanes of column tile ct that saw a logit over their threshold (SGPR pair)
     unsigned int cnt;    // pass B: entries this WAVE has parked in its own quarter of the candidate list (wave-uniform)
@@ -1765,22 +1766,24 @@ __device__ __forceinline__ float vmax8(const f32x4& lo, const f32x4& hi) {
         : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
     return r;
 }
-__device__ __forceinline__ void vmax8_into(float& m, const f32x4& lo, const f32x4& hi) {   // m = max(m, the eight)
-    float t;
-    asm("v_max3_f32 %1, %2, %3, %4\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max3_f32 %1, %1, %7, %8\n\tv_max3_f32 %0, %0, %1, %9"
-        : "+v"(m), "=&v"(t)
+// (volatile, with the temporary in a register the CALLER keeps alive over the whole slot - ScreenState::tmp: the statement then stays where
+// the schedule puts it, in the shadow of the step's MFMAs, and its temporary can never be a register a queued MFMA still has to read.
+// Non-volatile, hipcc sank all of a slot's looks behind its last MFMA: 16-20 vector instructions at a lone wave's 5.5-cycle cadence with
+// the matrix pipe idle - tools/valu_rate_probe.hip, round 6.)
+__device__ __forceinline__ void vmax8_into(float& m, float& t, const f32x4& lo, const f32x4& hi) {   // m = max(m, the eight)
+    asm volatile("v_max3_f32 %1, %2, %3, %4\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max3_f32 %1, %1, %7, %8\n\tv_max3_f32 %0, %0, %1, %9"
+        : "+v"(m), "+v"(t)
         : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
 }
 
 // Pass B, steady state: the eight-way maximum AND the threshold test in one statement, the outcome as a wave mask in SGPRs.
 // The four masks of a slot are OR-ed and tested ONCE at the end of the slot (one scalar branch per slot instead of four
 // exec-mask branches); a slot that has a candidate anywhere then runs screen_look() per column tile.
-__device__ __forceinline__ uint64_t screen_peek(const f32x4& lo, const f32x4& hi, const float thr) {
-    float t;
+__device__ __forceinline__ uint64_t screen_peek(float& t, const f32x4& lo, const f32x4& hi, const float thr) {
     uint64_t mask;
-    asm("v_max3_f32 %1, %2, %3, %4\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max3_f32 %1, %1, %7, %8\n\tv_max_f32 %1, %1, %9\n\t"
+    asm volatile("v_max3_f32 %1, %2, %3, %4\n\tv_max3_f32 %1, %1, %5, %6\n\tv_max3_f32 %1, %1, %7, %8\n\tv_max_f32 %1, %1, %9\n\t"
         "v_cmp_ge_f32 %0, %1, %10"
-        : "=s"(mask), "=&v"(t)
+        : "=s"(mask), "+v"(t)
         : "v"(lo[0]), "v"(lo[1]), "v"(lo[2]), "v"(lo[3]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]), "v"(thr));
     return mask;
 }
@@ -1796,7 +1799,7 @@ __device__ __forceinline__ void screen_look(const ScreenParams& p, char* cand, S
                 if (n0 + 16 * rt + 4 * g + i >= p.N) a.acc[rt][ct][i] = -INFINITY;
     }
     if (PASS == 0) {
-        vmax8_into(st.m[ct], a.acc[0][ct], a.acc[1][ct]);
+        vmax8_into(st.m[ct], st.tmp, a.acc[0][ct], a.acc[1][ct]);
     } else {
         // Every caller reaches this point with all 64 lanes active.  A lane whose best logit passes its threshold parks its
         // eight items (n0 + 16 rt + 4 g + i) as ONE entry with a bit per item that passed; the final phase rescores the marked
@@ -1857,7 +1860,12 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
                     }
                     pipe_fence();
                 } else {
+#if defined(SCREEN_PROBE_NO_SEAMWAIT)     // probe builds only (with SCREEN_PROBE_NO_CAND): the steady-state seam without its wait + barrier
+#elif defined(SCREEN_PROBE_NO_BARRIER)    // ... or without its barrier only
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+#else
                     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(VM) : "memory");
+#endif
                     pipe_stage<D>(sm.E, sm.n_stage, sm.stage_lds, wave_u, lane_off);
                 }
             }
@@ -1868,7 +1876,11 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
         // were requested while A(I) was already in flight
         constexpr int extra = (I >= MID && I < MID + PIPE_AD) ? PIPE_AD : 0;
         if constexpr (I + PIPE_AD < NI) pipe_a_issue<D, OFF, I + PIPE_AD>(lbase, a0, af[I + PIPE_AD]);
+#ifdef SCREEN_PROBE_NO_LDSWAIT     // probe builds only (with SCREEN_PROBE_NO_CAND): the steady-state steps do not wait for their A fragments
+        if constexpr (COLD) lgkm_wait<(I + PIPE_AD < NI ? PIPE_AD : NI - 1 - I) + extra>();
+#else
         lgkm_wait<(I + PIPE_AD < NI ? PIPE_AD : NI - 1 - I) + extra>();
+#endif
         constexpr int s = I >> 1, rt = I & 1;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -1878,7 +1890,7 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
         if constexpr (HAS_PREV && (I + 1) % (NI / CT) == 0) {
             constexpr int ct = (I + 1) / (NI / CT) - 1;
             asm volatile("" : "+v"(prev.acc[0][ct]), "+v"(prev.acc[1][ct]));   // not before this point of the chain
-            if constexpr (PASS == 1 && !COLD) st.mk[ct] = screen_peek(prev.acc[0][ct], prev.acc[1][ct], st.thr[ct]);
+            if constexpr (PASS == 1 && !COLD) st.mk[ct] = screen_peek(st.tmp, prev.acc[0][ct], prev.acc[1][ct], st.thr[ct]);
             else screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);
         }
         screen_pipe_logits<D, CT, PASS, OFF, OFFN, I + 1, SEAM, VM, HAS_PREV, COLD>(p, cand, lbase, a0, af, xb, cur, prev,
@@ -1887,7 +1899,14 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
         uint64_t any = st.mk[0];
 #pragma unroll
         for (int ct = 1; ct < CT; ++ct) any |= st.mk[ct];
-        if (any != 0) {   // rare: some lane of the wave has a candidate in the previous subtile
+        // rare: some lane of the wave has a candidate in the previous subtile (unlikely: hipcc then lays the ~250 instructions of the
+        // block out of line and the steady-state trip falls through - 906 instructions for 16 slots instead of 4 781)
+#ifdef SCREEN_PROBE_NO_BRANCH     // probe builds only (with SCREEN_PROBE_NO_CAND): the masks are computed, nothing looks at them
+        asm volatile("" :: "s"(any));
+        if (false) {
+#else
+        if (__builtin_expect(any != 0, 0)) {
+#endif
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
                 if (st.mk[ct] != 0) screen_look<D, CT, PASS, false>(p, cand, prev, n_prev, st, g, ct);   // scalar test again
@@ -1923,6 +1942,7 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
     bf16x8 xb[CT][G::KS];
     ScreenState<CT> st;
     st.cnt = 0u;
+    st.tmp = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const int64_t r = rw + 16 * ct + c;
@@ -2020,17 +2040,25 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
             for (int ct = 0; ct < CT; ++ct) screen_look<D, CT, PASS, true>(p, cand, a, (int64_t)(tt + sb) * 32, st, g, ct);
         }
     }
-    if (PASS == 1) {  // rescore the parked candidates of the four waves' lists, one item per thread
+    if (PASS == 1) {  // rescore the parked candidates of the four waves' lists
+        // One ENTRY per thread over all four lists at once (an entry = a lane's eight items with a bit per item that passed; nearly always
+        // one bit): the ~10^2 entries of a workgroup are one round of exact chains.  (Until round 6: one ITEM SLOT per thread, list after
+        // list - four dependent rounds of global round trips per workgroup with seven of eight threads idle; the order of the 64-bit
+        // atomicMax folds does not matter, the ids are the same.)
         unsigned int* counts = reinterpret_cast<unsigned int*>(cand + SCREEN_PIPE_CAP * 16);
         if (lane == 0) counts[wave] = min(st.cnt, (unsigned)(SCREEN_PIPE_CAP / 4));
         __syncthreads();
-        for (int w = 0; w < 4; ++w) {
-            const unsigned int cnt = counts[w];
-            const uint4* list = reinterpret_cast<const uint4*>(cand) + w * (SCREEN_PIPE_CAP / 4);
-            for (unsigned int j = threadIdx.x; j < 8 * cnt; j += 256) {   // entry j / 8, item (j % 8) of its lane
-                const uint4 en = list[j >> 3];
-                const int64_t n = (int64_t)en.y + 16 * ((j >> 2) & 1) + (j & 3);
-                if (((en.z >> (j & 7)) & 1u) && n < p.N) screen_rescore<D>(p, (int64_t)en.x, n);
+        const unsigned int c0 = counts[0], c1 = c0 + counts[1], c2 = c1 + counts[2], c3 = c2 + counts[3];
+        for (unsigned int e = threadIdx.x; e < c3; e += 256) {
+            const unsigned int w = e < c0 ? 0u : e < c1 ? 1u : e < c2 ? 2u : 3u;
+            const unsigned int base = w == 0u ? 0u : w == 1u ? c0 : w == 2u ? c1 : c2;
+            const uint4 en = (reinterpret_cast<const uint4*>(cand) + w * (SCREEN_PIPE_CAP / 4))[e - base];
+            unsigned int bits = en.z & 0xffu;
+            while (bits) {
+                const unsigned int b = (unsigned int)__builtin_ctz(bits);   // bit 4 rt + i <-> item n0 + 4 g + 16 rt + i
+                bits &= bits - 1u;
+                const int64_t n = (int64_t)en.y + 16 * ((b >> 2) & 1u) + (b & 3u);
+                if (n < p.N) screen_rescore<D>(p, (int64_t)en.x, n);
             }
         }
     }
@@ -2057,7 +2085,11 @@ __global__ void catalog_screen_threshold_kernel(ScreenParams p, int D) {
     for (int k = 0; k < D; ++k) ss = fmaf(p.x[r * D + k], p.x[r * D + k], ss);
     // two RNE roundings per product (2^-9 each), fp32 accumulation slack growing with the chain length
     const float eps = (0.00390625f * 1.02f + 2e-5f * (float)(D > 128 ? D / 128 : 1)) * sqrtf(ss) * p.e_max_norm;
+#ifdef SCREEN_PROBE_NO_CAND   // probe builds only (tools/screen_loop_probe.sh): no item ever passes - pass B without its candidate handling (ids garbage)
+    p.thr[r] = INFINITY;
+#else
     p.thr[r] = mm - 2.f * eps - 1e-30f;
+#endif
     p.eps2[r] = 2.f * eps + 1e-30f;
     p.best_key[r] = 0ull;
     if (r == 0) *p.overflow = 0u;
@@ -2067,7 +2099,11 @@ __global__ void catalog_screen_decode_kernel(ScreenParams p, int64_t* __restrict
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.R) return;
     const unsigned long long key = p.best_key[r];
+#ifdef SCREEN_PROBE_NO_CAND   // (probe builds: no candidate was folded, the key is empty - a VALID id, the callers gather with it)
+    idx[r] = 0;
+#else
     idx[r] = (int64_t)(0xffffffffu - (unsigned int)(key & 0xffffffffull));
+#endif
     if (best) best[r] = unordered_bits((unsigned int)(key >> 32));
 }
 
