@@ -641,7 +641,7 @@ def epoch_block(ctx, n_batches=16, val_batches=2):
                                     trainer=loop_tr)
             del loop_tr
             tr = Trainer(model, lr=LR, beta=BETA, capture_graph=not args.no_graph, resident_batch=True, optimizer=opt, **mode)
-            v = StepTimer(tr, ctx["batch"], B, ctx["lo"], False, device).run(10, 3)
+            v = StepTimer(tr, ctx["batch"], B, ctx["lo"], False, device).run(40, 5)   # (ms-scale steps: 10 of them left the ratio at +-5 %)
             step_ms = v["dt"] / v["steps"] * 1e3
             t_train, t_val = hist["train_seconds"][-1], hist["val_seconds"][-1]
             out[name] = {"slates_per_s": n_batches * B / (t_train + t_val), "train_slates_per_s": n_batches * B / t_train,
