@@ -284,7 +284,12 @@ def _x3_fuzz_sequence(ops, Dx, seed, cases=24):
         np.testing.assert_allclose(lse.cpu().numpy(), wl, rtol=2e-6 * k, atol=2e-6 + 2e-6 * xn, err_msg=msg)
         np.testing.assert_allclose(nll.cpu().numpy(), wn, rtol=2e-6 * k, atol=4e-6 + 2e-6 * xn + 2e-6 * k * float(np.abs(wl).max()),
                                    err_msg=msg)   # nll = lse - z_t cancels: the lse's ABSOLUTE error is what it carries
-        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5 * k, atol=2e-6 * k, err_msg=msg)
+        # dx = sum_n p_n E_n - E_t: a logit error of ~2e-6 |x| (above) is a relative error of that size on every p_n, so dx carries up to
+        # that times the largest table element - all of it when the catalog is a handful of items (N = 1: the reference's dx is exactly 0,
+        # the kernel's is (exp(logit error) - 1) E_0; seed 139 of the round-6 campaign: 2.2e-6 at N = 1, |x| = 3.7), averaged away over a
+        # large one
+        e_max = float(E.abs().max())
+        np.testing.assert_allclose(dx.cpu().numpy(), wd, rtol=2e-5 * k, atol=2e-6 * k + 2e-6 * xn * e_max, err_msg=msg)
 
 
 @pytest.mark.parametrize("Dx", [128, 256])
