@@ -32,6 +32,7 @@
 // the fp32 reference the per-logit error is ~2^-9 relative per product and zero-mean, so the ELBO terms of
 // a batch agree to ~1e-6 while individual gradients agree to ~1e-3 (tests/test_hip_bf16.py).
 #include "catalog_plan.h"
+#include <climits>
 #include <cstdlib>
 
 using namespace pcvae;
@@ -1741,7 +1742,19 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_kernel(ScreenParam
 // hipcc schedules between the MFMAs; an empty asm on the previous accumulators a few MFMAs into the slot keeps those reads
 // behind the MFMAs that wrote them).  Ring and seams as in the CE kernel; the seam sits at the end of a chunk's last slot.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int SCREEN_PIPE_CAP = 3072;   // 16-byte entries: (row, first item of the lane's eight, bit per item, -)
+// 8-byte entries: (row, first item of the lane's eight / 4 << 8 | bit per item) - the first item is a multiple of 4 below 2^26 (larger
+// catalogs take the two-waves kernel, see launch_screened); a quarter of the list per wave.
+//   D = 64 : 2032 entries - ring (64 KB) + list + counters = 81 808 bytes, so that TWO workgroups fit a CU's 160 KB (round 6: -17 % on
+//            config 3's generate batch, tools/screen_wg_ab.sh; until then 3072 entries of 16 bytes and one workgroup per CU everywhere);
+//   D >= 128: 6144 entries (48 KB), one workgroup per CU (two were measured at D = 128, config 4: +0.9 %; at D = 256 the ring is 96 KB).
+// SCREEN_PIPE_ENTRIES_64: A/B builds.
+#ifndef SCREEN_PIPE_ENTRIES_64
+#define SCREEN_PIPE_ENTRIES_64 2032
+#endif
+template <int D>
+__host__ __device__ constexpr int screen_pipe_cap() { return D == 64 ? SCREEN_PIPE_ENTRIES_64 : 6144; }
+constexpr int SCREEN_PIPE_ENTRY_BYTES = 8;
+constexpr int64_t SCREEN_PIPE_MAX_ITEMS = 1ll << 26;
 
 template <int CT>
 struct ScreenAcc { f32x4 acc[2][CT]; };
@@ -1818,8 +1831,9 @@ __device__ __forceinline__ void screen_look(const ScreenParams& p, char* cand, S
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) mask |= (a.acc[rt][ct][i] >= st.thr[ct] ? 1u : 0u) << (4 * rt + i);
-                uint4* list = reinterpret_cast<uint4*>(cand) + (threadIdx.x >> 6) * (SCREEN_PIPE_CAP / 4);
-                if (slot < (unsigned)(SCREEN_PIPE_CAP / 4)) list[slot] = make_uint4((unsigned int)st.row[ct], (unsigned int)(n0 + 4 * g), mask, 0u);
+                uint2* list = reinterpret_cast<uint2*>(cand) + (threadIdx.x >> 6) * (screen_pipe_cap<D>() / 4);
+                if (slot < (unsigned)(screen_pipe_cap<D>() / 4))
+                    list[slot] = make_uint2((unsigned int)st.row[ct], ((unsigned int)((n0 + 4 * g) >> 2) << 8) | mask);
                 else *p.overflow = 1u;
                 // everything this lane meets later only matters if it comes within 2 eps of what it has already seen
                 st.thr[ct] = fmaxf(st.thr[ct], v - st.eps2[ct]);
@@ -1915,7 +1929,7 @@ __device__ __forceinline__ void screen_pipe_logits(const ScreenParams& p, char* 
 }
 
 template <int D, int CT, int PASS>
-__global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParams p) {
+__global__ void __launch_bounds__(256, 2) catalog_screen_pipe_kernel(ScreenParams p) {
     using G = FastGeo<D>;
     using PG = PipeGeo<D, CT>;
     constexpr int CB = 16384, NW = 4, ROWS = PG::ROWS, SUB = G::SUB, TR = PG::TR, NB = PG::NB, PF = PG::PF;
@@ -2045,19 +2059,20 @@ __global__ void __launch_bounds__(256, 1) catalog_screen_pipe_kernel(ScreenParam
         // one bit): the ~10^2 entries of a workgroup are one round of exact chains.  (Until round 6: one ITEM SLOT per thread, list after
         // list - four dependent rounds of global round trips per workgroup with seven of eight threads idle; the order of the 64-bit
         // atomicMax folds does not matter, the ids are the same.)
-        unsigned int* counts = reinterpret_cast<unsigned int*>(cand + SCREEN_PIPE_CAP * 16);
-        if (lane == 0) counts[wave] = min(st.cnt, (unsigned)(SCREEN_PIPE_CAP / 4));
+        unsigned int* counts = reinterpret_cast<unsigned int*>(cand + screen_pipe_cap<D>() * SCREEN_PIPE_ENTRY_BYTES);
+        if (lane == 0) counts[wave] = min(st.cnt, (unsigned)(screen_pipe_cap<D>() / 4));
         __syncthreads();
         const unsigned int c0 = counts[0], c1 = c0 + counts[1], c2 = c1 + counts[2], c3 = c2 + counts[3];
         for (unsigned int e = threadIdx.x; e < c3; e += 256) {
             const unsigned int w = e < c0 ? 0u : e < c1 ? 1u : e < c2 ? 2u : 3u;
             const unsigned int base = w == 0u ? 0u : w == 1u ? c0 : w == 2u ? c1 : c2;
-            const uint4 en = (reinterpret_cast<const uint4*>(cand) + w * (SCREEN_PIPE_CAP / 4))[e - base];
-            unsigned int bits = en.z & 0xffu;
+            const uint2 en = (reinterpret_cast<const uint2*>(cand) + w * (screen_pipe_cap<D>() / 4))[e - base];
+            const int64_t first = (int64_t)(en.y >> 8) << 2;
+            unsigned int bits = en.y & 0xffu;
             while (bits) {
                 const unsigned int b = (unsigned int)__builtin_ctz(bits);   // bit 4 rt + i <-> item n0 + 4 g + 16 rt + i
                 bits &= bits - 1u;
-                const int64_t n = (int64_t)en.y + 16 * ((b >> 2) & 1u) + (b & 3u);
+                const int64_t n = first + 16 * ((b >> 2) & 1u) + (b & 3u);
                 if (n < p.N) screen_rescore<D>(p, (int64_t)en.x, n);
             }
         }
@@ -2186,9 +2201,18 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
     return PCVAE_EINVAL;
 }
 
+// ranges of at least this many 32-item tiles take the software-pipelined screening kernels.  PCVAE_PIPE_MIN_TILES (read per launch) moves
+// the threshold: the tests force the pipelined kernels onto small shapes with it.
+// (D = 64, round 6: from 128 tiles per range - the quarter-catalog prefix pass of config 3's generate step takes the pipelined
+// kernel too: 1.09 -> 1.05 ms per batch, same ids)
+static int screen_pipe_min(int D) {
+    const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
+    return env_min ? atoi(env_min) : (D == 64 ? 128 : 512);
+}
+
 template <int D>
 static int launch_screened(ScreenParams p, const CatalogPlan& pa, const CatalogPlan& pb, int64_t Ns, int64_t N, int64_t* idx,
-                           float* best, hipStream_t st) {
+                           float* best, int wgpc, hipStream_t st) {
     const size_t lds = SCREEN_LDS_BYTES;
     if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 0>), (int)lds)) return rc_optin;
     if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_bf16_kernel<D, 1>), (int)lds)) return rc_optin;
@@ -2196,13 +2220,14 @@ static int launch_screened(ScreenParams p, const CatalogPlan& pa, const CatalogP
     // long ranges: the software-pipelined screening kernels (one wave per SIMD, 64 rows per wave for D <= 128)
     constexpr int CT = D == 256 ? 2 : 4;
     using PG = PipeGeo<D, CT>;
-    constexpr int lds_pipe = PG::NB * 16384 + SCREEN_PIPE_CAP * 16 + 16;
-    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 0>), lds_pipe)) return rc_optin;
-    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 1>), lds_pipe)) return rc_optin;
-    const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
-    // (D = 64, round 6: from 128 tiles per range - the quarter-catalog prefix pass of config 3's generate step takes the pipelined
-    // kernel too: 1.09 -> 1.05 ms per batch, same ids)
-    const int pipe_min = env_min ? atoi(env_min) : (D == 64 ? 128 : 512);
+    // what the kernel uses; planned for one workgroup per CU it ASKS for 96 KB, so that the hardware does not co-schedule two anyway
+    constexpr int lds_used = PG::NB * 16384 + screen_pipe_cap<D>() * SCREEN_PIPE_ENTRY_BYTES + 16;
+    constexpr int lds_one = lds_used > 96 * 1024 ? lds_used : 96 * 1024;
+    const int lds_pipe = wgpc >= 2 ? lds_used : lds_one;
+    // (the opt-in is remembered per kernel, not per size: ask for the larger of the two once)
+    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 0>), lds_one)) return rc_optin;
+    if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_screen_pipe_kernel<D, CT, 1>), lds_one)) return rc_optin;
+    const int pipe_min = N < SCREEN_PIPE_MAX_ITEMS ? screen_pipe_min(D) : INT_MAX;   // (the pipelined kernels' entries hold item / 4 in 24 bits)
     p.N = Ns; p.nrb = pa.nrb; p.nsplit = pa.nsplit; p.tiles_per_split = pa.tiles_per_split; p.ntiles = pa.ntiles;
     if (pa.tiles_per_split >= pipe_min)
         hipLaunchKernelGGL((catalog_screen_pipe_kernel<D, CT, 0>), dim3((unsigned)(cdiv(p.R, PG::ROWS) * pa.nsplit)), dim3(256),
@@ -2235,7 +2260,26 @@ int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const
     static const int64_t prefix_div = [] { const char* e = getenv("PCVAE_SCREEN_PREFIX_DIV"); return e && atoll(e) > 0 ? atoll(e) : 4LL; }();
     const int64_t Ns = N >= 262144 ? (N / 16) / 128 * 128 : N >= prefix_min ? (N / prefix_div) / 128 * 128 : N;
     // the screen kernels always run 256-row workgroups: plan them as the D = 128 case
-    const CatalogPlan pa = catalog_plan(R, Ns, 128, PCVAE_PREC_BF16), pb = catalog_plan(R, N, 128, PCVAE_PREC_BF16);
+    // Two workgroups per CU at D = 64: a lone wave per SIMD issues one instruction per ~5.5 cycles and an MFMA per 17.5, two waves share
+    // the SIMD at ~2.7 and 16.5 (tools/valu_rate_probe.hip) - and a D = 64 screening slot is mostly bookkeeping (16 MFMAs + 41 other
+    // instructions).  The registers allow it (<= 202 VGPRs), the candidate list was what did not fit.
+    // At D = 128 a slot is 32 MFMAs under the same bookkeeping and two workgroups per CU bought nothing (config 4: 17.19 vs 17.35 ms per
+    // batch, tools/screen_wg_ab.sh): one, with the long candidate list.  PCVAE_SCREEN_WG_PER_CU=1 (read once) plans D = 64 for one as well
+    // and asks for 96 KB of LDS so that the hardware does not co-schedule two anyway (A/B measurements).
+    static const int wg_env = [] { const char* e = getenv("PCVAE_SCREEN_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    const int wgpc = (D == 64 && wg_env != 1) ? 2 : 1;
+    // (few rows: twice the ranges can push a range under the pipelined kernels' minimum - then the plan for one workgroup per CU, whose
+    // ranges are long enough, is the better one: config 3's pivot stage, R = 4096, 68 vs 97 us)
+    const int pipe_min = N < SCREEN_PIPE_MAX_ITEMS ? screen_pipe_min(D) : INT_MAX;
+    auto plan = [&](int64_t n) {
+        const CatalogPlan p2 = catalog_plan(R, n, 128, PCVAE_PREC_BF16, wgpc);
+        if (wgpc > 1 && p2.tiles_per_split < pipe_min) {
+            const CatalogPlan p1 = catalog_plan(R, n, 128, PCVAE_PREC_BF16, 1);
+            if (p1.tiles_per_split >= pipe_min) return p1;
+        }
+        return p2;
+    };
+    const CatalogPlan pa = plan(Ns), pb = plan(N);
     ScreenParams p{};
     p.x = x; p.Eb = Eb; p.Ef = Ef; p.R = R; p.e_max_norm = e_max_norm;
     p.best_key = reinterpret_cast<unsigned long long*>(ws);  // 8-byte atomics: keep first (ws is 16-byte aligned)
@@ -2244,9 +2288,9 @@ int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const
     p.pm = p.eps2 + R;   // [nsplit(A) <= 64][R]
     p.overflow = reinterpret_cast<unsigned int*>(p.pm + 64 * R);   // (pcvae_catalog_ws_bytes reserves 64 bytes behind pm)
     switch (D) {
-        case 64: return launch_screened<64>(p, pa, pb, Ns, N, idx, best, st);
-        case 128: return launch_screened<128>(p, pa, pb, Ns, N, idx, best, st);
-        case 256: return launch_screened<256>(p, pa, pb, Ns, N, idx, best, st);
+        case 64: return launch_screened<64>(p, pa, pb, Ns, N, idx, best, wgpc, st);
+        case 128: return launch_screened<128>(p, pa, pb, Ns, N, idx, best, wgpc, st);
+        case 256: return launch_screened<256>(p, pa, pb, Ns, N, idx, best, wgpc, st);
     }
     set_error("catalog_argmax(screened): unsupported D=%d (64, 128, 256)", D);
     return PCVAE_EINVAL;

@@ -43,7 +43,9 @@ struct CatalogPlan {
 // Deterministic in (R, N, D, precision) only - never in the device or the launch - so results are reproducible.
 //   f32 kernels : 128-row workgroups (4 waves), 2 resident per CU, any tile count per range
 //   bf16 kernels: 256-row workgroups (8 waves), 1 resident per CU, ranges are whole 128-item LDS chunks
-static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
+//   (wg_per_cu: resident workgroups per CU of the kernel the plan is for, where that is not the precision's default - the pipelined
+//   screening kernels at D <= 128 run two)
+static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec, int wg_per_cu = 1) {
     const bool f32 = prec == PCVAE_PREC_F32;
     // split-bf16 kernels (bf16x3: table rows of 4 D bytes, the geometry of the D = 256 bf16 kernel; bf16x6: 6 D bytes): one plan
     const bool x3 = prec == PCVAE_PREC_BF16X3 || prec == PCVAE_PREC_BF16X6;
@@ -56,7 +58,7 @@ static inline CatalogPlan catalog_plan(int64_t R, int64_t N, int D, int prec) {
     // workgroups: the cost model is rounds x tiles-per-range (e.g. 40 row blocks: 26 ranges = 1040 workgroups =
     // 4.06 rounds -> 5 rounds of 1202 tiles; 32 ranges = 1280 workgroups = exactly 5 rounds of 980 tiles, 19 % less).
     // Ranges stay long enough that the per-range prologue (rx fragments) and epilogue (partials) are amortised.
-    const int64_t slots = 256 * (f32 ? 2 : 1);
+    const int64_t slots = 256 * (f32 ? 2 : 1) * wg_per_cu;
     // the bf16 fast kernel for D = 256 runs 128-row workgroups (4 waves, one per SIMD): twice the workgroups per range
     const int64_t nblk = x3 ? cdiv(R, 64 * x3_ct(D)) : ((!f32 && D == 256) ? cdiv(R, 64 * PIPE_CT256) : p.nrb);
     const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(64, p.ntiles / (f32 ? 16 : 64)));

@@ -642,6 +642,33 @@ def test_catalog_argmax_screened_near_ties_and_duplicates(ops, D):
     assert idx[0] == 11 and idx[1] == 11 and idx[2] == 500 and idx[3] == 123 and idx[6] == 0
 
 
+@pytest.mark.parametrize("D", [64, 128, 256])
+def test_catalog_argmax_screened_pipelined_kernels_and_list_overflow(ops, D, monkeypatch):
+    """The software-pipelined screening kernels forced onto a small shape (PCVAE_PIPE_MIN_TILES, read per launch): fill slot, steady
+    trips, fenced last slots, ragged tail - and a candidate flood: sixteen all-zero queries in ONE wave's rows tie every item of the
+    catalog at 0, so that wave's quarter of the workgroup's candidate list (508 entries at D = 64, 1536 beyond; 8-byte entries,
+    round 6) overflows and pass B is redone by the exact two-waves kernel.  Ids and winning scores as the fp32 chain's, lowest index on
+    the ties."""
+    monkeypatch.setenv("PCVAE_PIPE_MIN_TILES", "1")
+    N, R = 40003, 600
+    E = unit_rows(N, D, seed=31)
+    x = rnd(R, D, seed=32, scale=2.0)
+    x[:16] = 0.0
+    x[300] = E[777] * 3.0
+    x[599] = E[N - 1] * 2.0
+    idx, best = ops.catalog_argmax(x.to(DEV), E.to(DEV), return_best=True, screened=True)
+    wi, wb = co.argmax(x.numpy(), E.numpy())
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(best.cpu().numpy(), wb)
+    assert int(idx[:16].abs().sum()) == 0 and idx[300] == 777 and idx[599] == N - 1
+    # the same without the flood: nothing overflows, the pipelined pass B alone answers
+    x[:16] = rnd(16, D, seed=33, scale=2.0)
+    idx, best = ops.catalog_argmax(x.to(DEV), E.to(DEV), return_best=True, screened=True)
+    wi, wb = co.argmax(x.numpy(), E.numpy())
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(best.cpu().numpy(), wb)
+
+
 def test_catalog_argmax_screened_unnormalised_table(ops):
     """Row norms spread over 3 decades: the bound uses the LARGEST row norm, small rows can still win nothing wrongly."""
     N, D, R = 50000, 128, 200
