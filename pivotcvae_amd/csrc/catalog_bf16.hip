@@ -1479,7 +1479,7 @@ int launch_ce_b(CatParamsB p, int mask_mode, bool want_dx, float e_max_norm, uin
             // small catalogs) stay on the two-waves-per-SIMD kernel.  PCVAE_PIPE_MIN_TILES (read per launch) moves the
             // threshold: the tests force the pipelined kernels onto small shapes with it.
             constexpr bool ALWAYS_PIPE = D == 256;
-            constexpr int CT = D == 256 ? PIPE_CT256 : 4;
+            constexpr int CT = D == 256 ? PIPE_CT256 : D == 64 ? PIPE_CT64 : 4;
             if (catalog_bf16_pipelined(D, p.tiles_per_split)) {
                 constexpr int lds_pipe = PipeGeo<D, CT>::NB * 16384;
                 if (int rc_optin = lds_optin(reinterpret_cast<const void*>(&catalog_ce_bf16_pipe_kernel<D, CT>), lds_pipe)) return rc_optin;

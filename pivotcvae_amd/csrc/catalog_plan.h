@@ -12,6 +12,12 @@
 #define X3_CT256 1   // D = 256: 16 rows per wave, 64 per workgroup (U alone is 128 accumulator registers at 32 rows: hipcc then spills)
 #endif
 static inline constexpr int x3_ct(int D) { return D == 256 ? X3_CT256 : X3_CT; }
+#ifndef PIPE_CT64
+#define PIPE_CT64 4    // column tiles of 16 rows per wave of the D = 64 bf16 cross-entropy kernel.  2 (128-row workgroups of 256 registers per
+                       // lane, TWO resident per CU - what gave the D = 64 screening kernels 17 %) was built and measured in round 6, same box,
+                       // alternating: config 3's kernel 0.865 vs 0.842 ms - its slot is bound by the exponentials (one quarter-rate v_exp_f32
+                       // per MFMA), which two waves share no better than one, and the A fragments are read twice.  4 stays.
+#endif
 #ifndef PIPE_CT256
 #define PIPE_CT256 2   // column tiles of 16 rows per wave of the D = 256 bf16 cross-entropy kernel (64 PIPE_CT256 rows per workgroup).
                        // 3 (48 rows per wave, a third less LDS traffic per MFMA) builds with a copy-free steady-state loop but 592 bytes
