@@ -2255,10 +2255,13 @@ int catalog_argmax_screened(const float* x, int64_t R, const uint16_t* Eb, const
     // generate step, N = 10^5, paid two full bf16 passes: 448 + 594 us of a 1.36 ms batch in the kernel trace,
     // profiles/r06_config3_generate_kernel_stats_before.csv.  The candidates per row, ~N / Ns, cost pass B rescoring time, and
     // relatively more so on a SHORT catalog pass: below 262144 items the prefix is N / 4 (sweep: profiles/r06_screen_prefix_sweep.txt).
-    // PCVAE_SCREEN_PREFIX_MIN_ITEMS / PCVAE_SCREEN_PREFIX_DIV move the switch / the short catalogs' divisor for A/B measurements.)
+    // PCVAE_SCREEN_PREFIX_MIN_ITEMS / PCVAE_SCREEN_PREFIX_DIV / PCVAE_SCREEN_PREFIX_DIV_LARGE move the switch / the short catalogs' divisor /
+    // the long catalogs' divisor for A/B measurements.)
     static const int64_t prefix_min = [] { const char* e = getenv("PCVAE_SCREEN_PREFIX_MIN_ITEMS"); return e ? atoll(e) : 65536LL; }();
     static const int64_t prefix_div = [] { const char* e = getenv("PCVAE_SCREEN_PREFIX_DIV"); return e && atoll(e) > 0 ? atoll(e) : 4LL; }();
-    const int64_t Ns = N >= 262144 ? (N / 16) / 128 * 128 : N >= prefix_min ? (N / prefix_div) / 128 * 128 : N;
+    // (long catalogs, config 4, round 6: N / 8 17.76, N / 12 17.35, N / 16 17.3, N / 24 17.2, N / 32 17.1-17.25 ms per batch - flat; 16 stays)
+    static const int64_t prefix_div_large = [] { const char* e = getenv("PCVAE_SCREEN_PREFIX_DIV_LARGE"); return e && atoll(e) > 0 ? atoll(e) : 16LL; }();
+    const int64_t Ns = N >= 262144 ? (N / prefix_div_large) / 128 * 128 : N >= prefix_min ? (N / prefix_div) / 128 * 128 : N;
     // the screen kernels always run 256-row workgroups: plan them as the D = 128 case
     // Two workgroups per CU at D = 64: a lone wave per SIMD issues one instruction per ~5.5 cycles and an MFMA per 17.5, two waves share
     // the SIMD at ~2.7 and 16.5 (tools/valu_rate_probe.hip) - and a D = 64 screening slot is mostly bookkeeping (16 MFMAs + 41 other
