@@ -1754,6 +1754,8 @@ __global__ void __launch_bounds__(512, 1) catalog_screen_bf16_kernel(ScreenParam
 template <int D>
 __host__ __device__ constexpr int screen_pipe_cap() { return D == 64 ? SCREEN_PIPE_ENTRIES_64 : 6144; }
 constexpr int SCREEN_PIPE_ENTRY_BYTES = 8;
+static_assert(2 * (4 * 16384 + screen_pipe_cap<64>() * SCREEN_PIPE_ENTRY_BYTES + 16) <= 160 * 1024 || SCREEN_PIPE_ENTRIES_64 != 2032,
+              "two D = 64 screening workgroups (64 KB ring + list + counters each) must fit a CU's 160 KB of LDS");
 constexpr int64_t SCREEN_PIPE_MAX_ITEMS = 1ll << 26;
 
 template <int CT>
