@@ -2206,10 +2206,11 @@ int catalog_ce_bf16(const float* rx, int64_t R, const uint16_t* E, int64_t N, in
 // ranges of at least this many 32-item tiles take the software-pipelined screening kernels.  PCVAE_PIPE_MIN_TILES (read per launch) moves
 // the threshold: the tests force the pipelined kernels onto small shapes with it.
 // (D = 64, round 6: from 128 tiles per range - the quarter-catalog prefix pass of config 3's generate step takes the pipelined
-// kernel too: 1.09 -> 1.05 ms per batch, same ids)
+// kernel too: 1.09 -> 1.05 ms per batch, same ids; then, with two workgroups per CU, from 96: the pivot stage's 4096 rows plan 512
+// workgroups of 98 tiles - 70 -> 54 us; sweep 128 / 96 / 64 / 48: 0.770 / 0.753 / 0.762 / 0.760 ms per batch)
 static int screen_pipe_min(int D) {
     const char* env_min = getenv("PCVAE_PIPE_MIN_TILES");
-    return env_min ? atoi(env_min) : (D == 64 ? 128 : 512);
+    return env_min ? atoi(env_min) : (D == 64 ? 96 : 512);
 }
 
 template <int D>
