@@ -322,12 +322,47 @@ def generate_throughput(model, cfg, device, iters=3):
                 model.recommend(ctx, u, return_item=True, eps=eps)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(iters):
+                items, _ = model.recommend(ctx, u, return_item=True, eps=eps)
+                torch.cuda.synchronize()
+                n_it = max(iters, min(200, int(0.05 / max(time.perf_counter() - t0, 1e-6))))   # ~50 ms of batches (a batch is 0.2 .. 40 ms)
+                t0 = time.perf_counter()
+                for _ in range(n_it):
                     items, _ = model.recommend(ctx, u, return_item=True, eps=eps)
                 torch.cuda.synchronize()
-                dt = (time.perf_counter() - t0) / iters
+                dt = (time.perf_counter() - t0) / n_it
             ids[name] = items
-            res[name] = {"slates_per_s": B / dt, "ms_per_batch": dt * 1e3, "algorithmic_TFLOPs": flops / dt / 1e12}
+            res[name] = {"slates_per_s": B / dt, "ms_per_batch": dt * 1e3, "algorithmic_TFLOPs": flops / dt / 1e12, "launch": "eager",
+                         "batches_timed": n_it}
+        # the same chain (~33 launches) captured once as a hipGraph and replayed - what the in-loop evaluation does
+        # (train_generative.recommendation_test(capture_graph=True)); it pays where the batch is launch-bound (configs 1-2)
+        ops.SCREENED_MIN_ITEMS = saved
+        try:
+            with torch.no_grad():
+                warm = {}
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side), ops.workspace_holder(warm):
+                    for _ in range(2):
+                        model.recommend(ctx, u, return_item=True, eps=eps)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, capture_error_mode="thread_local"), ops.workspace_holder(warm):
+                    items_g, _ = model.recommend(ctx, u, return_item=True, eps=eps)
+                gr.replay()
+                torch.cuda.synchronize()
+                n_it = res["screened"]["batches_timed"]
+                t0 = time.perf_counter()
+                for _ in range(n_it):
+                    gr.replay()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / n_it
+            res["graph"] = {"slates_per_s": B / dt, "ms_per_batch": dt * 1e3, "algorithmic_TFLOPs": flops / dt / 1e12,
+                            "launch": "hipGraph replay", "batches_timed": n_it, "ids_identical_to_eager": bool(torch.equal(items_g, ids["screened"]))}
+            del gr
+        except Exception as e:   # a measurement beside the eager one: say why it is missing
+            torch.cuda.synchronize()
+            res["graph"] = {"error": f"{type(e).__name__}: {e}"[:200]}
     finally:
         ops.SCREENED_MIN_ITEMS = saved
     # how many of the generated ids are NOT decided beyond fp32 rounding (top-2 margin <= 1e-5: the qualification SURVEY 7 attaches
@@ -355,12 +390,16 @@ def generate_throughput(model, cfg, device, iters=3):
                   "ids_equal_fp64_argmax_on_all_rows": bool(torch.equal(got, arg))}
     screened = cfg["D"] in ops.BF16_DIMS and cfg["N"] >= saved
     best = res["screened"]
+    g_ok = "slates_per_s" in res.get("graph", {}) and res["graph"]["ids_identical_to_eager"]
+    if g_ok and res["graph"]["slates_per_s"] > best["slates_per_s"]:
+        best = res["graph"]   # `value` = the faster of the two launch forms, named in `launch`
     # the screening pass does the algorithmic 2*R*N*D flops once over the whole catalog (+1/16 for the prefix pass)
     peak = PEAK_TFLOPS["bf16"] if screened else PEAK_TFLOPS["f32"]
     return {"value": best["slates_per_s"], "unit": "slates/s", "ms_per_batch": best["ms_per_batch"],
             "arithmetic": ("bf16 MFMA screening + exact fp32 rescoring (bit-exact greedy ids)" if screened
                            else "f32 MFMA (bit-exact greedy ids)"),
             "achieved_TFLOPs": best["algorithmic_TFLOPs"], "peak_TFLOPs": peak, "frac": best["algorithmic_TFLOPs"] / peak,
+            "launch": best["launch"], "eager": res["screened"], "graph_replay": res.get("graph"),
             "f32_kernel": res["f32"], "ids_identical_to_f32_kernel": bool(torch.equal(ids["screened"], ids["f32"])),
             "margin_safety": margin}
 
